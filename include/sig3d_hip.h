@@ -1,0 +1,145 @@
+/*
+ * include/sig3d_hip.h -- C ABI of libsig3d_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the SIG3D hot path.  Every entry point is extern "C",
+ * takes plain device pointers + sizes + an explicit HIP stream (void* == hipStream_t) and
+ * returns an int status (0 == hipSuccess, otherwise the hipError_t value; the message is
+ * available from sig3d_last_error()).  No torch / ATen types cross this boundary.
+ *
+ * Each function replaces one host->kernel wrapper of the reference
+ * (YunzeMan/Situation3D, paths relative to the reference root).  Differences from the
+ * reference wrappers, all deliberate:
+ *   - explicit stream argument (the reference takes at::cuda::getCurrentCUDAStream()
+ *     implicitly, e.g. lib/pointnet2/_ext_src/src/ball_query_gpu.cu:49);
+ *   - int status return instead of fprintf+exit(-1) (include/cuda_utils.h:30-39);
+ *   - outputs that the reference host code zero-initialises (torch::zeros) are
+ *     zero-initialised INSIDE these calls (hipMemsetAsync on the same stream), so callers
+ *     may pass uninitialised buffers.
+ * All pointers are device pointers; float == IEEE binary32, int == int32.
+ * All calls are asynchronous on `stream`, re-entrant, and keep no global state.
+ */
+#ifndef SIG3D_HIP_H
+#define SIG3D_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library info ------------------------------------------------------------------ */
+const char *sig3d_version(void);          /* "sig3d-hip <semver> gfx950" */
+const char *sig3d_last_error(void);       /* thread-local message of the last failing call */
+
+/* ---- PointNet++ ops: lib/pointnet2/_ext_src ------------------------------------------ */
+
+/* replaces furthest_point_sampling_kernel_wrapper(b,n,m,dataset,temp,idxs)
+ *   lib/pointnet2/_ext_src/src/sampling.cpp:11-13, sampling_gpu.cu:175-229
+ * dataset (b,n,3) -> idxs (b,m).  temp (b,n) is scratch; it is (re)initialised here
+ * (the reference fills it with 1e10 in sampling.cpp:74-76).  Bit-exact winner selection,
+ * including the reference's tie-break order and its `mag <= 1e-3` skip rule. */
+int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
+                                  int *idxs, void *stream);
+
+/* replaces gather_points_kernel_wrapper(b,c,n,npoints,points,idx,out)
+ *   sampling.cpp:4-6, sampling_gpu.cu:8-31.   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
+int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,
+                        const int *idx, float *out, void *stream);
+
+/* replaces gather_points_grad_kernel_wrapper(b,c,n,npoints,grad_out,idx,grad_points)
+ *   sampling.cpp:7-9, sampling_gpu.cu:34-57.  grad_points (b,c,n) is zeroed here. */
+int sig3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                             const int *idx, float *grad_points, void *stream);
+
+/* replaces query_ball_point_kernel_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)
+ *   ball_query.cpp:4-6, ball_query_gpu.cu:9-54.
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): first `nsample` points (in index
+ * order) with d2 < radius*radius, padded with the first hit; all-zero row when no hit. */
+int sig3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                     const float *xyz, int *idx, void *stream);
+
+/* replaces group_points_kernel_wrapper(b,c,n,npoints,nsample,points,idx,out)
+ *   group_points.cpp:4-6, group_points_gpu.cu:8-39.
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+int sig3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                       const int *idx, float *out, void *stream);
+
+/* replaces group_points_grad_kernel_wrapper(b,c,n,npoints,nsample,grad_out,idx,grad_points)
+ *   group_points.cpp:8-10, group_points_gpu.cu:43-75.  grad_points (b,c,n) is zeroed here. */
+int sig3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                            const float *grad_out, const int *idx, float *grad_points,
+                            void *stream);
+
+/* replaces three_nn_kernel_wrapper(b,n,m,unknown,known,dist2,idx)
+ *   interpolate.cpp:4-5, interpolate_gpu.cu:9-68.
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances ascending, idx (b,n,3) */
+int sig3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                   float *dist2, int *idx, void *stream);
+
+/* replaces three_interpolate_kernel_wrapper(b,c,m,n,points,idx,weight,out)
+ *   interpolate.cpp:6-8, interpolate_gpu.cu:72-111.
+ * points (b,c,m), idx (b,n,3), weight (b,n,3) -> out (b,c,n) */
+int sig3d_three_interpolate(int b, int c, int m, int n, const float *points,
+                            const int *idx, const float *weight, float *out, void *stream);
+
+/* replaces three_interpolate_grad_kernel_wrapper(b,c,n,m,grad_out,idx,weight,grad_points)
+ *   interpolate.cpp:9-12, interpolate_gpu.cu:116-154.  grad_points (b,c,m) is zeroed here. */
+int sig3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                 const int *idx, const float *weight, float *grad_points,
+                                 void *stream);
+
+/* ---- fused grouping (the path QueryAndGroup.forward takes) ---------------------------- */
+
+/* Fuses lib/pointnet2/pointnet2_utils.py:348-359 (QueryAndGroup.forward after ball_query):
+ *   grouped_xyz = group(xyz^T, idx) - new_xyz^T[..., None]  [ / radius if normalize ]
+ *   new_features = cat([grouped_xyz, group(features, idx)], dim=1)
+ * xyz (b,n,3), new_xyz (b,m,3), features (b,c,n) or NULL (c == 0), idx (b,m,nsample)
+ * -> out (b, (use_xyz?3:0)+c, m, nsample).  inv_radius = 1/radius when normalize_xyz else 1
+ * (division is performed as `/ radius`, not a multiply, to stay bit-identical: pass radius). */
+int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, int use_xyz,
+                            int normalize_xyz, float radius, const float *xyz,
+                            const float *new_xyz, const float *features, const int *idx,
+                            float *out, void *stream);
+
+/* Backward of the feature half of sig3d_query_group_fused: grad_out (b,c_total,m,nsample)
+ * with channel offset c_off -> grad_features (b,c,n) (zeroed here). */
+int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_total,
+                                 int c_off, const float *grad_out, const int *idx,
+                                 float *grad_features, void *stream);
+
+/* ---- situational pose re-encode -------------------------------------------------------- */
+
+/* replaces situation3d/utils/temp.py:42-97 (batch_matrix_function + homogeneous bmm):
+ * pose (b,7) = [tx,ty,tz, qx,qy,qz,qw]; points (b,n,3) -> out (b,n,3) = R(q) p + t with
+ * R exactly as written in temp.py:63-73 (x2-y2-z2+w2 form, no normalisation).
+ * inverse != 0 computes the agent-frame map R^T (p - t) instead (not in the reference). */
+int sig3d_situational_transform(int b, int n, const float *pose, const float *points,
+                                float *out, int inverse, void *stream);
+
+/* Backward: grad_out (b,n,3) -> grad_points (b,n,3) and grad_pose (b,7) (zeroed here). */
+int sig3d_situational_transform_grad(int b, int n, const float *pose, const float *points,
+                                     const float *grad_out, float *grad_points,
+                                     float *grad_pose, int inverse, void *stream);
+
+/* ---- Q-Former attention ---------------------------------------------------------------- */
+
+/* replaces BertSelfAttention.forward's core
+ *   3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py:185-223
+ * context = softmax(Q K^T * scale + mask) V  per (batch, head), fp32, exact-f32 MFMA.
+ * q (b,h,nq,d), k (b,h,nk,d), v (b,h,nk,d) contiguous; mask additive (b,nk) or NULL
+ * (the reference's (B,1,1,Nk) extended mask, Qformer.py:700-732); d must be 64.
+ * out (b,nq,h*d) -- already in the permuted "context_layer" layout of Qformer.py:225-227.
+ * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL). */
+int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
+                        const float *k, const float *v, const float *mask, float *out,
+                        float *lse, void *stream);
+
+/* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
+ * -> dq (b,h,nq,d), dk (b,h,nk,d), dv (b,h,nk,d). */
+int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
+                        const float *k, const float *v, const float *mask,
+                        const float *out, const float *lse, const float *grad_out,
+                        float *dq, float *dk, float *dv, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIG3D_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libsig3d_hip.so -- the only way product code reaches the HIP kernels.
+
+The library is looked up in-tree (next to this file).  There is NO CPU fallback: if the
+shared object is missing or a symbol cannot be resolved this raises, and every op that needs
+it fails loudly.  Mirrors the C ABI declared in include/sig3d_hip.h.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsig3d_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+
+# name -> argtypes (restype is int status everywhere); order == include/sig3d_hip.h
+SIGNATURES = {
+    "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "sig3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "sig3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "sig3d_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sig3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sig3d_query_group_fused": [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "sig3d_query_group_fused_grad": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_situational_transform": [_I, _I, _P, _P, _P, _I, _P],
+    "sig3d_situational_transform_grad": [_I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "sig3d_attention_fwd": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+}
+INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error")
+
+_lib = None
+
+
+class Sig3dError(RuntimeError):
+    """A libsig3d_hip call returned a non-zero status (the reference raises RuntimeError via
+    AT_ASSERT for argument errors; kernel failures there exit(-1), cuda_utils.h:30-39)."""
+
+
+def load():
+    """Load the shared library (no GPU needed to load or to resolve symbols)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsig3d_hip.so not found at %s -- build it with `python -m situation3d_amd.build` "
+            "(there is no CPU fallback for the HIP hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.sig3d_version.restype = ctypes.c_char_p
+    lib.sig3d_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().sig3d_version().decode()
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream on `device`."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def call(name, *args):
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if status != 0:
+        raise Sig3dError("%s failed: %s" % (name, lib.sig3d_last_error().decode()))
+
+
+def require_device(*tensors):
+    """The reference asserts "CPU not supported" for host tensors (e.g. ball_query.cpp:27-29)."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("CPU not supported")
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    return dev

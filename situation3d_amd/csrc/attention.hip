@@ -1,0 +1,355 @@
+// attention.hip -- Q-Former attention core (forward + backward) on exact-f32 MFMA for gfx950.
+//
+// Replaces the score/softmax/context part of BertSelfAttention.forward
+// (3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py:185-227):
+//   context = softmax(Q K^T / sqrt(d) + mask) V,   d = 64, few queries (32 / 52), many keys.
+// The reference materialises the (B,12,Nq,Nk) score tensor in HBM three times (scores, probs,
+// dropped probs); here scores never leave registers (streaming softmax over 32-key tiles).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is an exact f32 fma chain (no bf16/tf32 rounding), which is
+// what keeps the 1e-4 activation bar of the north star.  Peak for this instruction is the f32
+// matrix rate (157 TFLOP/s), not the bf16 one.
+//
+// Layout trick (CDNA MFMA C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)):
+// the forward pass computes the TRANSPOSED tiles S^T = K Q^T and O^T = V^T P^T, so a query row
+// is always a lane (col) and keys/features run over registers.  Row max / row sum / rescale
+// are then in-lane VALU work plus one swap with lane^32 -- no LDS, no cross-lane reduction
+// trees -- and the exponentiated S^T accumulator registers ARE the B operand of the PV MFMA
+// (contraction over keys == contraction over the accumulator's row index).
+// The reduction index of every MFMA is permuted (k-step s covers d = s and d = 32+s): sums are
+// reassociated relative to a sequential dot product, well inside the f32 tolerance.
+#include "sig3d_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT_D = 64;       // head size (Qformer.py:112: 768 / 12)
+constexpr int AT_WAVES = 4;    // waves per workgroup, each streams every 4th key tile
+constexpr int AT_NQ_MAX = 128; // backward keeps per-row statistics / dQ of one head in LDS
+
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// lane (row = l31, half) <- 32 contiguous floats base[row*stride + half*32 ...]; zero when !valid
+__device__ __forceinline__ void load_half_row(float (&f)[32], const float *base, long row,
+                                              long stride, int half, bool valid) {
+  if (valid) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * stride + half * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 t = p[i];
+      f[4 * i + 0] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) f[i] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: grid (q_tiles, h, b), 256 threads.
+__global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
+    int h, int nq, int nk, float scale, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const float *__restrict__ mask, float *__restrict__ out,
+    float *__restrict__ lse) {
+  __shared__ float s_o[AT_WAVES][AT_D][32];
+  __shared__ float s_m[AT_WAVES][32];
+  __shared__ float s_l[AT_WAVES][32];
+
+  const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
+  const float *Q = q + ((size_t)(bi * h + hi) * nq) * AT_D;
+  const float *K = k + ((size_t)(bi * h + hi) * nk) * AT_D;
+  const float *V = v + ((size_t)(bi * h + hi) * nk) * AT_D;
+  const float *M = mask ? mask + (size_t)bi * nk : nullptr;
+
+  float qf[32];
+  load_half_row(qf, Q, q0 + l31, AT_D, half, q0 + l31 < nq);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 o0 = {0}, o1 = {0};
+  const int ntiles = (nk + 31) / 32;
+  for (int t = wave; t < ntiles; t += AT_WAVES) {
+    const int key0 = t * 32;
+    float kf[32];
+    load_half_row(kf, K, min(key0 + l31, nk - 1), AT_D, half, true);
+    f32x16 st = {0};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
+    float p[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + mfma_row(r, half);
+      float sv = st[r] * scale;                     // Qformer.py:207 (/ sqrt(64) == * 0.125)
+      if (M) sv += M[min(key, nk - 1)];             // Qformer.py:210
+      sv = key < nk ? sv : -INFINITY;
+      p[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __expf(p[r] - m_new);
+      rs += p[r];
+    }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
+      const int key = min(key0 + mfma_row(s, half), nk - 1);
+      const float a0 = V[(size_t)key * AT_D + l31];
+      const float a1 = V[(size_t)key * AT_D + 32 + l31];
+      o0 = mfma32(a0, p[s], o0);
+      o1 = mfma32(a1, p[s], o1);
+    }
+  }
+
+  // combine the AT_WAVES partial (m, l, O^T) triples
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s_o[wave][mfma_row(r, half)][l31] = o0[r];
+    s_o[wave][32 + mfma_row(r, half)][l31] = o1[r];
+  }
+  if (half == 0) {
+    s_m[wave][l31] = m_run;
+    s_l[wave][l31] = l_run;
+  }
+  __syncthreads();
+  {
+    const int qq = threadIdx.x & 31, dg = threadIdx.x >> 5;  // 8 d-groups of 8 features
+    float mt = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < AT_WAVES; ++w) mt = fmaxf(mt, s_m[w][qq]);
+    float wgt[AT_WAVES], lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < AT_WAVES; ++w) {
+      wgt[w] = __expf(s_m[w][qq] - mt);  // waves without a tile: exp(-inf) = 0
+      lt += s_l[w][qq] * wgt[w];
+    }
+    const float inv = 1.f / lt;
+    if (q0 + qq < nq) {
+      float res[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * 8 + i][qq] * wgt[w];
+        res[i] = acc * inv;
+      }
+      // context_layer.permute(0,2,1,3).view(B, Nq, 768)  (Qformer.py:225-227)
+      float *o = out + ((size_t)bi * nq + q0 + qq) * (size_t)(h * AT_D) + hi * AT_D + dg * 8;
+      *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+      *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
+      if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: grid (key_splits, h, b), 256 threads.  A wave owns whole 32-key tiles, so dK / dV
+// are plain stores; dQ is reduced in LDS per workgroup (and with atomics across key splits).
+__global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
+    int h, int nq, int nk, float scale, int tiles_per_split, int atomic_dq,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
+    const float *__restrict__ grad_out, float *__restrict__ dq, float *__restrict__ dk,
+    float *__restrict__ dv) {
+  __shared__ float s_D[AT_NQ_MAX];
+  __shared__ float s_lse[AT_NQ_MAX];
+  __shared__ float s_T[AT_WAVES][32][33];
+  __shared__ float s_dq[AT_NQ_MAX][AT_D + 1];
+
+  const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int hi = blockIdx.y, bi = blockIdx.z;
+  const size_t bh = (size_t)(bi * h + hi);
+  const float *Q = q + bh * nq * AT_D;
+  const float *K = k + bh * nk * AT_D;
+  const float *V = v + bh * nk * AT_D;
+  const float *M = mask ? mask + (size_t)bi * nk : nullptr;
+  const size_t ostride = (size_t)h * AT_D;
+  const float *O = out + (size_t)bi * nq * ostride + hi * AT_D;        // row q at O + q*ostride
+  const float *dO = grad_out + (size_t)bi * nq * ostride + hi * AT_D;
+
+  // D[q] = sum_d dO[q][d] * O[q][d]; two threads per row
+  {
+    const int qq = threadIdx.x >> 1, hh = threadIdx.x & 1;
+    float part = 0.f;
+    if (qq < nq) {
+      const float4 *a = reinterpret_cast<const float4 *>(dO + (size_t)qq * ostride + hh * 32);
+      const float4 *c = reinterpret_cast<const float4 *>(O + (size_t)qq * ostride + hh * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 x = a[i], y = c[i];
+        part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+    }
+    part += __shfl_xor(part, 1);
+    if (hh == 0 && qq < AT_NQ_MAX) {
+      s_D[qq] = qq < nq ? part : 0.f;
+      s_lse[qq] = qq < nq ? lse[bh * nq + qq] : 0.f;
+    }
+    for (int i = threadIdx.x; i < AT_NQ_MAX * (AT_D + 1); i += AT_WAVES * 64) (&s_dq[0][0])[i] = 0.f;
+  }
+  __syncthreads();
+
+  const int ntiles = (nk + 31) / 32;
+  const int t_begin = blockIdx.x * tiles_per_split;
+  const int t_end = min(ntiles, t_begin + tiles_per_split);
+  const int nqt = (nq + 31) / 32;
+
+  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+    const int key0 = t * 32;
+    const int krow = min(key0 + l31, nk - 1);
+    const bool key_ok = key0 + l31 < nk;
+    float kf[32], vf[32];
+    load_half_row(kf, K, krow, AT_D, half, true);
+    load_half_row(vf, V, krow, AT_D, half, true);
+    const float mk = M ? M[krow] : 0.f;
+    f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
+
+    for (int qt = 0; qt < nqt; ++qt) {
+      const int q0 = qt * 32;
+      float fr[32];
+      load_half_row(fr, Q, q0 + l31, AT_D, half, q0 + l31 < nq);
+      f32x16 sacc = {0};
+#pragma unroll
+      for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + mfma_row(r, half);
+        const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq, AT_NQ_MAX - 1)]);
+        p[r] = (key_ok && qq < nq) ? e : 0.f;
+      }
+      load_half_row(fr, dO, q0 + l31, (long)ostride, half, q0 + l31 < nq);
+      f32x16 dpacc = {0};
+#pragma unroll
+      for (int s = 0; s < 32; ++s) dpacc = mfma32(fr[s], vf[s], dpacc);  // dP[q][key]
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + mfma_row(r, half);
+        ds[r] = p[r] * (dpacc[r] - s_D[min(qq, AT_NQ_MAX - 1)]);
+      }
+      // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int qq = min(q0 + mfma_row(s, half), nq - 1);
+        const float g0 = dO[(size_t)qq * ostride + l31], g1 = dO[(size_t)qq * ostride + 32 + l31];
+        const float x0 = Q[(size_t)qq * AT_D + l31], x1 = Q[(size_t)qq * AT_D + 32 + l31];
+        dvt0 = mfma32(g0, p[s], dvt0);
+        dvt1 = mfma32(g1, p[s], dvt1);
+        dkt0 = mfma32(x0, ds[s], dkt0);
+        dkt1 = mfma32(x1, ds[s], dkt1);
+      }
+      // dQ^T[d][q] = K^T[d][key] dS^T[key][q]: transpose the dS tile through wave-private LDS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_T[wave][l31][mfma_row(r, half)] = ds[r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      f32x16 dqt0 = {0}, dqt1 = {0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int kk = mfma_row(s, half);
+        const int key = min(key0 + kk, nk - 1);
+        const float bq = s_T[wave][kk][l31];
+        dqt0 = mfma32(K[(size_t)key * AT_D + l31], bq, dqt0);
+        dqt1 = mfma32(K[(size_t)key * AT_D + 32 + l31], bq, dqt1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (q0 + l31 < nq) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          atomicAdd(&s_dq[q0 + l31][mfma_row(r, half)], dqt0[r]);
+          atomicAdd(&s_dq[q0 + l31][32 + mfma_row(r, half)], dqt1[r]);
+        }
+      }
+    }
+    if (key_ok) {
+      float *dvp = dv + (bh * nk + key0 + l31) * AT_D;
+      float *dkp = dk + (bh * nk + key0 + l31) * AT_D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
+        const int d = 8 * g + 4 * half;
+        *reinterpret_cast<float4 *>(dvp + d) = make_float4(dvt0[4 * g], dvt0[4 * g + 1], dvt0[4 * g + 2], dvt0[4 * g + 3]);
+        *reinterpret_cast<float4 *>(dvp + 32 + d) = make_float4(dvt1[4 * g], dvt1[4 * g + 1], dvt1[4 * g + 2], dvt1[4 * g + 3]);
+        *reinterpret_cast<float4 *>(dkp + d) = make_float4(dkt0[4 * g] * scale, dkt0[4 * g + 1] * scale, dkt0[4 * g + 2] * scale, dkt0[4 * g + 3] * scale);
+        *reinterpret_cast<float4 *>(dkp + 32 + d) = make_float4(dkt1[4 * g] * scale, dkt1[4 * g + 1] * scale, dkt1[4 * g + 2] * scale, dkt1[4 * g + 3] * scale);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
+    const int qq = i / AT_D, d = i % AT_D;
+    const float val = s_dq[qq][d] * scale;
+    if (atomic_dq) unsafeAtomicAdd(dq + bh * nq * AT_D + i, val);
+    else dq[bh * nq * AT_D + i] = val;
+  }
+}
+
+}  // namespace
+
+extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale,
+                                   const float *q, const float *k, const float *v,
+                                   const float *mask, float *out, float *lse, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
+  SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
+  if (b == 0 || h == 0 || nq == 0) return 0;
+  SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
+  dim3 grid((nq + 31) / 32, h, b);
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
+                     q, k, v, mask, out, lse);
+  SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale,
+                                   const float *q, const float *k, const float *v,
+                                   const float *mask, const float *out, const float *lse,
+                                   const float *grad_out, float *dq, float *dk, float *dv,
+                                   void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
+  SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
+  SIG3D_REQUIRE(nq <= AT_NQ_MAX, "attention backward supports at most 128 query rows");
+  if (b == 0 || h == 0 || nq == 0) return 0;
+  SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
+  const int ntiles = (nk + 31) / 32;
+  // enough workgroups to cover the chip, but at least AT_WAVES tiles per workgroup
+  int splits = 1;
+  const long bh = (long)b * h;
+  if (bh < 512) {
+    splits = (int)((1024 + bh - 1) / bh);
+    const int max_splits = (ntiles + AT_WAVES - 1) / AT_WAVES;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  const int tiles_per_split = (ntiles + splits - 1) / splits;
+  splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
+  if (splits > 1)
+    SIG3D_HIP_TRY(hipMemsetAsync(dq, 0, sizeof(float) * (size_t)b * h * nq * AT_D, stream));
+  dim3 grid(splits, h, b);
+  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
+                     tiles_per_split, splits > 1 ? 1 : 0, q, k, v, mask, out, lse, grad_out, dq, dk,
+                     dv);
+  SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
+  return 0;
+}

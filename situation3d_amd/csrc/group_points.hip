@@ -1,0 +1,214 @@
+// group_points.hip -- neighbourhood gather / scatter-add for gfx950.
+//
+// Replaces lib/pointnet2/_ext_src/src/group_points_gpu.cu of the reference and fuses the
+// follow-up elementwise passes of QueryAndGroup.forward (pointnet2_utils.py:348-359).
+//
+// These kernels are HBM-write bound: the grouped tensor (b, c, npoints, nsample) is the
+// dominant traffic of the whole point encoder.  The reference launches ONE block per batch
+// element; here the (npoints*nsample) axis is spread over the grid, each lane owns FOUR
+// consecutive samples (16-byte idx load, 16-byte stores), and walks a slab of channels with
+// its four neighbour indices held in registers, so idx is read once per slab instead of once
+// per channel.  The gathered rows (n floats per channel) are L2-resident.
+#include "sig3d_common.h"
+
+namespace {
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_CSLAB = 8;  // channels walked per workgroup (idx reuse factor)
+
+// out[b,l,e] = points[b,l,idx[b,e]], e over npoints*nsample (vector path: total % 4 == 0)
+template <bool VEC4>
+__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
+    int c, int n, long total, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out) {
+  const int bi = blockIdx.z;
+  const long e = ((long)blockIdx.x * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
+  if (e >= total) return;
+  const int *ip = idx + (size_t)bi * total + e;
+  const int l0 = blockIdx.y * GP_CSLAB;
+  const int l1 = min(l0 + GP_CSLAB, c);
+  if (VEC4) {
+    const int4 ii = *reinterpret_cast<const int4 *>(ip);
+    for (int l = l0; l < l1; ++l) {
+      const float *row = points + ((size_t)bi * c + l) * n;
+      float4 v;
+      v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
+      *reinterpret_cast<float4 *>(out + ((size_t)bi * c + l) * total + e) = v;
+    }
+  } else {
+    const int ii = *ip;
+    for (int l = l0; l < l1; ++l)
+      out[((size_t)bi * c + l) * total + e] = points[((size_t)bi * c + l) * n + ii];
+  }
+}
+
+// grad_points[b,l,idx[b,e]] += grad_out[b,c_off+l,e]   (hardware f32 atomics in L2)
+template <bool VEC4>
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_kernel(
+    int c, int n, long total, int c_total, int c_off, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_points) {
+  const int bi = blockIdx.z;
+  const long e = ((long)blockIdx.x * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
+  if (e >= total) return;
+  const int *ip = idx + (size_t)bi * total + e;
+  const int l0 = blockIdx.y * GP_CSLAB;
+  const int l1 = min(l0 + GP_CSLAB, c);
+  if (VEC4) {
+    const int4 ii = *reinterpret_cast<const int4 *>(ip);
+    for (int l = l0; l < l1; ++l) {
+      const float4 g = *reinterpret_cast<const float4 *>(
+          grad_out + ((size_t)bi * c_total + c_off + l) * total + e);
+      float *row = grad_points + ((size_t)bi * c + l) * n;
+      unsafeAtomicAdd(row + ii.x, g.x);
+      unsafeAtomicAdd(row + ii.y, g.y);
+      unsafeAtomicAdd(row + ii.z, g.z);
+      unsafeAtomicAdd(row + ii.w, g.w);
+    }
+  } else {
+    const int ii = *ip;
+    for (int l = l0; l < l1; ++l)
+      unsafeAtomicAdd(grad_points + ((size_t)bi * c + l) * n + ii,
+                      grad_out[((size_t)bi * c_total + c_off + l) * total + e]);
+  }
+}
+
+// Fused QueryAndGroup tail (pointnet2_utils.py:348-359): channels [0,3) = (xyz[idx] - centre)
+// [/ radius], channels [3, 3+c) = features[idx]; one pass, grouped tensor written once.
+// blockIdx.y == 0 handles the xyz slab (when use_xyz), the others feature slabs.
+template <bool VEC4>
+__global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
+    int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
+  const int bi = blockIdx.z;
+  const long total = (long)m * nsample;
+  const long e = ((long)blockIdx.x * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
+  if (e >= total) return;
+  const int c_total = (use_xyz ? 3 : 0) + c;
+  const int *ip = idx + (size_t)bi * total + e;
+  int ii[4];
+  if (VEC4) {
+    const int4 t = *reinterpret_cast<const int4 *>(ip);
+    ii[0] = t.x; ii[1] = t.y; ii[2] = t.z; ii[3] = t.w;
+  } else {
+    ii[0] = *ip;
+  }
+  constexpr int V = VEC4 ? 4 : 1;
+  int slab = blockIdx.y;
+  if (use_xyz) {
+    if (slab == 0) {
+      // nsample % 4 == 0 on the vector path, so the four samples share one centre
+      const int j = (int)(e / nsample);
+      const float *ctr = new_xyz + ((size_t)bi * m + j) * 3;
+      const float *pts = xyz + (size_t)bi * n * 3;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float v[4];
+        const float ca = ctr[a];
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          float t = __fsub_rn(pts[3 * (size_t)ii[q] + a], ca);  // grouped_xyz -= new_xyz  (:349)
+          if (normalize_xyz) t = __fdiv_rn(t, radius);           // grouped_xyz /= radius   (:351)
+          v[q] = t;
+        }
+        float *o = out + ((size_t)bi * c_total + a) * total + e;
+        if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else *o = v[0];
+      }
+      return;
+    }
+    slab -= 1;
+  }
+  const int l0 = slab * GP_CSLAB;
+  const int l1 = min(l0 + GP_CSLAB, c);
+  const int c_off = use_xyz ? 3 : 0;
+  for (int l = l0; l < l1; ++l) {
+    const float *row = features + ((size_t)bi * c + l) * n;
+    float *o = out + ((size_t)bi * c_total + c_off + l) * total + e;
+    if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(row[ii[0]], row[ii[1]], row[ii[2]], row[ii[3]]);
+    else *o = row[ii[0]];
+  }
+}
+
+}  // namespace
+
+extern "C" int sig3d_group_points(int b, int c, int n, int npoints, int nsample,
+                                  const float *points, const int *idx, float *out,
+                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "negative size");
+  const long total = (long)npoints * nsample;
+  if (b == 0 || c == 0 || total == 0) return 0;
+  SIG3D_REQUIRE(n >= 1, "group_points: n must be >= 1 when idx is non-empty");
+  const bool vec = (total % 4 == 0);
+  dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS), sig3d_ceil_div(c, GP_CSLAB), b);
+  if (vec)
+    hipLaunchKernelGGL((group_points_kernel<true>), grid, dim3(GP_THREADS), 0, stream, c, n, total,
+                       points, idx, out);
+  else
+    hipLaunchKernelGGL((group_points_kernel<false>), grid, dim3(GP_THREADS), 0, stream, c, n, total,
+                       points, idx, out);
+  SIG3D_LAUNCH_CHECK("group_points_kernel");
+  return 0;
+}
+
+static int launch_group_grad(int b, int c, int n, long total, int c_total, int c_off,
+                             const float *grad_out, const int *idx, float *grad_points,
+                             hipStream_t stream) {
+  SIG3D_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream));
+  if (total == 0) return 0;
+  const bool vec = (total % 4 == 0);
+  dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS), sig3d_ceil_div(c, GP_CSLAB), b);
+  if (vec)
+    hipLaunchKernelGGL((group_points_grad_kernel<true>), grid, dim3(GP_THREADS), 0, stream, c, n,
+                       total, c_total, c_off, grad_out, idx, grad_points);
+  else
+    hipLaunchKernelGGL((group_points_grad_kernel<false>), grid, dim3(GP_THREADS), 0, stream, c, n,
+                       total, c_total, c_off, grad_out, idx, grad_points);
+  SIG3D_LAUNCH_CHECK("group_points_grad_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                       const float *grad_out, const int *idx,
+                                       float *grad_points, void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "negative size");
+  if (b == 0 || c == 0 || n == 0) return 0;
+  return launch_group_grad(b, c, n, (long)npoints * nsample, c, 0, grad_out, idx, grad_points,
+                           (hipStream_t)stream_);
+}
+
+extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, int use_xyz,
+                                       int normalize_xyz, float radius, const float *xyz,
+                                       const float *new_xyz, const float *features,
+                                       const int *idx, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0 && nsample >= 0, "negative size");
+  SIG3D_REQUIRE(use_xyz || c > 0, "Cannot have not features and not use xyz as a feature!");
+  SIG3D_REQUIRE(c == 0 || features != nullptr, "features pointer is NULL with c > 0");
+  const long total = (long)m * nsample;
+  if (b == 0 || total == 0) return 0;
+  SIG3D_REQUIRE(n >= 1, "query_group_fused: n must be >= 1 when idx is non-empty");
+  const bool vec = (nsample % 4 == 0);
+  dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS),
+            (use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB), b);
+  if (vec)
+    hipLaunchKernelGGL((query_group_fused_kernel<true>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+                       nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
+  else
+    hipLaunchKernelGGL((query_group_fused_kernel<false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+                       nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
+  SIG3D_LAUNCH_CHECK("query_group_fused_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample,
+                                            int c_total, int c_off, const float *grad_out,
+                                            const int *idx, float *grad_features,
+                                            void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0 && nsample >= 0, "negative size");
+  SIG3D_REQUIRE(c_off >= 0 && c_off + c <= c_total, "channel window out of range");
+  if (b == 0 || c == 0 || n == 0) return 0;
+  return launch_group_grad(b, c, n, (long)m * nsample, c_total, c_off, grad_out, idx,
+                           grad_features, (hipStream_t)stream_);
+}

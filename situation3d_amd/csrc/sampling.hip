@@ -1,0 +1,212 @@
+// sampling.hip -- furthest point sampling, gather_points and its gradient for gfx950.
+//
+// Replaces lib/pointnet2/_ext_src/src/sampling_gpu.cu of the reference (behaviour only; the
+// decomposition below is MI355X-specific).
+//
+// FPS design.  The reference re-reads the whole scene (xyz + temp, 20 B/point) from global
+// memory in every one of the m-1 dependent rounds and reduces through nine __syncthreads
+// steps.  Here a scene lives in the REGISTERS of one workgroup for the whole run (PPT points
+// per thread: x, y, z and the running min-distance), a round is one register sweep, two DPP
+// wave reductions and ONE barrier, and HBM is touched once at setup.  Scenes larger than the
+// register file keep their overflow tail in global memory (L2-resident).
+//
+// Bit-exactness.  The reference's winner is the point of maximal min-distance where ties are
+// resolved by its thread/tree decomposition (sampling_gpu.cu:95-168): a thread scans
+// k = tid, tid+bs, ... with a strict '>' (lowest k of its stride class wins), and every tree
+// step keeps the lower slot on ties, the LAST step (slot 0 vs 1) being the most significant.
+// That is a total order: maximise d2, then minimise key(k) = (bitrev_L(k mod bs), k div bs),
+// bs = opt_n_threads(n) (cuda_utils.h:13-19), L = log2(bs).  Because it is a total order, any
+// reduction shape that maximises (d2, -key) returns the reference's index; the key is packed
+// as (bitrev << 22) | (k >> L).  Points with x^2+y^2+z^2 <= 1e-3 (double compare, :100-101)
+// never take part: their running distance is pinned to -1, which also makes the all-skipped
+// case return index 0 as the reference does (best = -1, besti = 0).
+#include "sig3d_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned fps_key(unsigned k, int L, unsigned bsmask) {
+  const unsigned hi = L ? (__brev(k & bsmask) >> (32 - L)) : 0u;
+  return (hi << 22) | (k >> L);
+}
+__device__ __forceinline__ unsigned fps_unkey(unsigned key, int L) {
+  const unsigned hi = key >> 22, lo = key & 0x3FFFFFu;
+  const unsigned low = L ? (__brev(hi) >> (32 - L)) : 0u;
+  return (lo << L) | low;
+}
+
+// NT threads per workgroup (multiple of the reference block size bs, so that ascending
+// register slot == ascending key inside a thread), PPT register-resident points per thread.
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int L,
+                                                 const float *__restrict__ dataset_all,
+                                                 float *__restrict__ temp_all,
+                                                 int *__restrict__ idxs_all) {
+  constexpr int NW = NT / 64;
+  __shared__ int s_val[2][NW];
+  __shared__ unsigned s_key[2][NW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *dataset = dataset_all + (size_t)blockIdx.x * n * 3;
+  float *temp = temp_all + (size_t)blockIdx.x * n;
+  int *idxs = idxs_all + (size_t)blockIdx.x * m;
+  const unsigned bsmask = (1u << L) - 1u;
+
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int k = tid + NT * s;
+    float x = 0.f, y = 0.f, z = 0.f, t = -1.f;
+    if (k < n) {
+      x = dataset[3 * k + 0];
+      y = dataset[3 * k + 1];
+      z = dataset[3 * k + 2];
+      const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+      t = ((double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:100-101, sampling.cpp:74-76
+    }
+    px[s] = x; py[s] = y; pz[s] = z; pt[s] = t;
+  }
+  // overflow tail: running distance lives in `temp` (global), same -1 pinning
+  for (int k = NT * PPT + tid; k < n; k += NT) {
+    const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+    const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    temp[k] = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+  }
+
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[3 * old + 0], y1 = dataset[3 * old + 1], z1 = dataset[3 * old + 2];
+    float best = -1.f;
+    int bslot = 0;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
+      const float t = fminf(d, pt[s]);
+      pt[s] = t;
+      const bool gt = t > best;  // strict: lowest slot (== lowest key) of this thread wins
+      best = gt ? t : best;
+      bslot = gt ? s : bslot;
+    }
+    int bk = tid + NT * bslot;
+    for (int k = NT * PPT + tid; k < n; k += NT) {
+      const float d = sq_dist3(dataset[3 * k + 0], dataset[3 * k + 1], dataset[3 * k + 2], x1, y1, z1);
+      const float t = fminf(d, temp[k]);
+      temp[k] = t;
+      const bool gt = t > best;
+      best = gt ? t : best;
+      bk = gt ? k : bk;
+    }
+    // (best >= 0) or -1: both order correctly as signed integers
+    const int myv = __builtin_bit_cast(int, best);
+    const int wv = wave_allreduce_max_i32(myv);
+    const unsigned mykey = (myv == wv) ? fps_key((unsigned)bk, L, bsmask) : 0xFFFFFFFFu;
+    const unsigned wk = wave_allreduce_min_u32(mykey);
+    const int par = j & 1;
+    if (lane == 0) {
+      s_val[par][wave] = wv;
+      s_key[par][wave] = wk;
+    }
+    __syncthreads();
+    const int ov = s_val[par][lane & (NW - 1)];
+    const unsigned ok = s_key[par][lane & (NW - 1)];
+    const int gv = row_allreduce_max_i32(ov);
+    const unsigned gk = row_allreduce_min_u32(ov == gv ? ok : 0xFFFFFFFFu);
+    // every lane of every wave now holds the same (gv, gk); make that provable
+    const int gvu = __builtin_amdgcn_readfirstlane(gv);
+    const unsigned gku = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
+    old = (gvu < 0) ? 0 : (int)fps_unkey(gku, L);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
+template <int NT, int PPT>
+int launch_fps(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
+               hipStream_t stream) {
+  hipLaunchKernelGGL((fps_kernel<NT, PPT>), dim3(b), dim3(NT), 0, stream, n, m, L, dataset, temp,
+                     idxs);
+  SIG3D_LAUNCH_CHECK("fps_kernel");
+  return 0;
+}
+
+// ---- gather_points: out[b,c,j] = points[b,c,idx[b,j]] ---------------------------------------
+__global__ __launch_bounds__(256) void gather_points_kernel(int c, int n, int m,
+                                                            const float *__restrict__ points,
+                                                            const int *__restrict__ idx,
+                                                            float *__restrict__ out) {
+  const int bi = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    out[((size_t)bi * c + l) * m + j] = points[((size_t)bi * c + l) * n + a];
+}
+
+__global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, int m,
+                                                                 const float *__restrict__ grad_out,
+                                                                 const int *__restrict__ idx,
+                                                                 float *__restrict__ grad_points) {
+  const int bi = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  for (int l = blockIdx.y; l < c; l += gridDim.y)
+    unsafeAtomicAdd(grad_points + ((size_t)bi * c + l) * n + a,
+                    grad_out[((size_t)bi * c + l) * m + j]);
+}
+
+// cuda_utils.h:13-19 of the reference (host libm, double log ratio truncated)
+int ref_opt_n_threads_log2(int work_size) {
+  int pow_2 = (int)(log((double)work_size) / log(2.0));
+  if (pow_2 > 9) pow_2 = 9;
+  if (pow_2 < 0) pow_2 = 0;
+  return pow_2;
+}
+
+}  // namespace
+
+extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                             float *temp, int *idxs, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+  if (b == 0 || m <= 0) return 0;  // sampling_gpu.cu:73
+  SIG3D_REQUIRE(n >= 1, "furthest_point_sampling needs n >= 1");
+  SIG3D_REQUIRE((long)n < (1L << 31) - 1024, "n too large");
+  const int L = ref_opt_n_threads_log2(n);
+  // NT must be a multiple of the reference block size 2^L (<= 512).
+  if (n <= 256) return launch_fps<256, 1>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n < 512) return launch_fps<256, 2>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 512) return launch_fps<512, 1>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 1024) return launch_fps<512, 2>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 8192) return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 16384) return launch_fps<1024, 16>(b, n, m, L, dataset, temp, idxs, stream);
+  return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
+}
+
+extern "C" int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,
+                                   const int *idx, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "negative size");
+  if (b == 0 || c == 0 || npoints == 0) return 0;
+  dim3 grid(sig3d_ceil_div(npoints, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, stream, c, n, npoints, points, idx,
+                     out);
+  SIG3D_LAUNCH_CHECK("gather_points_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                        const int *idx, float *grad_points, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "negative size");
+  if (b == 0 || c == 0 || n == 0) return 0;
+  SIG3D_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * n, stream));
+  if (npoints == 0) return 0;
+  dim3 grid(sig3d_ceil_div(npoints, 256), c < 64 ? c : 64, b);
+  hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, stream, c, n, npoints,
+                     grad_out, idx, grad_points);
+  SIG3D_LAUNCH_CHECK("gather_points_grad_kernel");
+  return 0;
+}

@@ -1,0 +1,151 @@
+"""The nine native PointNet++ entry points, same names / positional order / return types as
+the reference's pybind module (lib/pointnet2/_ext_src/src/bindings.cpp:6-19), implemented by
+libsig3d_hip.so through its C ABI (include/sig3d_hip.h).
+
+Host-side behaviour mirrors the reference C++ wrappers: contiguity / dtype / device checks
+(include/utils.h:5-25) raise RuntimeError, CPU tensors raise "CPU not supported"
+(e.g. ball_query.cpp:27-29), outputs are allocated here on the input's device, and kernels are
+enqueued on torch's current stream.  There is no CPU implementation in this module by design.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+
+def _check_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+
+
+def _check_float(t, name):
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be a float tensor" % name)
+
+
+def _check_int(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError("%s must be an int tensor" % name)
+
+
+def _run(name, dev, *args):
+    with torch.cuda.device(dev):
+        _lib.call(name, *args, _lib.stream_ptr(dev))
+
+
+def gather_points(points, idx):
+    """sampling.cpp:15-38: points (B,C,N) f32, idx (B,M) i32 -> (B,C,M)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx")
+    _check_float(points, "points"); _check_int(idx, "idx")
+    dev = _lib.require_device(points, idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=dev)
+    _run("sig3d_gather_points", dev, b, c, n, m, _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """sampling.cpp:40-65: grad_out (B,C,M), idx (B,M) -> (B,C,n) scatter-add."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx")
+    dev = _lib.require_device(grad_out, idx)
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    _run("sig3d_gather_points_grad", dev, b, c, int(n), m, _lib.ptr(grad_out), _lib.ptr(idx),
+         _lib.ptr(out))
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """sampling.cpp:66-87: points (B,N,3) -> (B,nsamples) i32."""
+    _check_contiguous(points, "points"); _check_float(points, "points")
+    dev = _lib.require_device(points)
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    out = torch.zeros((b, nsamples), dtype=torch.int32, device=dev)
+    tmp = torch.empty((b, n), dtype=torch.float32, device=dev)
+    _run("sig3d_furthest_point_sampling", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
+         _lib.ptr(out))
+    return out
+
+
+def three_nn(unknowns, knows):
+    """interpolate.cpp:14-40: -> [dist2 (B,n,3) f32, idx (B,n,3) i32]."""
+    _check_contiguous(unknowns, "unknowns"); _check_contiguous(knows, "knows")
+    _check_float(unknowns, "unknowns"); _check_float(knows, "knows")
+    dev = _lib.require_device(unknowns, knows)
+    b, n, _ = unknowns.shape
+    m = knows.shape[1]
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+    _run("sig3d_three_nn", dev, b, n, m, _lib.ptr(unknowns), _lib.ptr(knows), _lib.ptr(dist2),
+         _lib.ptr(idx))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """interpolate.cpp:42-70: points (B,C,m), idx/weight (B,n,3) -> (B,C,n)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx")
+    _check_contiguous(weight, "weight")
+    _check_float(points, "points"); _check_int(idx, "idx"); _check_float(weight, "weight")
+    dev = _lib.require_device(points, idx, weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+    _run("sig3d_three_interpolate", dev, b, c, m, n, _lib.ptr(points), _lib.ptr(idx),
+         _lib.ptr(weight), _lib.ptr(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """interpolate.cpp:71-99: grad_out (B,C,n) -> (B,C,m)."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx")
+    _check_contiguous(weight, "weight")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx"); _check_float(weight, "weight")
+    dev = _lib.require_device(grad_out, idx, weight)
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=dev)
+    _run("sig3d_three_interpolate_grad", dev, b, c, n, int(m), _lib.ptr(grad_out), _lib.ptr(idx),
+         _lib.ptr(weight), _lib.ptr(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """ball_query.cpp:8-32 -- note the argument order: new_xyz first."""
+    _check_contiguous(new_xyz, "new_xyz"); _check_contiguous(xyz, "xyz")
+    _check_float(new_xyz, "new_xyz"); _check_float(xyz, "xyz")
+    dev = _lib.require_device(new_xyz, xyz)
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    nsample = int(nsample)
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=dev)
+    _run("sig3d_ball_query", dev, b, n, m, ctypes.c_float(radius), nsample, _lib.ptr(new_xyz),
+         _lib.ptr(xyz), _lib.ptr(idx))
+    return idx
+
+
+def group_points(points, idx):
+    """group_points.cpp:12-36: points (B,C,N), idx (B,P,S) -> (B,C,P,S)."""
+    _check_contiguous(points, "points"); _check_contiguous(idx, "idx")
+    _check_float(points, "points"); _check_int(idx, "idx")
+    dev = _lib.require_device(points, idx)
+    b, c, n = points.shape
+    _, npoints, nsample = idx.shape
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=dev)
+    _run("sig3d_group_points", dev, b, c, n, npoints, nsample, _lib.ptr(points), _lib.ptr(idx),
+         _lib.ptr(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """group_points.cpp:38-62: grad_out (B,C,P,S), idx (B,P,S) -> (B,C,n)."""
+    _check_contiguous(grad_out, "grad_out"); _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out"); _check_int(idx, "idx")
+    dev = _lib.require_device(grad_out, idx)
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.empty((b, c, int(n)), dtype=torch.float32, device=dev)
+    _run("sig3d_group_points_grad", dev, b, c, int(n), npoints, nsample, _lib.ptr(grad_out),
+         _lib.ptr(idx), _lib.ptr(out))
+    return out

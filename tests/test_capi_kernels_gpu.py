@@ -1,0 +1,125 @@
+"""Direct C-ABI checks (ctypes -> libsig3d_hip.so) of the situational transform and the
+attention kernels.  Floating point rows: tolerance written next to each assert
+(north star: fp32 activations within 1e-4).
+"""
+import ctypes
+import math
+
+import pytest
+import torch
+
+from util import poses, scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from situation3d_amd import _lib
+    return _lib
+
+
+@pytest.mark.parametrize("n", [1, 7, 256, 40000])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_situational_transform_vs_oracle(oracle, n, inverse):
+    L = _lib()
+    b = 3
+    pose = poses(b, seed=n)
+    pose[1, 3:] = torch.tensor([0.3, -0.2, 0.5, 0.9])  # non-unit quaternion: x2-y2-z2+w2 form
+    pts = scene(b, n, seed=n + 1)
+    out = torch.empty(b, n, 3, device=DEV)
+    pd, xd = pose.to(DEV), pts.to(DEV)
+    L.call("sig3d_situational_transform", b, n, L.ptr(pd), L.ptr(xd), L.ptr(out), inverse,
+           L.stream_ptr())
+    if not inverse:
+        ref = oracle.situational_transform(pose, pts)
+        assert torch.equal(out.cpu(), ref)  # same unfused evaluation order: bit-exact
+    else:
+        M = oracle.pose_to_matrix(pose)
+        ref = torch.einsum("bcr,bnc->bnr", M[:, :3, :3].double(), (pts - pose[:, None, :3]).double())
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_situational_transform_grad(oracle, inverse):
+    L = _lib()
+    b, n = 2, 1000
+    pose = poses(b, seed=3)
+    pose[:, 3:] += 0.1
+    pts = scene(b, n, seed=4)
+    go = torch.randn(b, n, 3, generator=torch.Generator().manual_seed(5))
+
+    def torch_fwd(pose, pts):
+        t, x, y, z, w = pose[:, :3], pose[:, 3], pose[:, 4], pose[:, 5], pose[:, 6]
+        R = torch.stack([
+            torch.stack([x * x - y * y - z * z + w * w, 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+            torch.stack([2 * (x * y + z * w), -x * x + y * y - z * z + w * w, 2 * (y * z - x * w)], -1),
+            torch.stack([2 * (x * z - y * w), 2 * (y * z + x * w), -x * x - y * y + z * z + w * w], -1)], 1)
+        if inverse:
+            return torch.einsum("bcr,bnc->bnr", R, pts - t[:, None])
+        return torch.einsum("brc,bnc->bnr", R, pts) + t[:, None]
+
+    p64 = pose.double().requires_grad_(True)
+    x64 = pts.double().requires_grad_(True)
+    (torch_fwd(p64, x64) * go.double()).sum().backward()
+    gp = torch.empty(b, n, 3, device=DEV)
+    gpose = torch.empty(b, 7, device=DEV)
+    pd, xd, gd = pose.to(DEV), pts.to(DEV), go.to(DEV)
+    L.call("sig3d_situational_transform_grad", b, n, L.ptr(pd), L.ptr(xd), L.ptr(gd), L.ptr(gp),
+           L.ptr(gpose), inverse, L.stream_ptr())
+    torch.testing.assert_close(gp.cpu().double(), x64.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gpose.cpu().double(), p64.grad, rtol=1e-4, atol=1e-3)
+
+
+def _attn_ref(q, k, v, mask, scale):
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask.double()[:, None, None, :]
+    p = torch.softmax(s, -1)
+    ctx = torch.matmul(p, v.double())  # (b,h,nq,d)
+    b, h, nq, d = ctx.shape
+    return ctx.permute(0, 2, 1, 3).reshape(b, nq, h * d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("b,h,nq,nk,use_mask", [(2, 12, 32, 256, True), (1, 3, 52, 52, True),
+                                                (2, 2, 32, 5000, False), (1, 1, 5, 33, True),
+                                                (1, 2, 32, 1, False), (1, 2, 100, 77, True)])
+def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
+    L = _lib()
+    g = torch.Generator().manual_seed(nq * 131 + nk)
+    q = torch.randn(b, h, nq, 64, generator=g)
+    k = torch.randn(b, h, nk, 64, generator=g)
+    v = torch.randn(b, h, nk, 64, generator=g)
+    mask = None
+    if use_mask:
+        keep = (torch.rand(b, nk, generator=g) > 0.2).float()
+        keep[:, 0] = 1.0
+        mask = (1.0 - keep) * -10000.0  # Qformer.py:731
+    scale = 1.0 / math.sqrt(64)
+    go = torch.randn(b, nq, h * 64, generator=g)
+
+    qd, kd, vd, god = q.to(DEV), k.to(DEV), v.to(DEV), go.to(DEV)
+    md = mask.to(DEV) if mask is not None else None
+    out = torch.empty(b, nq, h * 64, device=DEV)
+    lse = torch.empty(b, h, nq, device=DEV)
+    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+           L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.stream_ptr())
+
+    q64 = q.double().requires_grad_(True)
+    k64 = k.double().requires_grad_(True)
+    v64 = v.double().requires_grad_(True)
+    ref, ref_lse = _attn_ref(q64, k64, v64, mask, scale)
+    # tolerance: 1e-4 absolute on O(1) activations (north star), observed ~1e-6
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(lse.cpu().double(), ref_lse.detach(), rtol=1e-4, atol=1e-4)
+
+    (ref * go.double()).sum().backward()
+    dq = torch.empty_like(qd)
+    dk = torch.empty_like(kd)
+    dv = torch.empty_like(vd)
+    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+           L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
+           L.ptr(dv), L.stream_ptr())
+    torch.testing.assert_close(dq.cpu().double(), q64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dk.cpu().double(), k64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dv.cpu().double(), v64.grad, rtol=1e-4, atol=1e-4)

@@ -1,0 +1,132 @@
+"""Parity of the nine HIP PointNet++ ops (through pointnet2._ext -> C ABI) against the CPU
+oracle on identical seeded inputs.  Index outputs must be BIT-EXACT; gathers are bit-exact;
+scatter-add gradients (float atomics, order-dependent in the reference too:
+group_points_gpu.cu:59-60) within 1e-5 relative.
+"""
+import pytest
+import torch
+
+from util import feats, scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _fps_case(hip_ext, oracle, b, n, m, **kw):
+    xyz = scene(b, n, **kw)
+    ref = oracle.furthest_point_sampling(xyz, m)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    assert got.dtype == torch.int32 and got.shape == (b, m)
+    assert torch.equal(got, ref), "FPS indices differ at %s" % (got != ref).nonzero()[:4].tolist()
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 2), (9, 2), (64, 16), (100, 37), (255, 64), (256, 64),
+                                 (300, 100), (511, 128), (512, 128), (513, 128), (1000, 256),
+                                 (1024, 512), (2048, 1024), (4096, 512), (5000, 300), (9000, 256),
+                                 (20000, 128)])
+def test_fps_sizes(hip_ext, oracle, n, m):
+    _fps_case(hip_ext, oracle, 2, n, m, seed=n)
+
+
+def test_fps_ties_and_skips(hip_ext, oracle):
+    # duplicated points (exact ties in min-distance) and an all-zero padded tail
+    # (skipped by the mag <= 1e-3 rule, sampling_gpu.cu:100-101)
+    _fps_case(hip_ext, oracle, 3, 4096, 1024, seed=5, dup=1500, zero_tail=700)
+    _fps_case(hip_ext, oracle, 2, 700, 300, seed=6, dup=400, zero_tail=50)
+    # grid-aligned points: massive exact ties
+    g = torch.stack(torch.meshgrid(torch.arange(16.), torch.arange(16.), torch.arange(8.), indexing="ij"), -1)
+    xyz = (g.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()
+    ref = oracle.furthest_point_sampling(xyz, 512)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), 512).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_fps_all_skipped_and_m_gt_n(hip_ext, oracle):
+    xyz = torch.zeros(2, 300, 3)
+    assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 8).cpu(),
+                       oracle.furthest_point_sampling(xyz, 8))
+    xyz = scene(1, 40, seed=3)
+    assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 60).cpu(),
+                       oracle.furthest_point_sampling(xyz, 60))
+
+
+def test_fps_scene_40k(hip_ext, oracle):
+    # BASELINE shape (one scene, 40k points, SA1 npoint=2048) incl. the overflow-tail path
+    _fps_case(hip_ext, oracle, 1, 40000, 2048, seed=11, dup=500, zero_tail=100)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(9, 2, 5.0, 6), (9, 2, 10.0, 3), (4096, 512, 0.2, 64),
+                                      (4096, 512, 0.8, 16), (1000, 77, 0.5, 7), (100, 100, 0.3, 1),
+                                      (63, 5, 1.0, 130), (20000, 256, 0.4, 32)])
+def test_ball_query(hip_ext, oracle, n, m, r, ns):
+    xyz = scene(2, n, seed=n + ns, dup=n // 8)
+    new_xyz = xyz[:, torch.randperm(n, generator=torch.Generator().manual_seed(1))[:m]].contiguous()
+    new_xyz[:, -1] = 100.0  # a centre with no neighbour: row must stay all-zero
+    ref = oracle.ball_query(new_xyz, xyz, r, ns)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+    assert torch.equal(got, ref)
+    assert (got[:, -1] == 0).all()
+
+
+@pytest.mark.parametrize("c,n,p,s", [(3, 4096, 512, 64), (6, 9, 2, 3), (131, 2048, 256, 32),
+                                     (5, 100, 7, 5), (1, 50, 1, 1)])
+def test_group_points_and_grad(hip_ext, oracle, c, n, p, s):
+    g = torch.Generator().manual_seed(c + n)
+    pts = feats(2, c, n)
+    idx = torch.randint(0, n, (2, p, s), generator=g, dtype=torch.int32)
+    ref = oracle.group_points(pts, idx)
+    got = hip_ext.group_points(pts.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, ref)
+    go = torch.rand(2, c, p, s, generator=g)
+    refg = oracle.group_points_grad(go, idx, n)
+    gotg = hip_ext.group_points_grad(go.to(DEV), idx.to(DEV), n).cpu()
+    torch.testing.assert_close(gotg, refg, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("c,n,m", [(3, 4096, 512), (6, 9, 2), (256, 2048, 1024)])
+def test_gather_points_and_grad(hip_ext, oracle, c, n, m):
+    g = torch.Generator().manual_seed(c + m)
+    pts = feats(2, c, n)
+    idx = torch.randint(0, n, (2, m), generator=g, dtype=torch.int32)
+    assert torch.equal(hip_ext.gather_points(pts.to(DEV), idx.to(DEV)).cpu(), oracle.gather_points(pts, idx))
+    go = torch.rand(2, c, m, generator=g)
+    torch.testing.assert_close(hip_ext.gather_points_grad(go.to(DEV), idx.to(DEV), n).cpu(),
+                               oracle.gather_points_grad(go, idx, n), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,m", [(512, 256), (1024, 512), (100, 2), (7, 1), (3000, 1500), (50, 3)])
+def test_three_nn(hip_ext, oracle, n, m):
+    unknown = scene(2, n, seed=n)
+    known = scene(2, m, seed=m + 1, dup=m // 4)
+    rd, ri = oracle.three_nn(unknown, known)
+    gd, gi = hip_ext.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(gi.cpu(), ri)
+    assert torch.equal(gd.cpu(), rd)  # includes +inf for unfilled slots when m < 3
+
+
+def test_three_interpolate_and_grad(hip_ext, oracle):
+    g = torch.Generator().manual_seed(0)
+    b, c, m, n = 2, 256, 256, 512
+    pts = feats(b, c, m)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(b, n, 3, generator=g)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    assert torch.equal(hip_ext.three_interpolate(pts.to(DEV), idx.to(DEV), w.to(DEV)).cpu(),
+                       oracle.three_interpolate(pts, idx, w))
+    go = torch.rand(b, c, n, generator=g)
+    torch.testing.assert_close(
+        hip_ext.three_interpolate_grad(go.to(DEV), idx.to(DEV), w.to(DEV), m).cpu(),
+        oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-5, atol=1e-5)
+
+
+def test_reference_error_behaviour(hip_ext):
+    # "CPU not supported" (ball_query.cpp:27-29) and the CHECK_* macros (utils.h:5-25)
+    xyz = scene(1, 16)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        hip_ext.ball_query(xyz, xyz, 0.5, 4)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        hip_ext.furthest_point_sampling(scene(1, 16).to(DEV).transpose(1, 2), 4)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        hip_ext.gather_points(feats(1, 3, 16).to(DEV), torch.zeros(1, 4, dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError, match="float tensor"):
+        hip_ext.three_nn(xyz.double().to(DEV), xyz.to(DEV))
