@@ -124,7 +124,9 @@ int sig3d_situational_transform_grad(int b, int n, const float *pose, const floa
 /* replaces BertSelfAttention.forward's core
  *   3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py:185-223
  * context = softmax(Q K^T * scale + mask) V  per (batch, head), fp32, exact-f32 MFMA.
- * q (b,h,nq,d), k (b,h,nk,d), v (b,h,nk,d) contiguous; mask additive (b,nk) or NULL
+ * q (b,nq,h*d), k (b,nk,h*d), v (b,nk,h*d) contiguous and TOKEN-MAJOR, i.e. exactly what the
+ * query/key/value nn.Linear layers produce (Qformer.py:164-176) -- the transpose_for_scores
+ * permute (:140-147) is folded into the kernel's addressing; mask additive (b,nk) or NULL
  * (the reference's (B,1,1,Nk) extended mask, Qformer.py:700-732); d must be 64.
  * out (b,nq,h*d) -- already in the permuted "context_layer" layout of Qformer.py:225-227.
  * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL). */
@@ -133,7 +135,7 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale, const 
                         float *lse, void *stream);
 
 /* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
- * -> dq (b,h,nq,d), dk (b,h,nk,d), dv (b,h,nk,d). */
+ * -> dq (b,nq,h*d), dk (b,nk,h*d), dv (b,nk,h*d), token-major like the inputs. */
 int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
                         const float *k, const float *v, const float *mask,
                         const float *out, const float *lse, const float *grad_out,

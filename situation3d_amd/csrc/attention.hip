@@ -63,13 +63,15 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
-  const float *Q = q + ((size_t)(bi * h + hi) * nq) * AT_D;
-  const float *K = k + ((size_t)(bi * h + hi) * nk) * AT_D;
-  const float *V = v + ((size_t)(bi * h + hi) * nk) * AT_D;
+  // token-major operands (b, n, h*d): row r of head hi starts at base + r*hs + hi*64
+  const long hs = (long)h * AT_D;
+  const float *Q = q + (size_t)bi * nq * hs + hi * AT_D;
+  const float *K = k + (size_t)bi * nk * hs + hi * AT_D;
+  const float *V = v + (size_t)bi * nk * hs + hi * AT_D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
 
   float qf[32];
-  load_half_row(qf, Q, q0 + l31, AT_D, half, q0 + l31 < nq);
+  load_half_row(qf, Q, q0 + l31, hs, half, q0 + l31 < nq);
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o0 = {0}, o1 = {0};
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   for (int t = wave; t < ntiles; t += AT_WAVES) {
     const int key0 = t * 32;
     float kf[32];
-    load_half_row(kf, K, min(key0 + l31, nk - 1), AT_D, half, true);
+    load_half_row(kf, K, min(key0 + l31, nk - 1), hs, half, true);
     f32x16 st = {0};
 #pragma unroll
     for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
       const int key = min(key0 + mfma_row(s, half), nk - 1);
-      const float a0 = V[(size_t)key * AT_D + l31];
-      const float a1 = V[(size_t)key * AT_D + 32 + l31];
+      const float a0 = V[(size_t)key * hs + l31];
+      const float a1 = V[(size_t)key * hs + 32 + l31];
       o0 = mfma32(a0, p[s], o0);
       o1 = mfma32(a1, p[s], o1);
     }
@@ -178,11 +180,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int hi = blockIdx.y, bi = blockIdx.z;
   const size_t bh = (size_t)(bi * h + hi);
-  const float *Q = q + bh * nq * AT_D;
-  const float *K = k + bh * nk * AT_D;
-  const float *V = v + bh * nk * AT_D;
-  const float *M = mask ? mask + (size_t)bi * nk : nullptr;
   const size_t ostride = (size_t)h * AT_D;
+  const long hs = (long)ostride;
+  const float *Q = q + (size_t)bi * nq * ostride + hi * AT_D;
+  const float *K = k + (size_t)bi * nk * ostride + hi * AT_D;
+  const float *V = v + (size_t)bi * nk * ostride + hi * AT_D;
+  const float *M = mask ? mask + (size_t)bi * nk : nullptr;
   const float *O = out + (size_t)bi * nq * ostride + hi * AT_D;        // row q at O + q*ostride
   const float *dO = grad_out + (size_t)bi * nq * ostride + hi * AT_D;
 
@@ -218,15 +221,15 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     const int krow = min(key0 + l31, nk - 1);
     const bool key_ok = key0 + l31 < nk;
     float kf[32], vf[32];
-    load_half_row(kf, K, krow, AT_D, half, true);
-    load_half_row(vf, V, krow, AT_D, half, true);
+    load_half_row(kf, K, krow, hs, half, true);
+    load_half_row(vf, V, krow, hs, half, true);
     const float mk = M ? M[krow] : 0.f;
     f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
 
     for (int qt = 0; qt < nqt; ++qt) {
       const int q0 = qt * 32;
       float fr[32];
-      load_half_row(fr, Q, q0 + l31, AT_D, half, q0 + l31 < nq);
+      load_half_row(fr, Q, q0 + l31, hs, half, q0 + l31 < nq);
       f32x16 sacc = {0};
 #pragma unroll
       for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       for (int s = 0; s < 16; ++s) {
         const int qq = min(q0 + mfma_row(s, half), nq - 1);
         const float g0 = dO[(size_t)qq * ostride + l31], g1 = dO[(size_t)qq * ostride + 32 + l31];
-        const float x0 = Q[(size_t)qq * AT_D + l31], x1 = Q[(size_t)qq * AT_D + 32 + l31];
+        const float x0 = Q[(size_t)qq * hs + l31], x1 = Q[(size_t)qq * hs + 32 + l31];
         dvt0 = mfma32(g0, p[s], dvt0);
         dvt1 = mfma32(g1, p[s], dvt1);
         dkt0 = mfma32(x0, ds[s], dkt0);
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         const int kk = mfma_row(s, half);
         const int key = min(key0 + kk, nk - 1);
         const float bq = s_T[wave][kk][l31];
-        dqt0 = mfma32(K[(size_t)key * AT_D + l31], bq, dqt0);
-        dqt1 = mfma32(K[(size_t)key * AT_D + 32 + l31], bq, dqt1);
+        dqt0 = mfma32(K[(size_t)key * hs + l31], bq, dqt0);
+        dqt1 = mfma32(K[(size_t)key * hs + 32 + l31], bq, dqt1);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -283,8 +286,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       }
     }
     if (key_ok) {
-      float *dvp = dv + (bh * nk + key0 + l31) * AT_D;
-      float *dkp = dk + (bh * nk + key0 + l31) * AT_D;
+      float *dvp = dv + ((size_t)bi * nk + key0 + l31) * ostride + hi * AT_D;
+      float *dkp = dk + ((size_t)bi * nk + key0 + l31) * ostride + hi * AT_D;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
         const int d = 8 * g + 4 * half;
@@ -299,8 +302,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
     const int qq = i / AT_D, d = i % AT_D;
     const float val = s_dq[qq][d] * scale;
-    if (atomic_dq) unsafeAtomicAdd(dq + bh * nq * AT_D + i, val);
-    else dq[bh * nq * AT_D + i] = val;
+    float *dst = dq + ((size_t)bi * nq + qq) * ostride + hi * AT_D + d;
+    if (atomic_dq) unsafeAtomicAdd(dst, val);
+    else *dst = val;
   }
 }
 

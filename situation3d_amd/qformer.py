@@ -1,0 +1,420 @@
+"""BLIP-2 Q-Former (BERT encoder with learned queries + cross-attention) over the gfx950
+attention kernels -- host-side mirror of the reference's
+3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py for the path Blip2T5.forward uses
+(blip2_t5.py:121-128):
+
+    Qformer.bert(query_embeds=..., encoder_hidden_states=..., encoder_attention_mask=...,
+                 return_dict=True).last_hidden_state
+
+Module tree and parameter names equal the reference's, so a reference checkpoint's
+`Qformer.bert.*` keys load with strict=True:
+    bert.embeddings.{word_embeddings,position_embeddings,LayerNorm}
+    bert.encoder.layer.{i}.attention.{self.{query,key,value},output.{dense,LayerNorm}}
+    bert.encoder.layer.{i}.crossattention.(same)              (layers with i % freq == 0)
+    bert.encoder.layer.{i}.{intermediate,output,intermediate_query,output_query}
+`strip_text_branch()` reproduces what Blip2T5.__init__ removes (blip2_t5.py:63-69).
+
+softmax(QK^T/sqrt(d) + mask)V runs in sig3d_attention_fwd/bwd (exact-f32 MFMA, scores never
+materialised); the dense layers are plain library GEMMs (torch / hipBLASLt); LayerNorm, GELU and
+hidden-state dropout stay torch ops.  Attention-probability dropout (Qformer.py:219) is applied
+by the reference on the materialised probabilities; the fused kernel does not implement it, so
+`attention_probs_dropout_prob` must be 0 while training through this module (enforced).
+"""
+import ctypes
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class QFormerConfig:
+    """Field names follow transformers' BertConfig (+ the four Q-Former extras set in
+    Blip2Base.init_Qformer, blip2.py:50-60).  Defaults == bert-base-uncased."""
+
+    def __init__(self, **kw):
+        self.vocab_size = 30522
+        self.hidden_size = 768
+        self.num_hidden_layers = 12
+        self.num_attention_heads = 12
+        self.intermediate_size = 3072
+        self.hidden_act = "gelu"
+        self.hidden_dropout_prob = 0.1
+        self.attention_probs_dropout_prob = 0.0
+        self.max_position_embeddings = 512
+        self.initializer_range = 0.02
+        self.layer_norm_eps = 1e-12
+        self.pad_token_id = 0
+        self.position_embedding_type = "absolute"
+        self.encoder_width = 1408
+        self.add_cross_attention = True
+        self.cross_attention_freq = 2
+        self.query_length = 32
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class _AttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale + mask) v on token-major (B, N, H*64) operands."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, num_heads, scale):
+        dev = _lib.require_device(q, k, v, mask)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        b, nq, hd = q.shape
+        nk = k.shape[1]
+        d = hd // num_heads
+        out = torch.empty((b, nq, hd), dtype=torch.float32, device=dev)
+        lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
+        if mask is not None:
+            mask = mask.contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, ctypes.c_float(scale),
+                      _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
+                      _lib.ptr(lse), _lib.stream_ptr(dev))
+        ctx.save_for_backward(q, k, v, mask, out, lse)
+        ctx.cfg = (num_heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, mask, out, lse = ctx.saved_tensors
+        num_heads, scale = ctx.cfg
+        b, nq, hd = q.shape
+        nk = k.shape[1]
+        grad_out = grad_out.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        with torch.cuda.device(q.device):
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads,
+                      ctypes.c_float(scale), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask),
+                      _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), _lib.ptr(dq), _lib.ptr(dk),
+                      _lib.ptr(dv), _lib.stream_ptr(q.device))
+        return dq, dk, dv, None, None, None
+
+
+def fused_attention(q, k, v, additive_mask, num_heads):
+    """q (B,Nq,H*64), k/v (B,Nk,H*64), additive_mask (B,Nk) or None -> (B,Nq,H*64)."""
+    d = q.shape[-1] // num_heads
+    return _AttentionFn.apply(q, k, v, additive_mask, num_heads, 1.0 / math.sqrt(d))
+
+
+def _key_mask(mask, batch, nk):
+    """The reference passes additive masks shaped (B,1,1,Nk) (Qformer.py:700-732 and
+    invert_attention_mask); the kernel wants (B,Nk)."""
+    if mask is None:
+        return None
+    if mask.dim() == 4:
+        if mask.shape[1] != 1 or mask.shape[2] != 1:
+            raise NotImplementedError("per-query (3-D / causal) attention masks are not on the "
+                                      "hot path (Qformer.py:677-712 decoder branch)")
+        mask = mask[:, 0, 0, :]
+    return mask.expand(batch, nk).to(torch.float32)
+
+
+class BertEmbeddings(nn.Module):
+    """Qformer.py:51-98"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size,
+                                            padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.register_buffer("position_ids",
+                             torch.arange(config.max_position_embeddings).expand((1, -1)))
+        self.position_embedding_type = getattr(config, "position_embedding_type", "absolute")
+        self.config = config
+
+    def forward(self, input_ids=None, position_ids=None, query_embeds=None,
+                past_key_values_length=0):
+        seq_length = input_ids.size()[1] if input_ids is not None else 0
+        if position_ids is None:
+            position_ids = self.position_ids[
+                :, past_key_values_length: seq_length + past_key_values_length].clone()
+        if input_ids is not None:
+            embeddings = self.word_embeddings(input_ids)
+            if self.position_embedding_type == "absolute":
+                embeddings = embeddings + self.position_embeddings(position_ids)
+            if query_embeds is not None:
+                embeddings = torch.cat((query_embeds, embeddings), dim=1)
+        else:
+            embeddings = query_embeds
+        return self.dropout(self.LayerNorm(embeddings))
+
+
+class BertSelfAttention(nn.Module):
+    """Qformer.py:101-232; forward returns (context_layer, (key_layer, value_layer)) with the
+    key/value pair in the reference's (B, H, N, 64) view."""
+
+    def __init__(self, config, is_cross_attention):
+        super().__init__()
+        self.config = config
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention "
+                             "heads (%d)" % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        kv_in = config.encoder_width if is_cross_attention else config.hidden_size
+        self.key = nn.Linear(kv_in, self.all_head_size)
+        self.value = nn.Linear(kv_in, self.all_head_size)
+        self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+        if getattr(config, "position_embedding_type", "absolute") != "absolute":
+            raise NotImplementedError("relative position embeddings (Qformer.py:189-205) are not "
+                                      "used by BLIP-2 and are not on the hot path")
+
+    def transpose_for_scores(self, x):
+        return x.view(*x.size()[:-1], self.num_attention_heads,
+                      self.attention_head_size).permute(0, 2, 1, 3)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_value=None,
+                output_attentions=False):
+        if head_mask is not None or past_key_value is not None or output_attentions:
+            raise NotImplementedError("head_mask / past_key_value / output_attentions need the "
+                                      "materialised probabilities; not on the hot path")
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("attention_probs_dropout_prob must be 0 for the fused kernel")
+        is_cross_attention = encoder_hidden_states is not None
+        kv_src = encoder_hidden_states if is_cross_attention else hidden_states
+        if is_cross_attention:
+            attention_mask = encoder_attention_mask
+        key = self.key(kv_src)
+        value = self.value(kv_src)
+        query = self.query(hidden_states)
+        mask = _key_mask(attention_mask, query.shape[0], key.shape[1])
+        context_layer = fused_attention(query, key, value, mask, self.num_attention_heads)
+        return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
+
+
+class BertSelfOutput(nn.Module):
+    """Qformer.py:235-246"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+
+
+class BertAttention(nn.Module):
+    """Qformer.py:249-299"""
+
+    def __init__(self, config, is_cross_attention=False):
+        super().__init__()
+        self.self = BertSelfAttention(config, is_cross_attention)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_value=None,
+                output_attentions=False):
+        self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states,
+                                 encoder_attention_mask, past_key_value, output_attentions)
+        return (self.output(self_outputs[0], hidden_states),) + self_outputs[1:]
+
+
+class BertIntermediate(nn.Module):
+    """Qformer.py:302-314 (erf GELU)"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        if config.hidden_act != "gelu":
+            raise NotImplementedError("only hidden_act='gelu' (bert-base) is supported")
+        self.intermediate_act_fn = nn.GELU()
+
+    def forward(self, hidden_states):
+        return self.intermediate_act_fn(self.dense(hidden_states))
+
+
+class BertOutput(nn.Module):
+    """Qformer.py:317-328"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+
+
+class BertLayer(nn.Module):
+    """Qformer.py:331-428: self-attention over all tokens, cross-attention (every
+    `cross_attention_freq`-th layer) and the query FFN on the first `query_length` tokens, the
+    text FFN on the rest."""
+
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.config = config
+        self.attention = BertAttention(config)
+        self.layer_num = layer_num
+        if config.add_cross_attention and layer_num % config.cross_attention_freq == 0:
+            self.crossattention = BertAttention(config, is_cross_attention=True)
+            self.has_cross_attention = True
+        else:
+            self.has_cross_attention = False
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+        self.intermediate_query = BertIntermediate(config)
+        self.output_query = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_value=None,
+                output_attentions=False, query_length=0):
+        self_attention_outputs = self.attention(hidden_states, attention_mask, head_mask)
+        attention_output = self_attention_outputs[0]
+        present_key_value = self_attention_outputs[-1]
+        if query_length > 0:
+            query_attention_output = attention_output[:, :query_length, :]
+            if self.has_cross_attention:
+                assert encoder_hidden_states is not None, \
+                    "encoder_hidden_states must be given for cross-attention layers"
+                query_attention_output = self.crossattention(
+                    query_attention_output, attention_mask, head_mask, encoder_hidden_states,
+                    encoder_attention_mask)[0]
+            layer_output = self.feed_forward_chunk_query(query_attention_output)
+            if attention_output.shape[1] > query_length:
+                layer_output_text = self.feed_forward_chunk(attention_output[:, query_length:, :])
+                layer_output = torch.cat([layer_output, layer_output_text], dim=1)
+        else:
+            layer_output = self.feed_forward_chunk(attention_output)
+        return (layer_output, present_key_value)
+
+    def feed_forward_chunk(self, attention_output):
+        return self.output(self.intermediate(attention_output), attention_output)
+
+    def feed_forward_chunk_query(self, attention_output):
+        return self.output_query(self.intermediate_query(attention_output), attention_output)
+
+
+class BertEncoder(nn.Module):
+    """Qformer.py:431-526"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask=None, head_mask=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
+                use_cache=None, output_attentions=False, output_hidden_states=False,
+                return_dict=True, query_length=0):
+        all_hidden_states = () if output_hidden_states else None
+        for layer_module in self.layer:
+            if output_hidden_states:
+                all_hidden_states = all_hidden_states + (hidden_states,)
+            hidden_states = layer_module(hidden_states, attention_mask, None,
+                                         encoder_hidden_states, encoder_attention_mask, None,
+                                         output_attentions, query_length)[0]
+        if output_hidden_states:
+            all_hidden_states = all_hidden_states + (hidden_states,)
+        if not return_dict:
+            return tuple(v for v in (hidden_states, all_hidden_states) if v is not None)
+        return SimpleNamespace(last_hidden_state=hidden_states, past_key_values=None,
+                               hidden_states=all_hidden_states, attentions=None,
+                               cross_attentions=None)
+
+
+class BertModel(nn.Module):
+    """Qformer.py:613-869 (encoder mode: is_decoder=False; no pooler, as BLIP-2 builds it)."""
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        if add_pooling_layer:
+            raise NotImplementedError("BLIP-2 builds the Q-Former without a pooler (Qformer.py:903)")
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, module):
+        """Qformer.py:600-610"""
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    @staticmethod
+    def _additive(mask_2d, dtype):
+        """(1 - mask) * -10000 on a (B,N) 0/1 mask (Qformer.py:729-731, invert_attention_mask)."""
+        return (1.0 - mask_2d.to(dtype)) * -10000.0
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None,
+                query_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_values=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, is_decoder=False):
+        if is_decoder or past_key_values is not None or head_mask is not None:
+            raise NotImplementedError("decoder / cache / head-mask paths are outside the hot path")
+        if input_ids is None:
+            assert query_embeds is not None, \
+                "You have to specify query_embeds when input_ids is None"
+        query_length = query_embeds.shape[1] if query_embeds is not None else 0
+        embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
+                                           query_embeds=query_embeds)
+        batch_size, seq_length = embedding_output.shape[:2]
+        device = embedding_output.device
+        if attention_mask is None:
+            attention_mask = torch.ones((batch_size, seq_length), device=device)
+        if attention_mask.dim() != 2:
+            raise NotImplementedError("only (B, N) padding masks are on the hot path")
+        extended_attention_mask = self._additive(attention_mask, embedding_output.dtype)
+        encoder_extended_attention_mask = None
+        if encoder_hidden_states is not None:
+            if encoder_attention_mask is None:
+                encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2], device=device)
+            encoder_extended_attention_mask = self._additive(encoder_attention_mask,
+                                                             embedding_output.dtype)
+        enc = self.encoder(embedding_output, attention_mask=extended_attention_mask,
+                           encoder_hidden_states=encoder_hidden_states,
+                           encoder_attention_mask=encoder_extended_attention_mask,
+                           output_hidden_states=bool(output_hidden_states), return_dict=True,
+                           query_length=query_length)
+        if return_dict is False:
+            return (enc.last_hidden_state, None)
+        return SimpleNamespace(last_hidden_state=enc.last_hidden_state, pooler_output=None,
+                               past_key_values=None, hidden_states=enc.hidden_states,
+                               attentions=None, cross_attentions=None)
+
+
+class QFormer(nn.Module):
+    """The object Blip2Base.init_Qformer returns as `Qformer` (blip2.py:50-60), minus the LM
+    head (`cls`), which Blip2T5 deletes (blip2_t5.py:64)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.bert = BertModel(config)
+        self.cls = None
+
+    def strip_text_branch(self):
+        """blip2_t5.py:63-69: no word/position embeddings, no text FFN."""
+        self.bert.embeddings.word_embeddings = None
+        self.bert.embeddings.position_embeddings = None
+        for layer in self.bert.encoder.layer:
+            layer.output = None
+            layer.intermediate = None
+        return self
+
+
+def init_Qformer(num_query_token, vision_width, cross_attention_freq=2, **overrides):
+    """Blip2Base.init_Qformer (blip2.py:50-60) without the hub download: the config is
+    bert-base-uncased's, built locally; weights are random-initialised (_init_weights)."""
+    config = QFormerConfig(encoder_width=vision_width, add_cross_attention=True,
+                           cross_attention_freq=cross_attention_freq,
+                           query_length=num_query_token, **overrides)
+    qformer = QFormer(config)
+    query_tokens = nn.Parameter(torch.zeros(1, num_query_token, config.hidden_size))
+    query_tokens.data.normal_(mean=0.0, std=config.initializer_range)
+    return qformer, query_tokens

@@ -98,7 +98,10 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     scale = 1.0 / math.sqrt(64)
     go = torch.randn(b, nq, h * 64, generator=g)
 
-    qd, kd, vd, god = q.to(DEV), k.to(DEV), v.to(DEV), go.to(DEV)
+    # C ABI takes token-major (b, n, h*d) operands (what nn.Linear produces)
+    tm = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], -1).contiguous()
+    untm = lambda t: t.reshape(t.shape[0], t.shape[1], h, 64).permute(0, 2, 1, 3)
+    qd, kd, vd, god = tm(q).to(DEV), tm(k).to(DEV), tm(v).to(DEV), go.to(DEV)
     md = mask.to(DEV) if mask is not None else None
     out = torch.empty(b, nq, h * 64, device=DEV)
     lse = torch.empty(b, h, nq, device=DEV)
@@ -120,6 +123,6 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     L.call("sig3d_attention_bwd", b, h, nq, nk, 64, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
            L.ptr(dv), L.stream_ptr())
-    torch.testing.assert_close(dq.cpu().double(), q64.grad, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(dk.cpu().double(), k64.grad, rtol=1e-4, atol=1e-4)
-    torch.testing.assert_close(dv.cpu().double(), v64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(untm(dq.cpu()).double(), q64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(untm(dk.cpu()).double(), k64.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(untm(dv.cpu()).double(), v64.grad, rtol=1e-4, atol=1e-4)
