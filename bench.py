@@ -1,0 +1,202 @@
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one training pass of the hot path over one synthetic batch:
+point encoder (SA1-4 on 40 000 points / scene) -> situational pose re-encode -> Q-Former fusion
+(32 queries + 20 question tokens) -> losses -> backward -> value clip -> AdamW.  B = 8 scenes per
+GPU (BASELINE config "SQA3D train step fwd+bwd+Adam, 40k pts, B=8"), weak scaling over ranks
+(one process per GPU, bucketed RCCL all-reduce overlapped with backward).  Inputs are generated
+before the timed region and are resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from situation3d_amd import _lib  # noqa: E402
+from situation3d_amd.ddp import GradBucketReducer, init_distributed  # noqa: E402
+from situation3d_amd.model import SIG3DQFormer  # noqa: E402
+from situation3d_amd.trainer import build_optimizer, get_loss, train_step  # noqa: E402
+
+N_POINTS, BATCH, N_QUERY, N_TEXT, NUM_ANSWERS = 40000, 8, 32, 20, 706
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SA_LEVELS = [(40000, 2048, 64, 3), (2048, 1024, 32, 128), (1024, 512, 16, 256), (512, 256, 16, 256)]
+
+
+def synthetic_batch(batch, n_points, seed, device):
+    """xyz ~ U([0,8]x[0,8]x[0,3]) m, colours U(0,1), pose = U(room) +
+    z-rotation quaternion, 20 question token ids U(1000,30000), soft multi-hot answers."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(batch, n_points, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    rgb = torch.rand(batch, n_points, 3, generator=g)
+    t = torch.rand(batch, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    ang = (torch.rand(batch, generator=g) * 2 - 1) * 3.14159265
+    quat = torch.stack([torch.zeros(batch), torch.zeros(batch), torch.sin(ang / 2), torch.cos(ang / 2)], 1)
+    ids = torch.randint(1000, 30000, (batch, N_TEXT), generator=g)
+    ans = torch.zeros(batch, NUM_ANSWERS)
+    ans[torch.arange(batch), torch.randint(0, NUM_ANSWERS, (batch,), generator=g)] = 1.0
+    d = {
+        "point_clouds": torch.cat([xyz, rgb], -1),
+        "auxiliary_task": torch.cat([t, quat], 1),
+        "q_feat": {"input_ids": ids, "attention_mask": torch.ones(batch, N_TEXT, dtype=torch.long)},
+        "answer_cat_scores": ans,
+    }
+    return to_device(d, device)
+
+
+def to_device(d, device):
+    out = {}
+    for k, v in d.items():
+        out[k] = to_device(v, device) if isinstance(v, dict) else v.to(device).contiguous()
+    return out
+
+
+def group_algorithmic_bytes(b, n, m, ns, c):
+    """group_points(C) = B*(4CN + 4*M*ns + 4C*M*ns); the fused kernel moves the xyz
+    group (C=3) and the feature group (C=c) in one launch and reads idx once."""
+    return b * (4 * 3 * n + 4 * c * n + 4 * m * ns + 4 * (3 + c) * m * ns)
+
+
+def cpu_baseline(model, seed):
+    """The same step on the host cores through the ORACLE (kind "port"): one scene (B=1) of the
+    B=8 workload, forward + backward.  Checker code only -- never on the product path."""
+    from oracle import pointnet2_ref, qformer_ref
+    from situation3d_amd.pointnet2 import pointnet2_utils
+    import copy
+    cpu_model = copy.deepcopy(model).cpu().train()
+    batch = synthetic_batch(1, N_POINTS, seed, "cpu")
+    saved_ext = pointnet2_utils._ext
+    pointnet2_utils._ext = pointnet2_ref  # CPU restatement of the nine ops
+    try:
+        t0 = time.perf_counter()
+        pc = batch["point_clouds"]
+        xyz = pc[..., :3].contiguous()
+        feats = pc[..., 3:].transpose(1, 2).contiguous()
+        tok_xyz, tok_feat = cpu_model.encoder(xyz, feats)
+        tok_feat = tok_feat.transpose(1, 2)
+        pose = batch["auxiliary_task"]
+        M = pointnet2_ref.pose_to_matrix(pose)
+        sit = torch.einsum("bcr,bnc->bnr", M[:, :3, :3], tok_xyz - pose[:, None, :3])
+        tokens = tok_feat + cpu_model.pos_embed(sit)
+        sd = dict(cpu_model.Qformer.bert.state_dict())
+        sd.update({k: v for k, v in cpu_model.Qformer.bert.named_parameters()})
+        c = cpu_model.Qformer.config
+        cfg = dict(num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                   layer_norm_eps=c.layer_norm_eps, add_cross_attention=True,
+                   cross_attention_freq=c.cross_attention_freq)
+        q = batch["q_feat"]
+        att = torch.cat([torch.ones(1, N_QUERY, dtype=torch.long), q["attention_mask"]], 1)
+        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=cpu_model.query_tokens.expand(1, -1, -1),
+                                        input_ids=q["input_ids"], attention_mask=att,
+                                        encoder_hidden_states=tokens)
+        pooled = hidden[:, :N_QUERY].mean(1)
+        dd = dict(batch)
+        dd["aux_scores"] = cpu_model.aux_reg(pooled)
+        dd["answer_scores"] = cpu_model.answer_cls(pooled)
+        loss, _ = get_loss(dd)
+        loss.backward()
+        dt = time.perf_counter() - t0
+    finally:
+        pointnet2_utils._ext = saved_ext
+    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": pointnet2_ref.num_threads(),
+            "kind": "port",
+            "sample": "1 scene (B=1 of the B=8 step), 40k pts, fwd+bwd, oracle C ops (OpenMP) + "
+                      "torch CPU fp32 MLP/Q-Former, %d host cores, %.1f s" % (os.cpu_count(), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
+    device = torch.device("cuda", local)
+    torch.manual_seed(1234)  # identical initial weights on every rank
+    model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
+    optimizer = build_optimizer(model)
+    reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+
+    n_batches = min(4, args.steps + args.warmup)
+    batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device) for i in range(n_batches)]
+
+    def step(i):
+        return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+
+    for i in range(args.warmup):
+        step(i)
+    _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_furthest_point_sampling"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    recs = _lib.timing_records()
+    _lib.enable_timing(None)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        def kernel_ms(name):
+            r = recs[name]
+            return [s.elapsed_time(e) for s, e, _ in r]
+
+        grp = kernel_ms("sig3d_query_group_fused")
+        grp_bytes = sum(group_algorithmic_bytes(BATCH, *lvl) for lvl in SA_LEVELS) * args.steps
+        achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
+        bq = kernel_ms("sig3d_ball_query")
+        fps = kernel_ms("sig3d_furthest_point_sampling")
+        out = {
+            "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
+            "value": round(world * BATCH * args.steps / dt, 3),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SQA3D train step fwd+bwd+AdamW, 40k pts/scene, B=8/GPU, "
+                                   "SA1-4 -> 256 tokens -> situational re-encode -> Q-Former "
+                                   "(32 queries + 20 question tokens, 12 layers)",
+                       "global_batch": world * BATCH, "points_per_scene": N_POINTS,
+                       "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
+            "kernels_ms_per_step": {"query_group_fused": round(sum(grp) / args.steps, 4),
+                                    "ball_query": round(sum(bq) / args.steps, 4),
+                                    "furthest_point_sampling": round(sum(fps) / args.steps, 4)},
+            "final_loss": round(float(loss.item()), 5),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, 1234)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

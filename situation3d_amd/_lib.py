@@ -77,9 +77,30 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_timed = None  # None, or {entry-point name: [(start_event, end_event, int-args), ...]}
+
+
+def enable_timing(names):
+    """Bracket every call of the named entry points with HIP events on the launch stream
+    (torch's current stream).  bench.py uses this to get per-launch kernel durations live."""
+    global _timed
+    _timed = {n: [] for n in names} if names else None
+
+
+def timing_records():
+    return _timed
+
+
 def call(name, *args):
     lib = load()
+    rec = _timed.get(name) if _timed is not None else None
+    if rec is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
     status = getattr(lib, name)(*args)
+    if rec is not None:
+        end.record()
+        rec.append((start, end, tuple(a for a in args if isinstance(a, int))))
     if status != 0:
         raise Sig3dError("%s failed: %s" % (name, lib.sig3d_last_error().decode()))
 

@@ -1,0 +1,116 @@
+"""The composed hot path: PointNet++ point encoder -> situational pose re-encode -> Q-Former
+fusion, behind the reference's `forward(data_dict) -> data_dict` model API
+(situation3d/models/sqa_module.py:281-392; keys listed in SURVEY.md section 3.1).
+
+The three stages exist in the reference in three disjoint places, so the
+COMPOSITION is this build's; each stage is parity-checked against the reference code of that
+stage.  Shapes follow the north star: N = 40 000 points / scene -> SA1..SA4 (VoteNet lineage:
+2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16) -> 256 visual tokens x 256 channels, which is
+exactly SIG3D's visual-token interface (lib/config.py:104-105); 32 learned queries + the
+question tokens attend to them in a BLIP-2 Q-Former (cross-attention every 2nd layer).
+"""
+import torch
+import torch.nn as nn
+
+from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from .qformer import init_Qformer
+from .situational import gaussian_localisation_target, situational_transform
+
+
+class PointNet2Encoder(nn.Module):
+    """4 x SA (+ optional 2 x FP) backbone; SA hyper-parameters as in SURVEY.md section 8."""
+
+    def __init__(self, input_feature_dim=3, use_fp=False):
+        super().__init__()
+        self.sa1 = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64,
+                                         mlp=[input_feature_dim, 64, 64, 128], use_xyz=True,
+                                         normalize_xyz=True)
+        self.sa2 = PointnetSAModuleVotes(npoint=1024, radius=0.4, nsample=32,
+                                         mlp=[128, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.sa3 = PointnetSAModuleVotes(npoint=512, radius=0.8, nsample=16,
+                                         mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.sa4 = PointnetSAModuleVotes(npoint=256, radius=1.2, nsample=16,
+                                         mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.use_fp = use_fp
+        if use_fp:
+            self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+            self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    def forward(self, xyz, features, inds=None):
+        """xyz (B,N,3), features (B,C,N) -> token xyz (B,T,3), token features (B,256,T).
+        `inds` optionally carries precomputed FPS indices for the four levels (geometry does not
+        depend on the features, so it can be produced ahead of time on another stream)."""
+        inds = inds or (None, None, None, None)
+        xyz1, f1, i1 = self.sa1(xyz, features, inds[0])
+        xyz2, f2, i2 = self.sa2(xyz1, f1, inds[1])
+        xyz3, f3, i3 = self.sa3(xyz2, f2, inds[2])
+        xyz4, f4, i4 = self.sa4(xyz3, f3, inds[3])
+        if not self.use_fp:
+            return xyz4, f4
+        f3u = self.fp1(xyz3, xyz4, f3, f4)
+        f2u = self.fp2(xyz2, xyz3, f2, f3u)
+        return xyz2, f2u
+
+
+class SIG3DQFormer(nn.Module):
+    """data_dict in : point_clouds (B,N,3+C) f32 [xyz | per-point features],
+                      auxiliary_task (B,7) f32 [x,y,z, quat_xyzw] (situation; sepdataset.py:306-315),
+                      q_feat {"input_ids" (B,T) i64, "attention_mask" (B,T)} (question tokens)
+       data_dict out: answer_scores (B,num_answers), aux_scores (B,7), auxiliary_task_loc_gt (B,T),
+                      pred_pos_likelihood (B,T), pred_rotation (B,T,6), scene_positions (B,T,3),
+                      att_feat_pre (B,T,256), att_feat_ori (B,32,768)
+    """
+
+    def __init__(self, num_answers=706, input_feature_dim=3, num_query_token=32, use_fp=False,
+                 qformer_overrides=None, vocab_size=30522):
+        super().__init__()
+        self.encoder = PointNet2Encoder(input_feature_dim, use_fp)
+        feat_dim = 256
+        # sqa_module.py:274-278 uses a 2-D (x,y) MLP; the situational frame is 3-D here
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, feat_dim))
+        overrides = dict(vocab_size=vocab_size)
+        overrides.update(qformer_overrides or {})
+        self.Qformer, self.query_tokens = init_Qformer(num_query_token, feat_dim, **overrides)
+        hidden = self.Qformer.config.hidden_size
+        self.position_head = nn.Linear(feat_dim, 1)
+        self.rotation_head = nn.Linear(feat_dim, 6)
+        self.aux_reg = nn.Sequential(nn.Linear(hidden, hidden), nn.GELU(), nn.Linear(hidden, 7))
+        self.answer_cls = nn.Sequential(nn.Linear(hidden, hidden), nn.GELU(), nn.Dropout(0.1),
+                                        nn.Linear(hidden, num_answers))
+
+    def forward(self, data_dict):
+        pc = data_dict["point_clouds"]
+        xyz = pc[..., :3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
+        tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("fps_inds"))
+        tok_feat = tok_feat.transpose(1, 2).contiguous()            # (B,T,256)
+        data_dict["scene_positions"] = tok_xyz
+        data_dict["att_feat_pre"] = tok_feat
+
+        # situational re-encode: token positions in the agent's frame, R(q)^T (p - t)
+        pose = data_dict["auxiliary_task"]
+        sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
+        data_dict["situational_positions"] = sit_xyz
+        data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose[:, :3])
+        tokens = tok_feat + self.pos_embed(sit_xyz)
+
+        data_dict["pred_pos_likelihood"] = self.position_head(tokens).squeeze(-1)
+        data_dict["pred_rotation"] = self.rotation_head(tokens)
+
+        q = data_dict.get("q_feat")
+        b = tokens.shape[0]
+        query_tokens = self.query_tokens.expand(b, -1, -1)
+        kwargs = {}
+        if q is not None:
+            ones = torch.ones(b, query_tokens.shape[1], dtype=q["attention_mask"].dtype,
+                              device=tokens.device)
+            kwargs = dict(input_ids=q["input_ids"],
+                          attention_mask=torch.cat([ones, q["attention_mask"]], dim=1))
+        out = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=tokens,
+                                encoder_attention_mask=None, return_dict=True, **kwargs)
+        fused = out.last_hidden_state[:, :query_tokens.shape[1], :]
+        data_dict["att_feat_ori"] = fused
+        pooled = fused.mean(dim=1)
+        data_dict["aux_scores"] = self.aux_reg(pooled)
+        data_dict["answer_scores"] = self.answer_cls(pooled)
+        return data_dict

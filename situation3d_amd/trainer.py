@@ -1,0 +1,77 @@
+"""Training-step semantics of the reference's two harnesses, for the composed hot path.
+
+SQA3D side (lib/solver.py + lib/loss_helper.py + situation3d/train/train.py):
+  * loss = QA_W * answer_loss + SITUATION_W * (POS_W * pos + ROT_W * rot), then `loss *= 10`
+    (loss_helper.py:195-227, 286-300; weights lib/config.py:72-79);
+  * answer loss = BCE-with-logits, reduction 'sum' / batch when soft multi-hot targets
+    (`answer_cat_scores`) are present, cross-entropy on `answer_cat` otherwise (:222-227);
+  * zero_grad -> backward -> clip_grad_VALUE_(1.0) -> optimizer.step()  (solver.py:618-627);
+  * AdamW with no weight decay on names containing "bias" / "LayerNorm.weight"
+    (train.py:186-238; scripts/train.sh:7: lr 2e-5, wd 0.05).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LOSS_W = dict(SITUATION_W=0.1, QA_W=0.1, SITUATION_POS_W=1.0, SITUATION_ROT_W=1.0)
+
+
+def compute_answer_classification_loss(data_dict):
+    if "answer_cat_scores" in data_dict:
+        return F.binary_cross_entropy_with_logits(
+            data_dict["answer_scores"], data_dict["answer_cat_scores"],
+            reduction="sum") / data_dict["answer_scores"].shape[0]
+    return F.cross_entropy(data_dict["answer_scores"], data_dict["answer_cat"])
+
+
+def compute_aux_situation_loss(data_dict, tag="__l2__quat__"):
+    fn = F.mse_loss if "__l2__" in tag else F.l1_loss
+    pos = fn(data_dict["aux_scores"][:, :3], data_dict["auxiliary_task"][:, :3], reduction="mean")
+    rot = fn(data_dict["aux_scores"][:, 3:], data_dict["auxiliary_task"][:, 3:], reduction="mean")
+    return LOSS_W["SITUATION_POS_W"] * pos + LOSS_W["SITUATION_ROT_W"] * rot, pos, rot
+
+
+def get_loss(data_dict, situation_loss_tag="__l2__quat__", use_aux_situation=True, use_answer=True):
+    zero = data_dict["answer_scores"].new_zeros(())
+    data_dict["answer_loss"] = compute_answer_classification_loss(data_dict) if use_answer else zero
+    if use_aux_situation:
+        aux, pos, rot = compute_aux_situation_loss(data_dict, situation_loss_tag)
+    else:
+        aux = pos = rot = zero
+    data_dict["aux_loss"], data_dict["pos_loss"], data_dict["rot_loss"] = aux, pos, rot
+    loss = LOSS_W["SITUATION_W"] * aux + LOSS_W["QA_W"] * data_dict["answer_loss"]
+    loss = loss * 10  # loss_helper.py:300 "amplify"
+    data_dict["loss"] = loss
+    return loss, data_dict
+
+
+def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name="adamw"):
+    no_decay_filter = ("bias", "LayerNorm.weight")
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if any(nd in n for nd in no_decay_filter) else decay).append(p)
+    groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
+    cls = torch.optim.AdamW if name == "adamw" else torch.optim.Adam
+    # fused=True: one multi-tensor HIP kernel per step instead of ~4 launches per parameter
+    kw = {"fused": True} if all(p.is_cuda for g in groups for p in g["params"]) else {}
+    return cls(groups, lr=lr, betas=betas, eps=eps, **kw)
+
+
+def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
+    """One Solver iteration (solver.py:374-402, 618-627).  With a GradBucketReducer the gradient
+    all-reduce is launched bucket by bucket from inside backward and joined before clipping."""
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=False)
+    data_dict = model(data_dict)
+    loss, data_dict = get_loss(data_dict)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    if max_grad_value is not None and max_grad_value > 0:
+        nn.utils.clip_grad_value_(model.parameters(), clip_value=max_grad_value)
+    optimizer.step()
+    return loss

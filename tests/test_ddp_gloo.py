@@ -1,0 +1,110 @@
+"""N>1 path on CPU: two gloo ranks, the bucketed gradient reducer must reproduce the reference
+DDP semantics (mean of per-rank gradients, identical parameters after a step on every rank;
+runner_base.py:88-95), including parameters that receive no gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = nn.Sequential(nn.Linear(16, 64), nn.GELU(), nn.Linear(64, 64), nn.GELU(),
+                                  nn.Linear(64, 4))
+        self.unused = nn.Linear(8, 8)  # never used in forward: gets no gradient
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return _Net()
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from situation3d_amd.ddp import GradBucketReducer, init_distributed
+    init_distributed(backend="gloo")
+    model = _make_model()
+    # tiny buckets: several collectives, exercised in backward order
+    reducer = GradBucketReducer(model.parameters(), bucket_bytes=4096)
+    assert reducer.num_collectives() >= 3
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    x, y = _data(rank)
+    for _ in range(2):
+        reducer.zero_grad()
+        loss = ((model(x) - y) ** 2).mean()
+        loss.backward()
+        reducer.finish()
+        grads = [p.grad.clone() for p in model.parameters()]
+        opt.step()
+    torch.save({"grads": grads, "params": [p.detach().clone() for p in model.parameters()]},
+               os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_reducer_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b), "ranks diverged"
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)
+
+    # single-process reference: mean of the two ranks' gradients, same optimiser
+    model = _make_model()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=False)
+        for p in model.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        for rank in range(world):
+            x, y = _data(rank)
+            (((model(x) - y) ** 2).mean() / world).backward()
+        grads = [p.grad.clone() for p in model.parameters()]
+        opt.step()
+    for a, b in zip(r0["grads"], grads):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    for a, b in zip(r0["params"], model.parameters()):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_reducer_single_process_is_identity():
+    from situation3d_amd.ddp import GradBucketReducer
+    model = _make_model()
+    reducer = GradBucketReducer(model.parameters(), bucket_bytes=1 << 20)
+    x, y = _data(0)
+    reducer.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    reducer.finish()
+    ref = _make_model()
+    ((ref(x) - y) ** 2).mean().backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        if q.grad is None:
+            assert p.grad.abs().max() == 0
+        else:
+            assert torch.equal(p.grad, q.grad)
