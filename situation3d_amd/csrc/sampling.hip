@@ -129,6 +129,153 @@ int launch_fps(int b, int n, int m, int L, const float *dataset, float *temp, in
   return 0;
 }
 
+// ---- cooperative FPS: one scene spread over W workgroups ------------------------------------
+// A 40 000-point scene does not fit the register file of ONE workgroup (16 waves x 128 VGPRs
+// hold ~24 points per thread), and a global-memory overflow tail costs ~5 us per round.  Here W
+// workgroups each keep n/W points in registers and exchange their per-round candidate
+// (distance, key) through 8-byte {round, value} granules in global memory:
+//   - a granule is ONE aligned 8-byte agent-scope relaxed store (sc1, write-through), so the
+//     data is its own flag -- no fence, no separate flag word, no torn reads;
+//   - consumers poll with agent-scope relaxed loads (L1 bypass) from one wave only;
+//   - slots are double-buffered by round parity: a workgroup can be at most one round ahead of
+//     its peers (to publish round j+1 it must have consumed every peer's round j), so a slot is
+//     never overwritten before all peers have read it;
+//   - all polled words are zeroed by a memset node on the same stream before EVERY launch;
+//   - the result never depends on which XCD / CU a workgroup lands on.  Block ids are arranged so
+//     that (with b a multiple of 8) the W workgroups of a scene share an XCD -- speed only.
+// All W*b workgroups must be co-resident (W*b <= 256 CUs is checked by the launcher); every spin
+// is bounded and a timeout poisons the output with -1 instead of hanging the GPU.
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+constexpr int FPS_SLOT_U64 = 64;  // per scene: 2 parities x up to 8 workgroups x {val,key}, padded
+
+template <int NT, int PPT, int W>
+__global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L,
+                                                      const float *__restrict__ dataset_all,
+                                                      u64 *__restrict__ slots_all,
+                                                      int *__restrict__ idxs_all) {
+  constexpr int NW = NT / 64;
+  __shared__ int s_val[2][NW];
+  __shared__ unsigned s_key[2][NW];
+  __shared__ int s_win[2][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scene = blockIdx.x % b, w = blockIdx.x / b;
+  const float *dataset = dataset_all + (size_t)scene * n * 3;
+  int *idxs = idxs_all + (size_t)scene * m;
+  gu64 *slots = (gu64 *)(slots_all + (size_t)scene * FPS_SLOT_U64);
+  const unsigned bsmask = (1u << L) - 1u;
+
+  // thread's points: k = tid + NT*(s*W + w); NT is a multiple of the reference block size, so
+  // ascending slot s == ascending key inside a thread (see fps_kernel)
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+#pragma unroll
+  for (int s = 0; s < PPT; ++s) {
+    const int k = tid + NT * (s * W + w);
+    float x = 0.f, y = 0.f, z = 0.f, t = -1.f;
+    if (k < n) {
+      x = dataset[3 * k + 0];
+      y = dataset[3 * k + 1];
+      z = dataset[3 * k + 2];
+      const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+      t = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+    }
+    px[s] = x; py[s] = y; pz[s] = z; pt[s] = t;
+  }
+
+  int old = 0;
+  if (tid == 0 && w == 0) idxs[0] = 0;
+  bool dead = false;
+
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[3 * old + 0], y1 = dataset[3 * old + 1], z1 = dataset[3 * old + 2];
+    float best = -1.f;
+    int bslot = 0;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
+      const float t = fminf(d, pt[s]);
+      pt[s] = t;
+      const bool gt = t > best;
+      best = gt ? t : best;
+      bslot = gt ? s : bslot;
+    }
+    const int bk = tid + NT * (bslot * W + w);
+    const int myv = __builtin_bit_cast(int, best);
+    const int wv = wave_allreduce_max_i32(myv);
+    const unsigned mykey = (myv == wv) ? fps_key((unsigned)bk, L, bsmask) : 0xFFFFFFFFu;
+    const unsigned wk = wave_allreduce_min_u32(mykey);
+    const int par = j & 1;
+    if (lane == 0) {
+      s_val[par][wave] = wv;
+      s_key[par][wave] = wk;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int ov = s_val[par][lane & (NW - 1)];
+      const unsigned ok = s_key[par][lane & (NW - 1)];
+      const int lv = row_allreduce_max_i32(ov);
+      const unsigned lk = row_allreduce_min_u32(ov == lv ? ok : 0xFFFFFFFFu);
+      gu64 *slot = slots + (size_t)par * (2 * 8);
+      if (lane == 0) {
+        __hip_atomic_store(slot + 2 * w + 0, ((u64)(unsigned)j << 32) | (unsigned)lv,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slot + 2 * w + 1, ((u64)(unsigned)j << 32) | lk, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // lanes 0..W-1 each wait for one peer's pair (lane w reads its own, already published)
+      int pv = (int)0x80000000;
+      unsigned pk = 0xFFFFFFFFu;
+      unsigned spins = 0;
+      bool ok_all = false;
+      while (!ok_all) {
+        bool mine = true;
+        if (lane < W) {
+          const u64 a = __hip_atomic_load(slot + 2 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const u64 c = __hip_atomic_load(slot + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          mine = ((unsigned)(a >> 32) == (unsigned)j) && ((unsigned)(c >> 32) == (unsigned)j);
+          pv = (int)(unsigned)a;
+          pk = (unsigned)c;
+        }
+        ok_all = __all(mine);
+        if (!ok_all) {
+          if (++spins > (1u << 22)) { dead = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (lane >= W) { pv = (int)0x80000000; pk = 0xFFFFFFFFu; }
+      const int gv = row_allreduce_max_i32(pv);
+      const unsigned gk = row_allreduce_min_u32(pv == gv ? pk : 0xFFFFFFFFu);
+      if (lane == 0) {
+        s_win[par][0] = dead ? (int)0x80000001 : gv;
+        s_win[par][1] = (int)gk;
+      }
+    }
+    __syncthreads();
+    const int gvu = __builtin_amdgcn_readfirstlane(s_win[par][0]);
+    const unsigned gku = (unsigned)__builtin_amdgcn_readfirstlane(s_win[par][1]);
+    if (gvu == (int)0x80000001) {  // a peer never showed up: poison instead of hanging
+      if (w == 0)
+        for (int jj = j + tid; jj < m; jj += NT) idxs[jj] = -1;
+      return;
+    }
+    old = (gvu < 0) ? 0 : (int)fps_unkey(gku, L);
+    if (tid == 0 && w == 0) idxs[j] = old;
+  }
+}
+
+template <int NT, int PPT, int W>
+int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
+                    hipStream_t stream) {
+  // the granule slots live at the front of the caller's temp scratch (b*n floats >= b*128)
+  SIG3D_HIP_TRY(hipMemsetAsync(temp, 0, sizeof(u64) * (size_t)b * FPS_SLOT_U64, stream));
+  hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
+                     dataset, (u64 *)temp, idxs);
+  SIG3D_LAUNCH_CHECK("fps_coop_kernel");
+  return 0;
+}
+
 // ---- gather_points: out[b,c,j] = points[b,c,idx[b,j]] ---------------------------------------
 __global__ __launch_bounds__(256) void gather_points_kernel(int c, int n, int m,
                                                             const float *__restrict__ points,
@@ -182,7 +329,27 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
   if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 16384) return launch_fps<1024, 16>(b, n, m, L, dataset, temp, idxs, stream);
-  return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 24576) return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
+  if (n <= 196608) {
+    // cooperative kernel; at most 64 co-resident workgroups per launch (so that several
+    // concurrent launches -- other streams, other processes -- can never starve each other)
+    const int W = n <= 98304 ? 4 : 8;
+    const int chunk = 64 / W;
+    for (int s0 = 0; s0 < b; s0 += chunk) {
+      const int bc = (b - s0) < chunk ? (b - s0) : chunk;
+      const float *ds = dataset + (size_t)s0 * n * 3;
+      float *tp = temp + (size_t)s0 * n;
+      int *ix = idxs + (size_t)s0 * m;
+      int rc;
+      if (n <= 40960) rc = launch_fps_coop<1024, 10, 4>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 65536) rc = launch_fps_coop<1024, 16, 4>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 98304) rc = launch_fps_coop<1024, 24, 4>(bc, n, m, L, ds, tp, ix, stream);
+      else rc = launch_fps_coop<1024, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
 }
 
 extern "C" int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -33,8 +33,9 @@ def _sample_centres(xyz, npoint, inds=None):
 
 
 def _max_over_samples(x):
-    """F.max_pool2d(x, [1, nsample]).squeeze(-1)  (pointnet2_modules.py:66-69)"""
-    return F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+    """F.max_pool2d(x, [1, nsample]).squeeze(-1)  (pointnet2_modules.py:66-69), as a last-dim
+    max reduction (same values; the gradient goes to one arg-max element in both forms)."""
+    return torch.max(x, dim=3)[0]
 
 
 def _build_scales(npoint, radii, nsamples, mlps, bn, use_xyz, sample_uniformly):
@@ -133,7 +134,7 @@ class PointnetSAModuleVotes(nn.Module):
 
         new_features = self.mlp_module(grouped_features)  # (B, mlp[-1], npoint, nsample)
         if self.pooling == 'max':
-            new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+            new_features = torch.max(new_features, dim=3, keepdim=True)[0]
         elif self.pooling == 'avg':
             new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
         elif self.pooling == 'rbf':

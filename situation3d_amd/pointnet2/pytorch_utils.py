@@ -6,11 +6,29 @@ Only what the hot path uses is kept: `SharedMLP` (pytorch_utils.py:11-36), its `
 reference's, so `state_dict()` keys match checkpoint for checkpoint
 (`layer{i}.conv.weight`, `layer{i}.bn.bn.{weight,bias,running_mean,running_var,...}`).
 """
+import torch
 import torch.nn as nn
 
 
 def _named(block, name, module):
     block.add_module(name, module)
+
+
+class PointwiseConv2d(nn.Conv2d):
+    """nn.Conv2d whose 1x1 / stride-1 case runs as ONE batched GEMM W(Cout,Cin) @ X(B,Cin,P*S)
+    (library GEMM, f32) instead of MIOpen's NCHW->NHWC transposes + implicit-GEMM convolution.
+    Same parameters, same state_dict keys, same math as the reference's Conv2d 1x1
+    (pytorch_utils.py:147-185)."""
+
+    def forward(self, x):
+        if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) \
+                and self.groups == 1 and x.dim() == 4:
+            b, cin, p, s = x.shape
+            y = torch.matmul(self.weight.view(self.out_channels, cin), x.reshape(b, cin, p * s))
+            if self.bias is not None:
+                y = y + self.bias.view(1, -1, 1)
+            return y.view(b, self.out_channels, p, s)
+        return super().forward(x)
 
 
 class _BNWrap(nn.Sequential):
@@ -72,7 +90,7 @@ class Conv2d(_ConvBlock):
     def __init__(self, in_size, out_size, *, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0),
                  activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_,
                  bias=True, preact=False, name=""):
-        super().__init__(nn.Conv2d, BatchNorm2d, in_size, out_size, kernel_size, stride, padding,
+        super().__init__(PointwiseConv2d, BatchNorm2d, in_size, out_size, kernel_size, stride, padding,
                          activation, bn, init, bias, preact, name)
 
 
