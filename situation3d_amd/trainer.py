@@ -54,8 +54,10 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
         (no_decay if any(nd in n for nd in no_decay_filter) else decay).append(p)
     groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
     cls = torch.optim.AdamW if name == "adamw" else torch.optim.Adam
-    # fused=True: one multi-tensor HIP kernel per step instead of ~4 launches per parameter
-    kw = {"fused": True} if all(p.is_cuda for g in groups for p in g["params"]) else {}
+    # fused: one multi-tensor HIP kernel per step instead of ~4 launches per parameter;
+    # capturable: step counters live on the device so the step can sit inside a hipGraph
+    on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+    kw = {"fused": True, "capturable": True} if on_gpu else {}
     return cls(groups, lr=lr, betas=betas, eps=eps, **kw)
 
 
