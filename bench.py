@@ -136,40 +136,43 @@ def main():
     n_batches = min(4, args.steps + args.warmup)
     batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device) for i in range(n_batches)]
 
-    use_graph = (world == 1) and not args.no_graph
-    if use_graph:
-        graphed = GraphedTrainStep(model, optimizer, batches[0])
-
-        def step(i):
-            return graphed(batches[i % n_batches])
-    else:
-        def step(i):
-            return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
-
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    final_loss = float(loss.item())
-
-    # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
-    # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
-    # issued once more eagerly right after the timed region and bracketed there.
+    # every forward/backward of this process runs on ONE non-default stream (see graph_step.py)
+    work = torch.cuda.Stream(device)
     KSTEPS = 3
-    _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_furthest_point_sampling"])
-    for i in range(KSTEPS):
-        train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
-    torch.cuda.synchronize()
-    recs = _lib.timing_records()
-    _lib.enable_timing(None)
+    with torch.cuda.stream(work):
+        use_graph = (world == 1) and not args.no_graph
+        if use_graph:
+            graphed = GraphedTrainStep(model, optimizer, batches[0])
+
+            def step(i):
+                return graphed(batches[i % n_batches])
+        else:
+            def step(i):
+                return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+
+        for i in range(args.warmup):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(args.warmup + i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        final_loss = float(loss.item())
+
+        # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
+        # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
+        # issued once more eagerly right after the timed region and bracketed there.
+        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_furthest_point_sampling"])
+        for i in range(KSTEPS):
+            train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+        torch.cuda.synchronize()
+        recs = _lib.timing_records()
+        _lib.enable_timing(None)
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:

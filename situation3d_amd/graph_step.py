@@ -9,8 +9,14 @@ by the hardware queue instead of the interpreter.  Everything on the path is cap
 construction: the C-ABI kernels launch on the capturing stream, their zero-fills are memset
 nodes, no entry point synchronises or allocates, and the optimizer runs in `capturable` mode.
 
+Stream discipline: warm-up, capture, replay and any eager steps of the same model must all run
+on ONE non-default stream (`with torch.cuda.stream(work): ...`).  Autograd's AccumulateGrad
+nodes remember the stream they were first used on; if that differs from the capture stream,
+backward forks onto the other stream inside the capture and the allocator's single-stream
+assumption for graph pools breaks (observed on MI355X as corrupted activations / faults).
+
 Inputs live in static device buffers that are refreshed (device-to-device copy) before each
-replay; outputs (loss) are read from static buffers after it.
+replay; outputs (loss, answer_scores, ...) are read from static buffers after it.
 """
 import torch
 import torch.nn as nn
@@ -32,38 +38,36 @@ def _clone(d):
 
 class GraphedTrainStep:
     """Captures `zero_grad -> forward -> get_loss -> backward -> clip_grad_value_ -> step`
-    (lib/solver.py:374-402, 618-627) for one fixed batch shape."""
+    (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3):
-        self.model, self.optimizer = model, optimizer
-        self.max_grad_value = max_grad_value
+        stream = torch.cuda.current_stream()
+        if stream == torch.cuda.default_stream():
+            raise RuntimeError("GraphedTrainStep must be built (and used) inside "
+                               "`with torch.cuda.stream(work_stream):` -- not on the default stream")
+        self.model, self.optimizer, self.stream = model, optimizer, stream
         self.static_batch = _clone(example_batch)
         self.static_loss = None
+        self.static_out = None
         self.graph = torch.cuda.CUDAGraph()
         params = [p for p in model.parameters() if p.requires_grad]
 
         def one_step():
             out = model(dict(self.static_batch))
-            loss, _ = get_loss(out)
+            loss, out = get_loss(out)
+            self.static_out = out  # answer_scores, aux_scores, ... of the last replay
             loss.backward()
             if max_grad_value is not None and max_grad_value > 0:
                 nn.utils.clip_grad_value_(params, clip_value=max_grad_value)
             optimizer.step()
             return loss
 
-        # warm-up on a side stream (library workspaces, autotuning, allocator pools), as required
-        # before capture
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                optimizer.zero_grad(set_to_none=True)
-                one_step()
-        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(warmup):  # library workspaces, autotuning, allocator pools
+            optimizer.zero_grad(set_to_none=True)
+            one_step()
         torch.cuda.synchronize()
-
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=stream):
             self.static_loss = one_step()
         torch.cuda.synchronize()
 
