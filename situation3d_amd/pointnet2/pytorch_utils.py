@@ -24,7 +24,10 @@ class PointwiseConv2d(nn.Conv2d):
         if self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0) \
                 and self.groups == 1 and x.dim() == 4:
             b, cin, p, s = x.shape
-            y = torch.matmul(self.weight.view(self.out_channels, cin), x.reshape(b, cin, p * s))
+            # bmm with a stride-0 batch of W: torch.matmul(2-D, 3-D) would fold the batch into
+            # rows and materialise TRANSPOSED copies of the whole activation (fwd and bwd)
+            w = self.weight.view(1, self.out_channels, cin).expand(b, -1, -1)
+            y = torch.bmm(w, x.reshape(b, cin, p * s))
             if self.bias is not None:
                 y = y + self.bias.view(1, -1, 1)
             return y.view(b, self.out_channels, p, s)
