@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="compute FPS/ball-query geometry inline instead of one batch ahead")
     args = ap.parse_args()
 
     rank, local, world = init_distributed()
@@ -142,10 +144,11 @@ def main():
     with torch.cuda.stream(work):
         use_graph = (world == 1) and not args.no_graph
         if use_graph:
-            graphed = GraphedTrainStep(model, optimizer, batches[0])
+            graphed = GraphedTrainStep(model, optimizer, batches[0],
+                                       prefetch_geometry=not args.no_prefetch)
 
             def step(i):
-                return graphed(batches[i % n_batches])
+                return graphed(batches[i % n_batches], batches[(i + 1) % n_batches])
         else:
             def step(i):
                 return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)

@@ -49,6 +49,13 @@ int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,
 int sig3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                              const int *idx, float *grad_points, void *stream);
 
+/* Fuses the centre gather of _PointnetSAModuleBase.forward / PointnetSAModuleVotes.forward
+ *   lib/pointnet2/pointnet2_modules.py:52-56, 233-240
+ * (xyz.transpose(1,2).contiguous() -> gather_operation -> .transpose(1,2).contiguous()):
+ * xyz (b,n,3), idx (b,m) -> out (b,m,3) with out[b,j,:] = xyz[b,idx[b,j],:]. */
+int sig3d_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out,
+                     void *stream);
+
 /* replaces query_ball_point_kernel_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)
  *   ball_query.cpp:4-6, ball_query_gpu.cu:9-54.
  * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): first `nsample` points (in index

@@ -302,6 +302,20 @@ __global__ __launch_bounds__(256) void gather_points_grad_kernel(int c, int n, i
                     grad_out[((size_t)bi * c + l) * m + j]);
 }
 
+// new_xyz[b,j,:] = xyz[b,idx[b,j],:] -- the (B,N,3)-layout gather that _PointnetSAModuleBase
+// spells as transpose -> gather_operation -> transpose (pointnet2_modules.py:233-240)
+__global__ __launch_bounds__(256) void gather_xyz_kernel(int n, int m, const float *__restrict__ xyz,
+                                                         const int *__restrict__ idx,
+                                                         float *__restrict__ out) {
+  const int bi = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int a = idx[(size_t)bi * m + j];
+  const float *src = xyz + ((size_t)bi * n + a) * 3;
+  float *dst = out + ((size_t)bi * m + j) * 3;
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
 // cuda_utils.h:13-19 of the reference (host libm, double log ratio truncated)
 int ref_opt_n_threads_log2(int work_size) {
   int pow_2 = (int)(log((double)work_size) / log(2.0));
@@ -375,5 +389,16 @@ extern "C" int sig3d_gather_points_grad(int b, int c, int n, int npoints, const 
   hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, stream, c, n, npoints,
                      grad_out, idx, grad_points);
   SIG3D_LAUNCH_CHECK("gather_points_grad_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, float *out,
+                                void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+  if (b == 0 || m == 0) return 0;
+  dim3 grid(sig3d_ceil_div(m, 256), b);
+  hipLaunchKernelGGL(gather_xyz_kernel, grid, dim3(256), 0, stream, n, m, xyz, idx, out);
+  SIG3D_LAUNCH_CHECK("gather_xyz_kernel");
   return 0;
 }

@@ -1,0 +1,63 @@
+"""Geometry plan of the point encoder: everything in the SA stack that depends on xyz ONLY.
+
+FPS indices, centre coordinates and ball-query neighbour lists of all set-abstraction levels are
+functions of the input coordinates alone (pointnet2_modules.py:233-240 + pointnet2_utils.py:334)
+-- no learned parameter and no feature enters them.  FPS is a chain of ~3800 strictly dependent
+rounds per step (latency-bound, a few workgroups), so it is the worst possible citizen of the
+critical path and the best possible candidate for overlap: a `GeometryPlan` computes the whole
+chain into PREALLOCATED buffers through the C ABI (no allocator traffic, safe on a side stream
+and inside hipGraph capture), which lets the training step of batch i run concurrently with the
+geometry of batch i+1 (graph_step.GraphedTrainStep, `prefetch_geometry=True`) -- the same role
+the reference gives its DataLoader workers for the CPU-side voxelisation (lib/sepdataset.py).
+
+The numbers produced are bit-identical to calling the ops inline.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class GeometryPlan:
+    """levels: list of (npoint, radius, nsample) from the first SA layer down."""
+
+    def __init__(self, batch, n_points, levels, device):
+        self.levels = list(levels)
+        self.batch, self.n_points = batch, n_points
+        self.inds, self.new_xyz, self.ball_idx, self._temp = [], [], [], []
+        n = n_points
+        for npoint, radius, nsample in self.levels:
+            self.inds.append(torch.zeros(batch, npoint, dtype=torch.int32, device=device))
+            self.new_xyz.append(torch.zeros(batch, npoint, 3, dtype=torch.float32, device=device))
+            self.ball_idx.append(torch.zeros(batch, npoint, nsample, dtype=torch.int32, device=device))
+            self._temp.append(torch.zeros(batch, max(n, 128), dtype=torch.float32, device=device))
+            n = npoint
+
+    def compute(self, xyz):
+        """Launch the chain for xyz (B,N,3) on the current stream; fills the plan's buffers."""
+        dev = _lib.require_device(xyz)
+        if not xyz.is_contiguous() or xyz.dtype != torch.float32:
+            raise RuntimeError("xyz must be a contiguous float tensor")
+        b, n, _ = xyz.shape
+        assert (b, n) == (self.batch, self.n_points)
+        s = _lib.stream_ptr(dev)
+        cur = xyz
+        with torch.cuda.device(dev):
+            for lvl, (npoint, radius, nsample) in enumerate(self.levels):
+                _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
+                          _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
+                _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
+                          _lib.ptr(self.new_xyz[lvl]), s)
+                _lib.call("sig3d_ball_query", b, n, npoint, ctypes.c_float(radius), nsample,
+                          _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
+                cur, n = self.new_xyz[lvl], npoint
+        return self
+
+    def level(self, i):
+        return self.inds[i], self.new_xyz[i], self.ball_idx[i]
+
+    def copy_from(self, other):
+        for a, b in zip(self.inds + self.new_xyz + self.ball_idx,
+                        other.inds + other.new_xyz + other.ball_idx):
+            a.copy_(b, non_blocking=True)

@@ -1,4 +1,4 @@
-"""hipGraph capture of the training step.
+"""hipGraph capture of the training step (+ geometry prefetch on a forked branch).
 
 One step of the composed hot path is ~2000 kernel launches (12 Q-Former layers x ~40 small
 kernels forward, twice that backward, 4 SA levels, the optimizer).  Issued eagerly from Python
@@ -9,11 +9,22 @@ by the hardware queue instead of the interpreter.  Everything on the path is cap
 construction: the C-ABI kernels launch on the capturing stream, their zero-fills are memset
 nodes, no entry point synchronises or allocates, and the optimizer runs in `capturable` mode.
 
+Geometry prefetch.  FPS / centre gather / ball query depend on xyz only (geometry.py) and FPS is
+a latency-bound chain that keeps a handful of CUs busy for milliseconds.  With
+`prefetch_geometry=True` the graph has TWO branches: the training step of batch i (reading the
+geometry plan computed during the previous replay) and, forked onto a second stream, the
+geometry plan of batch i+1.  The branches join at the end of the graph, where the freshly
+computed plan is handed over.  Every step still performs the full work of one batch (one
+geometry chain + one training pass); only the order is pipelined, like a data loader running one
+batch ahead.  The plan is bit-identical to computing it inline.
+
 Stream discipline: warm-up, capture, replay and any eager steps of the same model must all run
 on ONE non-default stream (`with torch.cuda.stream(work): ...`).  Autograd's AccumulateGrad
 nodes remember the stream they were first used on; if that differs from the capture stream,
 backward forks onto the other stream inside the capture and the allocator's single-stream
 assumption for graph pools breaks (observed on MI355X as corrupted activations / faults).
+The prefetch branch is safe because it allocates nothing: it only launches C-ABI kernels into
+preallocated buffers.
 
 Inputs live in static device buffers that are refreshed (device-to-device copy) before each
 replay; outputs (loss, answer_scores, ...) are read from static buffers after it.
@@ -21,6 +32,7 @@ replay; outputs (loss, answer_scores, ...) are read from static buffers after it
 import torch
 import torch.nn as nn
 
+from .geometry import GeometryPlan
 from .trainer import get_loss
 
 
@@ -40,7 +52,8 @@ class GraphedTrainStep:
     """Captures `zero_grad -> forward -> get_loss -> backward -> clip_grad_value_ -> step`
     (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
 
-    def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3):
+    def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
+                 prefetch_geometry=False, geometry_levels=None):
         stream = torch.cuda.current_stream()
         if stream == torch.cuda.default_stream():
             raise RuntimeError("GraphedTrainStep must be built (and used) inside "
@@ -50,10 +63,26 @@ class GraphedTrainStep:
         self.static_loss = None
         self.static_out = None
         self.graph = torch.cuda.CUDAGraph()
-        params = [p for p in model.parameters() if p.requires_grad]
+        self.prefetch = bool(prefetch_geometry)
+        self._primed = False
+        self._expected = None
+        params =[p for p in model.parameters() if p.requires_grad]
+
+        if self.prefetch:
+            pc = self.static_batch["point_clouds"]
+            b, n = pc.shape[0], pc.shape[1]
+            levels = geometry_levels or model.encoder.LEVELS
+            self.plan_cur = GeometryPlan(b, n, levels, pc.device)
+            self.plan_next = GeometryPlan(b, n, levels, pc.device)
+            self.static_next_xyz = pc[..., :3].contiguous()
+            self.side = torch.cuda.Stream(pc.device)
+            self.plan_cur.compute(self.static_next_xyz)  # geometry of the example batch
 
         def one_step():
-            out = model(dict(self.static_batch))
+            batch = dict(self.static_batch)
+            if self.prefetch:
+                batch["geometry_plan"] = self.plan_cur
+            out = model(batch)
             loss, out = get_loss(out)
             self.static_out = out  # answer_scores, aux_scores, ... of the last replay
             loss.backward()
@@ -68,10 +97,31 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph, stream=stream):
+            if self.prefetch:
+                self.side.wait_stream(stream)                    # fork
+                with torch.cuda.stream(self.side):
+                    self.plan_next.compute(self.static_next_xyz)
             self.static_loss = one_step()
+            if self.prefetch:
+                stream.wait_stream(self.side)                    # join
+                self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
         torch.cuda.synchronize()
 
-    def __call__(self, batch):
+    def prime(self, batch):
+        """Prefetch mode: compute the geometry of the FIRST batch (pipeline prologue)."""
+        if self.prefetch:
+            self.plan_cur.compute(batch["point_clouds"][..., :3].contiguous())
+        self._primed = True
+
+    def __call__(self, batch, next_batch=None):
+        if self.prefetch:
+            if next_batch is None:
+                raise ValueError("prefetch_geometry=True needs the batch of the NEXT step")
+            key = batch["point_clouds"].data_ptr()
+            if not self._primed or self._expected != key:
+                self.prime(batch)  # pipeline prologue, or the caller broke the announced order
+            self._expected = next_batch["point_clouds"].data_ptr()
+            self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         return self.static_loss

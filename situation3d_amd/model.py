@@ -36,15 +36,17 @@ class PointNet2Encoder(nn.Module):
             self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
             self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
 
-    def forward(self, xyz, features, inds=None):
+    LEVELS = [(2048, 0.2, 64), (1024, 0.4, 32), (512, 0.8, 16), (256, 1.2, 16)]
+
+    def forward(self, xyz, features, plan=None):
         """xyz (B,N,3), features (B,C,N) -> token xyz (B,T,3), token features (B,256,T).
-        `inds` optionally carries precomputed FPS indices for the four levels (geometry does not
-        depend on the features, so it can be produced ahead of time on another stream)."""
-        inds = inds or (None, None, None, None)
-        xyz1, f1, i1 = self.sa1(xyz, features, inds[0])
-        xyz2, f2, i2 = self.sa2(xyz1, f1, inds[1])
-        xyz3, f3, i3 = self.sa3(xyz2, f2, inds[2])
-        xyz4, f4, i4 = self.sa4(xyz3, f3, inds[3])
+        `plan` optionally carries the precomputed geometry of the four levels (FPS indices, centre
+        coordinates, ball-query lists: functions of xyz only -- geometry.GeometryPlan)."""
+        g = [plan.level(i) if plan is not None else None for i in range(4)]
+        xyz1, f1, i1 = self.sa1(xyz, features, geometry=g[0])
+        xyz2, f2, i2 = self.sa2(xyz1, f1, geometry=g[1])
+        xyz3, f3, i3 = self.sa3(xyz2, f2, geometry=g[2])
+        xyz4, f4, i4 = self.sa4(xyz3, f3, geometry=g[3])
         if not self.use_fp:
             return xyz4, f4
         f3u = self.fp1(xyz3, xyz4, f3, f4)
@@ -82,7 +84,7 @@ class SIG3DQFormer(nn.Module):
         pc = data_dict["point_clouds"]
         xyz = pc[..., :3].contiguous()
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
-        tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("fps_inds"))
+        tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("geometry_plan"))
         tok_feat = tok_feat.transpose(1, 2).contiguous()            # (B,T,256)
         data_dict["scene_positions"] = tok_xyz
         data_dict["att_feat_pre"] = tok_feat

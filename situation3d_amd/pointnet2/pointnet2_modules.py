@@ -27,6 +27,8 @@ def _sample_centres(xyz, npoint, inds=None):
         return None, inds
     if inds is None:
         inds = pointnet2_utils.furthest_point_sample(xyz, npoint)
+    if xyz.is_cuda and not (torch.is_grad_enabled() and xyz.requires_grad):
+        return pointnet2_utils.gather_xyz(xyz, inds), inds  # one kernel, no transposes
     xyz_flipped = xyz.transpose(1, 2).contiguous()
     new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
     return new_xyz, inds
@@ -121,12 +123,18 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None,
-                inds: torch.Tensor = None):
-        if inds is not None:
+                inds: torch.Tensor = None, geometry=None):
+        """`geometry` (optional, not in the reference signature): a precomputed
+        (inds, new_xyz, ball_idx) triple for this layer from geometry.GeometryPlan."""
+        if geometry is not None:
+            inds, new_xyz, ball_idx = geometry
             assert inds.shape[1] == self.npoint
-        new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
-
-        grouped = self.grouper(xyz, new_xyz, features)
+            grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
+        else:
+            if inds is not None:
+                assert inds.shape[1] == self.npoint
+            new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
+            grouped = self.grouper(xyz, new_xyz, features)
         if self.ret_unique_cnt:
             grouped_features, grouped_xyz, unique_cnt = grouped
         else:

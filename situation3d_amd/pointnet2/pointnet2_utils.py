@@ -53,6 +53,20 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
+def gather_xyz(xyz, idx):
+    """new_xyz (B,M,3) = xyz[b, idx[b,j], :] in one kernel -- what the reference spells as
+    gather_operation(xyz.transpose(1,2).contiguous(), idx).transpose(1,2).contiguous()
+    (pointnet2_modules.py:233-240).  Bit-identical; used when xyz needs no gradient."""
+    dev = _lib.require_device(xyz, idx)
+    b, n, _ = xyz.shape
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("sig3d_gather_xyz", b, n, m, _lib.ptr(xyz.contiguous()), _lib.ptr(idx),
+                  _lib.ptr(out), _lib.stream_ptr(dev))
+    return out
+
+
 class ThreeNN(Function):
     """pointnet2_utils.py:120-146 (returns sqrt of the squared distances, :140-142)"""
 
@@ -175,8 +189,11 @@ class QueryAndGroup(nn.Module):
         if self.ret_unique_cnt:
             assert self.sample_uniformly
 
-    def forward(self, xyz, new_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz, new_xyz, features=None, idx=None):
+        """`idx` (optional, not in the reference signature): a precomputed ball-query result for
+        exactly these (xyz, new_xyz, radius, nsample) -- see geometry.GeometryPlan."""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
 
         if self.sample_uniformly:  # :336-345, host-bound python loop kept for API parity
             unique_cnt = torch.zeros((idx.shape[0], idx.shape[1]))

@@ -168,3 +168,76 @@ def test_composed_model_step_and_entry_smoke():
     """forward(data_dict) contract keys + one optimiser step; then the driver's smoke()."""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_gather_xyz_matches_reference_spelling(hip_ext):
+    from situation3d_amd.pointnet2 import pointnet2_utils as U
+    from util import scene
+    xyz = scene(3, 777, seed=4).to(DEV)
+    idx = torch.randint(0, 777, (3, 100), dtype=torch.int32, device=DEV)
+    ref = hip_ext.gather_points(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    assert torch.equal(U.gather_xyz(xyz, idx), ref)
+
+
+def test_geometry_plan_equals_inline_ops(hip_ext):
+    from situation3d_amd.geometry import GeometryPlan
+    from util import scene
+    xyz = scene(2, 6000, seed=8).to(DEV)
+    levels = [(512, 0.3, 16), (128, 0.6, 8)]
+    plan = GeometryPlan(2, 6000, levels, DEV).compute(xyz)
+    cur = xyz
+    for i, (m, r, ns) in enumerate(levels):
+        inds = hip_ext.furthest_point_sampling(cur, m)
+        new = hip_ext.gather_points(cur.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        idx = hip_ext.ball_query(new, cur, r, ns)
+        assert torch.equal(plan.inds[i], inds) and torch.equal(plan.new_xyz[i], new)
+        assert torch.equal(plan.ball_idx[i], idx)
+        cur = new
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_graphed_step_matches_eager(prefetch):
+    """hipGraph replay (with and without the forked geometry-prefetch branch) reproduces the eager
+    training trajectory: same losses for the same batches."""
+    from situation3d_amd.graph_step import GraphedTrainStep
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.trainer import build_optimizer, train_step
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0)
+
+    def make():
+        torch.manual_seed(3)
+        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, build_optimizer(m, lr=1e-3)
+
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for i in range(3):
+        b, n = 2, 5000
+        xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+        batches.append({
+            "point_clouds": torch.cat([xyz, torch.rand(b, n, 3, generator=g)], -1).to(DEV),
+            "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * b).to(DEV),
+            "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
+                       "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
+            "answer_cat_scores": torch.zeros(b, 16, device=DEV),
+        })
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        m1, o1 = make()
+        # the graphed object runs 3 warm-up steps + 1 capture step on batches[0] first
+        for _ in range(4):
+            train_step(m1, o1, dict(batches[0]))
+        eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(5)]
+        m2, o2 = make()
+        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=prefetch)
+        graph = []
+        for i in range(5):
+            loss = gs(batches[i % 3], batches[(i + 1) % 3])
+            graph.append(float(loss.item()))
+    torch.cuda.synchronize()
+    # float atomics in the scatter-add gradients make runs differ in the last bits only
+    torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
