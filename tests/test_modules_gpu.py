@@ -228,8 +228,8 @@ def test_graphed_step_matches_eager(prefetch):
     work = torch.cuda.Stream()
     with torch.cuda.stream(work):
         m1, o1 = make()
-        # the graphed object runs 3 warm-up steps + 1 capture step on batches[0] first
-        for _ in range(4):
+        # the graphed object runs 3 eager warm-up steps on batches[0] first (capture executes nothing)
+        for _ in range(3):
             train_step(m1, o1, dict(batches[0]))
         eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(5)]
         m2, o2 = make()
