@@ -112,6 +112,48 @@ int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_
                                  int c_off, const float *grad_out, const int *idx,
                                  float *grad_features, void *stream);
 
+/* ---- fused SharedMLP (1x1 conv + BatchNorm(train) + ReLU) + neighbourhood max-pool -------- */
+
+/* One layer of pt_utils.SharedMLP (lib/pointnet2/pytorch_utils.py:11-36: Conv2d 1x1 bias=False,
+ * then BatchNorm2d, then ReLU) as ONE kernel: y (b,cout,e) = w (cout,cin) . a, where
+ * a = x (b,cin,e) when pscale == NULL, else a = relu(x * pscale[ci] + pshift[ci]) -- i.e. the
+ * PREVIOUS layer's BatchNorm+ReLU applied on load to its raw conv output.  stat_sum / stat_sq
+ * (cout doubles each; zeroed here) receive sum_e y and sum_e y^2 per output channel. */
+int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
+                        const float *pscale, const float *pshift, float *y, double *stat_sum,
+                        double *stat_sq, void *stream);
+
+/* Turns the sums into the layer's training-mode BatchNorm affine: scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale (biased var), saves mean / invstd for the backward pass and updates
+ * running_mean / running_var (unbiased) / num_batches_tracked like nn.BatchNorm2d; the three
+ * running_* pointers may be NULL. */
+int sig3d_bn_finalize(int c, double count, float eps, float momentum, const double *stat_sum,
+                      const double *stat_sq, const float *gamma, const float *beta, float *scale,
+                      float *shift, float *save_mean, float *save_invstd, float *running_mean,
+                      float *running_var, long long *num_batches_tracked, void *stream);
+
+/* Last layer's BatchNorm + ReLU fused with F.max_pool2d(x, [1, nsample])
+ * (lib/pointnet2/pointnet2_modules.py:259-262): y (b,c,p,s) raw -> out (b,c,p), arg (b,c,p) =
+ * index of the first maximum along s. */
+int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y, const float *scale,
+                          const float *shift, float *out, int *arg, void *stream);
+
+/* Backward of BatchNorm(train)+ReLU of one layer: y (b,c,e) raw conv output, upstream gradient
+ * either dense dA (b,c,e) or -- for the last layer -- the max-pool gradient given as
+ * dOut (b,c,e/s) + arg (b,c,e/s) (pass dA = NULL).  Produces s1 = sum dZ (= d beta) and
+ * s2 = sum dZ*xhat (= d gamma) as doubles (zeroed here) and dY (b,c,e), the gradient w.r.t. the
+ * raw conv output.  scale/shift/mean/invstd are the outputs of sig3d_bn_finalize. */
+int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, const float *dOut,
+                      const int *arg, const float *y, const float *scale, const float *shift,
+                      const float *mean, const float *invstd, double *s1, double *s2, float *dY,
+                      void *stream);
+
+/* Weight gradient of one layer: dW (cout,cin) = sum_{b,e} dY[b,co,e] * a[b,ci,e], with a = x or
+ * relu(x*pscale + pshift) exactly as in sig3d_mlp_layer_fwd.  dW is zeroed here.  (The input
+ * gradient dA = W^T dY is sig3d_mlp_layer_fwd with x = dY and w = W^T.) */
+int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
+                       const float *pscale, const float *pshift, float *dW, void *stream);
+
 /* ---- situational pose re-encode -------------------------------------------------------- */
 
 /* replaces situation3d/utils/temp.py:42-97 (batch_matrix_function + homogeneous bmm):

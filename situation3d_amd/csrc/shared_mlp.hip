@@ -1,0 +1,517 @@
+// shared_mlp.hip -- fused SharedMLP (1x1 conv + BatchNorm(train) + ReLU stacks) and the
+// neighbourhood max-pool of a PointNet++ set-abstraction layer, for gfx950.
+//
+// Replaces, for the training-mode hot path, what the reference runs as separate torch ops:
+//   pt_utils.SharedMLP = [Conv2d(1x1,bias=False) -> BatchNorm2d -> ReLU(inplace)] x L
+//   (lib/pointnet2/pytorch_utils.py:11-36, 67-120) followed by
+//   F.max_pool2d(new_features, [1, nsample]) (lib/pointnet2/pointnet2_modules.py:259-262).
+// the grouped tensor and every layer output otherwise make
+// ~7 full HBM round trips each (conv write, BN stats read, BN apply read+write, ReLU
+// read+write, next conv read).  Here a layer is ONE kernel:
+//   prologue : the previous layer's BatchNorm + ReLU are applied to its RAW conv output while
+//              it is loaded as the MFMA B operand (scale/shift per input channel);
+//   GEMM     : Y[co][e] = sum_ci W[co][ci] * a[ci][e] on exact-f32 MFMA (32x32x2), W staged in
+//              LDS with an odd row stride (conflict-free A-operand reads);
+//   epilogue : raw Y is written once and the per-channel sum / sum-of-squares needed for THIS
+//              layer's batch statistics are accumulated (lane-local over the workgroup's tiles,
+//              one DPP/LDS reduction, f64 atomics per workgroup).
+// Each activation is therefore written once and read once; BatchNorm never gets its own pass.
+// Batch statistics are finished in f64 (no E[x^2]-E[x]^2 cancellation), running statistics are
+// updated exactly like nn.BatchNorm2d (momentum, unbiased running_var, num_batches_tracked).
+//
+// Layout: activations (B, C, E) with E = npoint*nsample contiguous -- the reference's
+// (B, C, npoint, nsample).  MFMA map: rows (M) = output channels, cols (N) = 32 positions (one
+// per lane&31), K = input channels; C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#include "sig3d_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ML_WAVES = 4;  // waves per workgroup, one 32-position tile each per sweep
+constexpr int ML_KC = 16;    // K-steps (of 2 input channels) per software-pipeline chunk
+
+__device__ __forceinline__ int mrow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float row32_sum(float v) {
+  // sum over the 32 lanes that share (lane >> 5): two DPP rows of 16, then the neighbour row
+  v = row_allreduce_sum_f32(v);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+
+__host__ __device__ inline int ml_kpad(int cin) { return (cin + 2 * ML_KC - 1) / (2 * ML_KC) * (2 * ML_KC); }
+
+// ---- forward layer -------------------------------------------------------------------------
+// grid (cout / (32*MT), position chunks, B); dynamic LDS: W tile [32*MT][ldw] + pscale[kpad] +
+// pshift[kpad] + cross-wave stat scratch.  The B operand (one activation value per lane per
+// K-step) is software-pipelined in chunks of ML_KC steps: the loads of chunk c+1 are in flight
+// while the MFMAs of chunk c issue.
+template <int MT, bool PROLOGUE>
+__global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fwd_kernel(
+    int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
+    const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
+    float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CT = 32 * MT;
+  const int kpad = ml_kpad(cin);
+  const int ldw = kpad | 1;  // odd stride: A-operand reads (one row per lane) hit distinct banks
+  float *s_w = smem;                // [CT][ldw]
+  float *s_ps = s_w + CT * ldw;     // [kpad]
+  float *s_pb = s_ps + kpad;        // [kpad]
+  float *s_red = s_pb + kpad;       // [ML_WAVES][2][CT]
+
+  const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int co0 = blockIdx.x * CT;
+  const int bi = blockIdx.z;
+
+  for (int i = threadIdx.x; i < CT * kpad; i += ML_WAVES * 64) {
+    const int r = i / kpad, c = i % kpad;
+    s_w[r * ldw + c] = (c < cin && co0 + r < cout) ? w[(size_t)(co0 + r) * cin + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < kpad; i += ML_WAVES * 64) {
+    s_ps[i] = (PROLOGUE && i < cin) ? pscale[i] : 1.f;
+    s_pb[i] = (PROLOGUE && i < cin) ? pshift[i] : 0.f;
+  }
+  __syncthreads();
+
+  const float *xb = x + (size_t)bi * cin * E;
+  float *yb = y + ((size_t)bi * cout + co0) * E;
+  float s1[MT][16], s2[MT][16];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+
+  const int nchunks = kpad / (2 * ML_KC);
+  const long chunk = (long)ML_WAVES * 32 * tiles_per_wave;
+  const long e_begin = (long)blockIdx.y * chunk;
+  for (int t = 0; t < tiles_per_wave; ++t) {
+    const long e0 = e_begin + ((long)t * ML_WAVES + wave) * 32;
+    if (e0 >= E) break;
+    const long e = e0 + l31;
+    const bool ok = e < E;
+    const float *xe = xb + (ok ? e : E - 1);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+
+    auto load_chunk = [&](float (&buf)[ML_KC], int c) {
+#pragma unroll
+      for (int i = 0; i < ML_KC; ++i) {
+        const int k = (c * ML_KC + i) * 2 + half;
+        buf[i] = xe[(size_t)min(k, cin - 1) * E];
+      }
+    };
+    auto mma_chunk = [&](const float (&buf)[ML_KC], int c) {
+#pragma unroll
+      for (int i = 0; i < ML_KC; ++i) {
+        const int k = (c * ML_KC + i) * 2 + half;
+        float b = buf[i];
+        if (PROLOGUE) b = fmaxf(0.f, b * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
+        b = (k < cin) ? b : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w[(mt * 32 + l31) * ldw + k], b, acc[mt], 0, 0, 0);
+      }
+    };
+    float bufa[ML_KC], bufb[ML_KC];
+    load_chunk(bufa, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+      if (c + 1 < nchunks) load_chunk(bufb, c + 1);
+      mma_chunk(bufa, c);
+      if (c + 1 < nchunks) {
+        if (c + 2 < nchunks) load_chunk(bufa, c + 2);
+        mma_chunk(bufb, c + 1);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + mrow(r, half);
+        const float v = acc[mt][r];
+        if (ok && co0 + co < cout) {
+          yb[(size_t)co * E + e] = v;
+          s1[mt][r] += v;
+          s2[mt][r] += v * v;
+        }
+      }
+  }
+
+  // per-channel partial sums of this workgroup -> f64 atomics
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float a = row32_sum(s1[mt][r]);
+      const float q = row32_sum(s2[mt][r]);
+      if (l31 == 0) {
+        const int co = mt * 32 + mrow(r, half);
+        s_red[(wave * 2 + 0) * CT + co] = a;
+        s_red[(wave * 2 + 1) * CT + co] = q;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x < 2 * CT) {
+    const int which = threadIdx.x / CT, co = threadIdx.x % CT;
+    if (co0 + co < cout) {
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < ML_WAVES; ++wv) tot += (double)s_red[(wv * 2 + which) * CT + co];
+      unsafeAtomicAdd((which ? stat_sq : stat_sum) + co0 + co, tot);
+    }
+  }
+}
+
+// ---- BatchNorm statistics -> affine (scale, shift), saved stats, running stats ---------------
+// nn.BatchNorm2d training semantics: biased variance for normalisation, unbiased for
+// running_var, running = (1-momentum)*running + momentum*batch, num_batches_tracked += 1.
+__global__ void bn_finalize_kernel(int c, double count, float eps, float momentum,
+                                   const double *__restrict__ stat_sum,
+                                   const double *__restrict__ stat_sq,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ scale, float *__restrict__ shift,
+                                   float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   long long *__restrict__ num_batches_tracked) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (i >= c) return;
+  const double mean = stat_sum[i] / count;
+  double var = stat_sq[i] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[i] : 1.f, bt = beta ? beta[i] : 0.f;
+  scale[i] = (float)((double)g * invstd);
+  shift[i] = (float)((double)bt - mean * (double)g * invstd);
+  save_mean[i] = (float)mean;
+  save_invstd[i] = (float)invstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[i] = (float)((1.0 - momentum) * (double)running_mean[i] + momentum * mean);
+    running_var[i] = (float)((1.0 - momentum) * (double)running_var[i] + momentum * unbiased);
+  }
+}
+
+// ---- last layer: BN + ReLU + max over the nsample axis (+ arg-max for the backward pass) -----
+// y (B,C,P,S) raw -> out (B,C,P), arg (B,C,P) int32 (first maximum, like max_pool2d)
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long groups, int c, int P, int S,
+                                                              const float *__restrict__ y,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              float *__restrict__ out,
+                                                              int *__restrict__ arg) {
+  // 16 lanes (one DPP row) per group of S samples: coalesced 64-byte segments, row reduction.
+  // groups are ordered (b, c, p): channel = (g / P) % c.
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  const long gc = g < groups ? g : groups - 1;
+  const int ch = (int)((gc / P) % c);
+  const float sc = scale[ch], sh = shift[ch];
+  const float *row = y + gc * S;
+  float best = -1.f;  // relu output is >= 0, so any sample beats -1
+  int bi = 0;
+  for (int s = sub; s < S; s += 16) {
+    const float v = fmaxf(0.f, row[s] * sc + sh);
+    if (v > best) { best = v; bi = s; }  // ascending s + strict '>' : first maximum of this lane
+  }
+  const int bv = __builtin_bit_cast(int, best);  // -1 or >= 0: ordered as signed ints
+  const int mv = row_allreduce_max_i32(bv);
+  const unsigned mi = row_allreduce_min_u32(bv == mv ? (unsigned)bi : 0xFFFFFFFFu);
+  if (sub == 0 && g < groups) {
+    out[g] = __builtin_bit_cast(float, mv);
+    arg[g] = (int)mi;
+  }
+}
+
+
+// ---- backward: BatchNorm(train) + ReLU ------------------------------------------------------
+// With z = y*scale + shift, a = relu(z), xhat = (y - mean)*invstd and upstream gradient dA:
+//   dZ = dA * [z > 0];  S1 = sum dZ (= d beta);  S2 = sum dZ*xhat (= d gamma)
+//   dY = gamma*invstd * (dZ - S1/n - xhat*S2/n)
+// TOP = true: dA is not a dense tensor but the max-pool gradient, i.e. dOut[b,c,j] routed to the
+// arg-max sample of each group (and only where the pooled output is > 0).
+template <bool TOP>
+__device__ __forceinline__ float upstream_grad(const float *__restrict__ dA, const float *__restrict__ dOut,
+                                               const int *__restrict__ arg, size_t row, long e, int S,
+                                               long groups_per_row) {
+  if (!TOP) return dA[row + e];
+  const long j = e / S;
+  const int s = (int)(e - j * S);
+  const size_t g = (row / ((size_t)groups_per_row * S)) * groups_per_row + j;
+  return (arg[g] == s) ? dOut[g] : 0.f;
+}
+
+constexpr int BNB_THREADS = 256;
+constexpr int BNB_CHUNK = 8192;  // elements of one (b, c) row per workgroup
+
+template <bool TOP>
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_kernel(
+    int c, long E, int S, const float *__restrict__ dA, const float *__restrict__ dOut,
+    const int *__restrict__ arg, const float *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+    double *__restrict__ s1, double *__restrict__ s2) {
+  __shared__ float red[2][BNB_THREADS / 64];
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t row = ((size_t)bi * c + ch) * E;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  const long e0 = (long)blockIdx.x * BNB_CHUNK, e1 = min(E, e0 + BNB_CHUNK);
+  float a1 = 0.f, a2 = 0.f;
+  for (long e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+    const float yv = y[row + e];
+    const float g = upstream_grad<TOP>(dA, dOut, arg, row, e, S, E / S);
+    const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
+    a1 += dz;
+    a2 += dz * ((yv - mu) * is);
+  }
+  a1 = wave_allreduce_sum_f32(a1);
+  a2 = wave_allreduce_sum_f32(a2);
+  if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < BNB_THREADS / 64; ++w) t += (double)red[threadIdx.x][w];
+    unsafeAtomicAdd((threadIdx.x ? s2 : s1) + ch, t);
+  }
+}
+
+template <bool TOP>
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
+    int c, long E, int S, double count, const float *__restrict__ dA, const float *__restrict__ dOut,
+    const int *__restrict__ arg, const float *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const double *__restrict__ s1, const double *__restrict__ s2, float *__restrict__ dY) {
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t row = ((size_t)bi * c + ch) * E;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
+  const long e0 = (long)blockIdx.x * BNB_CHUNK, e1 = min(E, e0 + BNB_CHUNK);
+  for (long e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+    const float yv = y[row + e];
+    const float g = upstream_grad<TOP>(dA, dOut, arg, row, e, S, E / S);
+    const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
+    dY[row + e] = sc * (dz - m1 - (yv - mu) * is * m2);  // sc == gamma * invstd
+  }
+}
+
+// ---- backward: weight gradient dW[co][ci] = sum_{b,e} dY[b,co,e] * a[b,ci,e] ----------------
+// a = x (first layer) or relu(x*pscale + pshift) (x = previous layer's raw conv output).
+// Reduction over ALL positions: each workgroup owns a chunk of positions, stages 32-position
+// tiles of dY and a in LDS (coalesced row loads, stride-33 rows), its four waves split the
+// (cout/32) x (cin/32) output tiles and accumulate with MFMA over the chunk; one f32 atomic per
+// output element per workgroup at the end.
+constexpr int DW_TE = 32;
+constexpr int DW_MAX_TILES = 12;  // output tiles per wave (register budget)
+
+template <bool PROLOGUE>
+__global__ __launch_bounds__(ML_WAVES * 64, 1) void mlp_dw_kernel(
+    int cin, int cout, long E, int tiles_per_block, const float *__restrict__ dY,
+    const float *__restrict__ x, const float *__restrict__ pscale, const float *__restrict__ pshift,
+    float *__restrict__ dW) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cinp = (cin + 31) & ~31;
+  float *t_dy = smem;                       // [cout][33]
+  float *t_a = t_dy + (size_t)cout * 33;    // [cinp][33]
+  const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int bi = blockIdx.y;
+  const int mtiles = cout / 32, ntiles = cinp / 32, total = mtiles * ntiles;
+  // wave w owns output tiles w, w+4, ...
+  f32x16 acc[DW_MAX_TILES];
+#pragma unroll
+  for (int i = 0; i < DW_MAX_TILES; ++i) acc[i] = (f32x16){0};
+
+  const float *dyb = dY + (size_t)bi * cout * E;
+  const float *xb = x + (size_t)bi * cin * E;
+  const long t_begin = (long)blockIdx.x * tiles_per_block;
+  const long n_tiles = (E + DW_TE - 1) / DW_TE;
+  for (long t = t_begin; t < min(n_tiles, t_begin + tiles_per_block); ++t) {
+    const long e0 = t * DW_TE;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cout * DW_TE; i += ML_WAVES * 64) {
+      const int r = i >> 5, cidx = i & 31;
+      const long e = e0 + cidx;
+      t_dy[r * 33 + cidx] = e < E ? dyb[(size_t)r * E + e] : 0.f;
+    }
+    for (int i = threadIdx.x; i < cinp * DW_TE; i += ML_WAVES * 64) {
+      const int r = i >> 5, cidx = i & 31;
+      const long e = e0 + cidx;
+      float v = 0.f;
+      if (r < cin && e < E) {
+        v = xb[(size_t)r * E + e];
+        if (PROLOGUE) v = fmaxf(0.f, v * pscale[r] + pshift[r]);
+      }
+      t_a[r * 33 + cidx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DW_MAX_TILES; ++i) {
+      const int tile = wave + i * ML_WAVES;
+      if (tile < total) {
+        const int mt = tile / ntiles, nt = tile % ntiles;
+        const float *pa = t_dy + (mt * 32 + l31) * 33 + half;
+        const float *pb = t_a + (nt * 32 + l31) * 33 + half;
+#pragma unroll
+        for (int s = 0; s < DW_TE / 2; ++s)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], pb[2 * s], acc[i], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DW_MAX_TILES; ++i) {
+    const int tile = wave + i * ML_WAVES;
+    if (tile < total) {
+      const int mt = tile / ntiles, nt = tile % ntiles;
+      const int ci = nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + mrow(r, half);
+        if (ci < cin) unsafeAtomicAdd(dW + (size_t)co * cin + ci, acc[i][r]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// ---- C ABI ----------------------------------------------------------------------------------
+
+template <int MT, bool PROLOGUE>
+static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
+                          const float *pscale, const float *pshift, float *y, double *stat_sum,
+                          double *stat_sq, hipStream_t stream) {
+  constexpr int CT = 32 * MT;
+  const int kpad = ml_kpad(cin), ldw = kpad | 1;
+  const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT);
+  static bool attr_done = false;  // per template instance
+  if (!attr_done) {
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<MT, PROLOGUE>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  // enough position chunks to cover the chip a few times over
+  const long wave_tiles = (e + 31) / 32;
+  const int cblocks = sig3d_ceil_div(cout, CT);
+  int tpw = 8;
+  while (tpw > 1 && (long)b * cblocks * ((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)) < 1024) tpw >>= 1;
+  dim3 grid(cblocks, (unsigned)((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)), b);
+  hipLaunchKernelGGL((mlp_layer_fwd_kernel<MT, PROLOGUE>), grid, dim3(ML_WAVES * 64), lds, stream, cin,
+                     cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
+  SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
+                                   const float *pscale, const float *pshift, float *y,
+                                   double *stat_sum, double *stat_sq, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
+  SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
+  SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * cout, stream));
+  SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
+  if (b == 0 || e == 0) return 0;
+  const int kpad = ml_kpad(cin), ldw = kpad | 1;
+  SIG3D_REQUIRE(sizeof(float) * ((size_t)64 * ldw + 2 * kpad + ML_WAVES * 2 * 64) <= 160 * 1024,
+                "input channel count too large for the LDS weight tile");
+  // 128-channel tiles (x re-read from L2 half as often) when they fit LDS next to a second workgroup
+  const bool wide = cout >= 128 && sizeof(float) * ((size_t)128 * ldw + 2 * kpad + ML_WAVES * 2 * 128) <= 150 * 1024;
+  if (wide) {
+    return pscale ? launch_mlp_fwd<4, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+                  : launch_mlp_fwd<4, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  }
+  return pscale ? launch_mlp_fwd<2, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+                : launch_mlp_fwd<2, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+}
+
+extern "C" int sig3d_bn_finalize(int c, double count, float eps, float momentum,
+                                 const double *stat_sum, const double *stat_sq, const float *gamma,
+                                 const float *beta, float *scale, float *shift, float *save_mean,
+                                 float *save_invstd, float *running_mean, float *running_var,
+                                 long long *num_batches_tracked, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(c >= 1 && count >= 1.0, "bad size");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(sig3d_ceil_div(c, 256)), dim3(256), 0, stream, c, count,
+                     eps, momentum, stat_sum, stat_sq, gamma, beta, scale, shift, save_mean,
+                     save_invstd, running_mean, running_var, num_batches_tracked);
+  SIG3D_LAUNCH_CHECK("bn_finalize_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y, const float *scale,
+                                     const float *shift, float *out, int *arg, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && p >= 0 && s >= 1, "bad size");
+  const long groups = (long)b * c * p;
+  if (groups == 0) return 0;
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0,
+                     stream, groups, c, p, s, y, scale, shift, out, arg);
+  SIG3D_LAUNCH_CHECK("bn_relu_maxpool_kernel");
+  return 0;
+}
+
+
+// ---- backward entry points -----------------------------------------------------------------
+
+extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, const float *dOut,
+                                 const int *arg, const float *y, const float *scale,
+                                 const float *shift, const float *mean, const float *invstd,
+                                 double *s1, double *s2, float *dY, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && s >= 1, "bad size");
+  SIG3D_REQUIRE((dA != nullptr) != (dOut != nullptr && arg != nullptr),
+                "pass either a dense dA or the (dOut, arg) pair of the max-pool");
+  SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * c, stream));
+  SIG3D_HIP_TRY(hipMemsetAsync(s2, 0, sizeof(double) * c, stream));
+  if (b == 0 || e == 0) return 0;
+  const double count = (double)b * (double)e;
+  dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
+  if (dA) {
+    hipLaunchKernelGGL((bn_relu_bwd_stats_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
+                       dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2);
+    hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
+                       count, dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2, dY);
+  } else {
+    hipLaunchKernelGGL((bn_relu_bwd_stats_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
+                       dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2);
+    hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
+                       count, dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2, dY);
+  }
+  SIG3D_LAUNCH_CHECK("bn_relu_bwd kernels");
+  return 0;
+}
+
+extern "C" int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                  const float *pscale, const float *pshift, float *dW,
+                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
+  SIG3D_REQUIRE(cout % 32 == 0, "output channel count must be a multiple of 32");
+  SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
+  SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
+  if (b == 0 || e == 0) return 0;
+  const int cinp = (cin + 31) & ~31;
+  const int total = (cout / 32) * (cinp / 32);
+  SIG3D_REQUIRE(total <= DW_MAX_TILES * ML_WAVES, "layer too wide for the weight-gradient kernel");
+  const size_t lds = sizeof(float) * 33 * ((size_t)cout + cinp);
+  const long n_tiles = (e + DW_TE - 1) / DW_TE;
+  long blocks = 512 / (b > 0 ? b : 1);
+  if (blocks < 1) blocks = 1;
+  if (blocks > n_tiles) blocks = n_tiles;
+  const int tpb = (int)((n_tiles + blocks - 1) / blocks);
+  dim3 grid((unsigned)((n_tiles + tpb - 1) / tpb), b);
+  if (pscale) {
+    static bool a1 = false;
+    if (!a1) { SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
+    hipLaunchKernelGGL((mlp_dw_kernel<true>), grid, dim3(ML_WAVES * 64), lds, stream, cin, cout, e, tpb,
+                       dY, x, pscale, pshift, dW);
+  } else {
+    static bool a2 = false;
+    if (!a2) { SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a2 = true; }
+    hipLaunchKernelGGL((mlp_dw_kernel<false>), grid, dim3(ML_WAVES * 64), lds, stream, cin, cout, e, tpb,
+                       dY, x, pscale, pshift, dW);
+  }
+  SIG3D_LAUNCH_CHECK("mlp_dw_kernel");
+  return 0;
+}

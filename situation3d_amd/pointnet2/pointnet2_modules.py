@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused_mlp
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -139,6 +140,13 @@ class PointnetSAModuleVotes(nn.Module):
             grouped_features, grouped_xyz, unique_cnt = grouped
         else:
             grouped_features, grouped_xyz = grouped
+
+        if self.pooling == 'max' and fused_mlp.can_fuse(self.mlp_module, grouped_features):
+            # training-mode Conv1x1+BN+ReLU stack and the max over nsample as fused MFMA kernels
+            new_features = fused_mlp.fused_mlp_max(self.mlp_module, grouped_features)
+            if self.ret_unique_cnt:
+                return new_xyz, new_features, inds, unique_cnt
+            return new_xyz, new_features, inds
 
         new_features = self.mlp_module(grouped_features)  # (B, mlp[-1], npoint, nsample)
         if self.pooling == 'max':
