@@ -298,79 +298,123 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
 
 // ---- backward: weight gradient dW[co][ci] = sum_{b,e} dY[b,co,e] * a[b,ci,e] ----------------
 // a = x (first layer) or relu(x*pscale + pshift) (x = previous layer's raw conv output).
-// Reduction over ALL positions: each workgroup owns a chunk of positions, stages 32-position
-// tiles of dY and a in LDS (coalesced row loads, stride-33 rows), its four waves split the
-// (cout/32) x (cin/32) output tiles and accumulate with MFMA over the chunk; one f32 atomic per
-// output element per workgroup at the end.
-constexpr int DW_TE = 32;
-constexpr int DW_MAX_TILES = 12;  // output tiles per wave (register budget)
+// A reduction over ALL positions with a small (cout x cin) result: no LDS, no barriers.  One
+// wave owns a 2x2 block of 32x32 output tiles and a chunk of positions; both MFMA operands are
+// rows of global tensors, so a lane reads a CONTIGUOUS 64-byte run of its own row per 32-position
+// step (the K index is permuted: step s pairs position s of the first 16 with position 16+s of
+// the last 16, identically for both operands).  Fragments of the next step are loaded while the
+// MFMAs of the current one issue.  Partial tiles are combined across the workgroup's waves with
+// LDS atomics and flushed with one global f32 atomic per element per workgroup.
+constexpr int DW_WAVES = 4;
 
-template <bool PROLOGUE>
-__global__ __launch_bounds__(ML_WAVES * 64, 1) void mlp_dw_kernel(
-    int cin, int cout, long E, int tiles_per_block, const float *__restrict__ dY,
+template <bool PROLOGUE, bool VEC>
+__global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
+    int cin, int cout, long E, int steps_per_wave, int nblk_n, const float *__restrict__ dY,
     const float *__restrict__ x, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ dW) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int cinp = (cin + 31) & ~31;
-  float *t_dy = smem;                       // [cout][33]
-  float *t_a = t_dy + (size_t)cout * 33;    // [cinp][33]
+  __shared__ float s_tile[4][32][33];
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int bi = blockIdx.y;
-  const int mtiles = cout / 32, ntiles = cinp / 32, total = mtiles * ntiles;
-  // wave w owns output tiles w, w+4, ...
-  f32x16 acc[DW_MAX_TILES];
-#pragma unroll
-  for (int i = 0; i < DW_MAX_TILES; ++i) acc[i] = (f32x16){0};
+  const int bi = blockIdx.z;
+  const int co0 = (blockIdx.y / nblk_n) * 64, ci0 = (blockIdx.y % nblk_n) * 64;
 
-  const float *dyb = dY + (size_t)bi * cout * E;
-  const float *xb = x + (size_t)bi * cin * E;
-  const long t_begin = (long)blockIdx.x * tiles_per_block;
-  const long n_tiles = (E + DW_TE - 1) / DW_TE;
-  for (long t = t_begin; t < min(n_tiles, t_begin + tiles_per_block); ++t) {
-    const long e0 = t * DW_TE;
-    __syncthreads();
-    for (int i = threadIdx.x; i < cout * DW_TE; i += ML_WAVES * 64) {
-      const int r = i >> 5, cidx = i & 31;
-      const long e = e0 + cidx;
-      t_dy[r * 33 + cidx] = e < E ? dyb[(size_t)r * E + e] : 0.f;
-    }
-    for (int i = threadIdx.x; i < cinp * DW_TE; i += ML_WAVES * 64) {
-      const int r = i >> 5, cidx = i & 31;
-      const long e = e0 + cidx;
-      float v = 0.f;
-      if (r < cin && e < E) {
-        v = xb[(size_t)r * E + e];
-        if (PROLOGUE) v = fmaxf(0.f, v * pscale[r] + pshift[r]);
+  for (int i = threadIdx.x; i < 4 * 32 * 33; i += DW_WAVES * 64) (&s_tile[0][0][0])[i] = 0.f;
+  __syncthreads();
+
+  // per-lane row pointers / prologue constants of the two A rows (co) and two B rows (ci)
+  const float *arow[2];
+  const float *brow[2];
+  float bsc[2], bsh[2];
+  bool bok[2], aok[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int co = co0 + 32 * t + l31, ci = ci0 + 32 * t + l31;
+    aok[t] = co < cout;
+    bok[t] = ci < cin;
+    arow[t] = dY + ((size_t)bi * cout + (aok[t] ? co : 0)) * E;
+    brow[t] = x + ((size_t)bi * cin + (bok[t] ? ci : 0)) * E;
+    bsc[t] = (PROLOGUE && bok[t]) ? pscale[ci] : 1.f;
+    bsh[t] = (PROLOGUE && bok[t]) ? pshift[ci] : 0.f;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+
+  const long n_steps = (E + 31) / 32;
+  const long st_begin = ((long)blockIdx.x * DW_WAVES + wave) * steps_per_wave;
+  const long st_end = min(n_steps, st_begin + steps_per_wave);
+
+  auto load_frag = [&](float (&f)[16], const float *row, long e0, bool ok) {
+    const long eb = e0 + 16 * half;
+    if (VEC) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(row + eb);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = p4[q];
+        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
       }
-      t_a[r * 33 + cidx] = v;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) f[q] = (eb + q < E) ? row[eb + q] : 0.f;
     }
-    __syncthreads();
+    (void)ok;
+  };
+
+  float fa[2][2][16], fb[2][2][16];  // [buffer][tile][k]
+  if (st_begin < st_end) {
 #pragma unroll
-    for (int i = 0; i < DW_MAX_TILES; ++i) {
-      const int tile = wave + i * ML_WAVES;
-      if (tile < total) {
-        const int mt = tile / ntiles, nt = tile % ntiles;
-        const float *pa = t_dy + (mt * 32 + l31) * 33 + half;
-        const float *pb = t_a + (nt * 32 + l31) * 33 + half;
+    for (int t = 0; t < 2; ++t) {
+      load_frag(fa[0][t], arow[t], st_begin * 32, aok[t]);
+      load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
+    }
+  }
+  for (long st = st_begin; st < st_end; st += 2) {
 #pragma unroll
-        for (int s = 0; s < DW_TE / 2; ++s)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * s], pb[2 * s], acc[i], 0, 0, 0);
+    for (int ph = 0; ph < 2; ++ph) {
+      const long cur = st + ph;
+      if (cur < st_end) {
+        if (cur + 1 < st_end) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            load_frag(fa[ph ^ 1][t], arow[t], (cur + 1) * 32, aok[t]);
+            load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
+          }
+        }
+        const bool tail = !VEC && (cur * 32 + 32 > E);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          float av[2], bv[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            av[t] = aok[t] ? fa[ph][t][k] : 0.f;
+            float v = fb[ph][t][k];
+            if (PROLOGUE) v = fmaxf(0.f, v * bsc[t] + bsh[t]);
+            if (tail && (cur * 32 + 16 * half + k >= E)) v = 0.f;
+            bv[t] = bok[t] ? v : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
+  // combine the workgroup's waves in LDS, then one global atomic per element
 #pragma unroll
-  for (int i = 0; i < DW_MAX_TILES; ++i) {
-    const int tile = wave + i * ML_WAVES;
-    if (tile < total) {
-      const int mt = tile / ntiles, nt = tile % ntiles;
-      const int ci = nt * 32 + l31;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = mt * 32 + mrow(r, half);
-        if (ci < cin) unsafeAtomicAdd(dW + (size_t)co * cin + ci, acc[i][r]);
-      }
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) atomicAdd(&s_tile[i * 2 + j][mrow(r, half)][l31], acc[i][j][r]);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 4 * 32 * 32; idx += DW_WAVES * 64) {
+    const int tile = idx >> 10, r = (idx >> 5) & 31, c = idx & 31;
+    const int co = co0 + 32 * (tile >> 1) + r, ci = ci0 + 32 * (tile & 1) + c;
+    if (co < cout && ci < cin) unsafeAtomicAdd(dW + (size_t)co * cin + ci, s_tile[tile][r][c]);
   }
 }
 
@@ -482,36 +526,35 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
   return 0;
 }
 
+template <bool PROLOGUE, bool VEC>
+static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
+                         const float *pscale, const float *pshift, float *dW, hipStream_t stream) {
+  const int nblk_m = sig3d_ceil_div(cout, 64), nblk_n = sig3d_ceil_div(cin, 64);
+  const long n_steps = (e + 31) / 32;
+  // ~4096 waves in flight, at least 8 steps per wave
+  long waves_per_block_row = 4096 / ((long)b * nblk_m * nblk_n);
+  if (waves_per_block_row < DW_WAVES) waves_per_block_row = DW_WAVES;
+  long spw = (n_steps + waves_per_block_row - 1) / waves_per_block_row;
+  if (spw < 8) spw = 8;
+  const long wgs = (n_steps + spw * DW_WAVES - 1) / (spw * DW_WAVES);
+  dim3 grid((unsigned)wgs, nblk_m * nblk_n, b);
+  hipLaunchKernelGGL((mlp_dw_kernel<PROLOGUE, VEC>), grid, dim3(DW_WAVES * 64), 0, stream, cin, cout, e,
+                     (int)spw, nblk_n, dY, x, pscale, pshift, dW);
+  SIG3D_LAUNCH_CHECK("mlp_dw_kernel");
+  return 0;
+}
+
 extern "C" int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
                                   const float *pscale, const float *pshift, float *dW,
                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
-  SIG3D_REQUIRE(cout % 32 == 0, "output channel count must be a multiple of 32");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
   SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
   if (b == 0 || e == 0) return 0;
-  const int cinp = (cin + 31) & ~31;
-  const int total = (cout / 32) * (cinp / 32);
-  SIG3D_REQUIRE(total <= DW_MAX_TILES * ML_WAVES, "layer too wide for the weight-gradient kernel");
-  const size_t lds = sizeof(float) * 33 * ((size_t)cout + cinp);
-  const long n_tiles = (e + DW_TE - 1) / DW_TE;
-  long blocks = 512 / (b > 0 ? b : 1);
-  if (blocks < 1) blocks = 1;
-  if (blocks > n_tiles) blocks = n_tiles;
-  const int tpb = (int)((n_tiles + blocks - 1) / blocks);
-  dim3 grid((unsigned)((n_tiles + tpb - 1) / tpb), b);
-  if (pscale) {
-    static bool a1 = false;
-    if (!a1) { SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a1 = true; }
-    hipLaunchKernelGGL((mlp_dw_kernel<true>), grid, dim3(ML_WAVES * 64), lds, stream, cin, cout, e, tpb,
-                       dY, x, pscale, pshift, dW);
-  } else {
-    static bool a2 = false;
-    if (!a2) { SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); a2 = true; }
-    hipLaunchKernelGGL((mlp_dw_kernel<false>), grid, dim3(ML_WAVES * 64), lds, stream, cin, cout, e, tpb,
-                       dY, x, pscale, pshift, dW);
-  }
-  SIG3D_LAUNCH_CHECK("mlp_dw_kernel");
-  return 0;
+  const bool vec = (e % 32 == 0);  // every 16-position run is in range and 16-byte aligned
+  if (pscale) return vec ? launch_mlp_dw<true, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
+                         : launch_mlp_dw<true, false>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
+  return vec ? launch_mlp_dw<false, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
+             : launch_mlp_dw<false, false>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
 }
