@@ -43,19 +43,25 @@ __device__ __forceinline__ float row32_sum(float v) {
 __host__ __device__ inline int ml_kpad(int cin) { return (cin + 2 * ML_KC - 1) / (2 * ML_KC) * (2 * ML_KC); }
 
 // ---- forward layer -------------------------------------------------------------------------
-// grid (cout / (32*MT), position chunks, B); dynamic LDS: W tile [32*MT][ldw] + pscale[kpad] +
-// pshift[kpad] + cross-wave stat scratch.  The B operand (one activation value per lane per
-// K-step) is software-pipelined in chunks of ML_KC steps: the loads of chunk c+1 are in flight
+// grid (cout / (32*NT), position chunks, B); dynamic LDS: W tile [32*NT][ldw] + pscale[kpad] +
+// pshift[kpad] + cross-wave stat scratch.
+// MFMA orientation: D[i = position][j = channel] = sum_k a[k][position] * W[channel][k]
+// (A operand = activations, B operand = weights).  With channels on LANES, the per-channel batch
+// statistics are plain in-lane sums over the 16 accumulator registers (2 registers per 32-channel
+// tile, instead of a 64-register lane-local image), and four consecutive accumulator registers
+// are four consecutive positions of one channel row -> 16-byte stores.
+// The A operand (one activation value per lane per K-step, a coalesced 128-byte row segment per
+// half-wave) is software-pipelined in chunks of ML_KC steps: the loads of chunk c+1 are in flight
 // while the MFMAs of chunk c issue.
-template <int MT, bool PROLOGUE>
-__global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fwd_kernel(
+template <int NT, bool PROLOGUE, bool VEC>
+__global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int CT = 32 * MT;
+  constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin);
-  const int ldw = kpad | 1;  // odd stride: A-operand reads (one row per lane) hit distinct banks
+  const int ldw = kpad | 1;  // odd stride: one weight row per lane -> distinct banks
   float *s_w = smem;                // [CT][ldw]
   float *s_ps = s_w + CT * ldw;     // [kpad]
   float *s_pb = s_ps + kpad;        // [kpad]
@@ -77,12 +83,10 @@ __global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fw
   __syncthreads();
 
   const float *xb = x + (size_t)bi * cin * E;
-  float *yb = y + ((size_t)bi * cout + co0) * E;
-  float s1[MT][16], s2[MT][16];
+  float *yb = y + (size_t)bi * cout * E;
+  float s1[NT], s2[NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 
   const int nchunks = kpad / (2 * ML_KC);
   const long chunk = (long)ML_WAVES * 32 * tiles_per_wave;
@@ -91,11 +95,10 @@ __global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fw
     const long e0 = e_begin + ((long)t * ML_WAVES + wave) * 32;
     if (e0 >= E) break;
     const long e = e0 + l31;
-    const bool ok = e < E;
-    const float *xe = xb + (ok ? e : E - 1);
-    f32x16 acc[MT];
+    const float *xe = xb + (e < E ? e : E - 1);
+    f32x16 acc[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
 
     auto load_chunk = [&](float (&buf)[ML_KC], int c) {
 #pragma unroll
@@ -108,12 +111,12 @@ __global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fw
 #pragma unroll
       for (int i = 0; i < ML_KC; ++i) {
         const int k = (c * ML_KC + i) * 2 + half;
-        float b = buf[i];
-        if (PROLOGUE) b = fmaxf(0.f, b * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
-        b = (k < cin) ? b : 0.f;
+        float a = buf[i];
+        if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
+        a = (k < cin) ? a : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w[(mt * 32 + l31) * ldw + k], b, acc[mt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
       }
     };
     float bufa[ML_KC], bufb[ML_KC];
@@ -126,36 +129,48 @@ __global__ __launch_bounds__(ML_WAVES * 64, (MT <= 2 ? 2 : 1)) void mlp_layer_fw
         mma_chunk(bufb, c + 1);
       }
     }
+    // epilogue: acc[nt][4g..4g+3] = positions e0 + 8g + 4*half + (0..3) of channel co0+32nt+l31
+    const bool full = e0 + 32 <= E;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const int co = co0 + nt * 32 + l31;
+      if (co < cout) {
+        float *yrow = yb + (size_t)co * E + e0 + 4 * half;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = mt * 32 + mrow(r, half);
-        const float v = acc[mt][r];
-        if (ok && co0 + co < cout) {
-          yb[(size_t)co * E + e] = v;
-          s1[mt][r] += v;
-          s2[mt][r] += v * v;
+        for (int g = 0; g < 4; ++g) {
+          const float v0 = acc[nt][4 * g], v1 = acc[nt][4 * g + 1], v2 = acc[nt][4 * g + 2], v3 = acc[nt][4 * g + 3];
+          if (VEC && full) {
+            *reinterpret_cast<float4 *>(yrow + 8 * g) = make_float4(v0, v1, v2, v3);
+            s1[nt] += (v0 + v1) + (v2 + v3);
+            s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          } else {
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (e0 + 8 * g + 4 * half + q < E) {
+                yrow[8 * g + q] = vv[q];
+                s1[nt] += vv[q];
+                s2[nt] += vv[q] * vv[q];
+              }
+          }
         }
       }
+    }
   }
 
-  // per-channel partial sums of this workgroup -> f64 atomics
+  // per-channel partial sums: the two half-waves hold disjoint position sets of the same channel
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float a = row32_sum(s1[mt][r]);
-      const float q = row32_sum(s2[mt][r]);
-      if (l31 == 0) {
-        const int co = mt * 32 + mrow(r, half);
-        s_red[(wave * 2 + 0) * CT + co] = a;
-        s_red[(wave * 2 + 1) * CT + co] = q;
-      }
+  for (int nt = 0; nt < NT; ++nt) {
+    const float a = s1[nt] + __shfl_xor(s1[nt], 32);
+    const float q = s2[nt] + __shfl_xor(s2[nt], 32);
+    if (half == 0) {
+      s_red[(wave * 2 + 0) * CT + nt * 32 + l31] = a;
+      s_red[(wave * 2 + 1) * CT + nt * 32 + l31] = q;
     }
+  }
   __syncthreads();
-  if (threadIdx.x < 2 * CT) {
-    const int which = threadIdx.x / CT, co = threadIdx.x % CT;
+  for (int i = threadIdx.x; i < 2 * CT; i += ML_WAVES * 64) {
+    const int which = i / CT, co = i % CT;
     if (co0 + co < cout) {
       double tot = 0.0;
 #pragma unroll
@@ -422,16 +437,16 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
 
 // ---- C ABI ----------------------------------------------------------------------------------
 
-template <int MT, bool PROLOGUE>
+template <int NT, bool PROLOGUE, bool VEC>
 static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                           const float *pscale, const float *pshift, float *y, double *stat_sum,
                           double *stat_sq, hipStream_t stream) {
-  constexpr int CT = 32 * MT;
+  constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
   const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT);
   static bool attr_done = false;  // per template instance
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<MT, PROLOGUE>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -441,10 +456,21 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
   int tpw = 8;
   while (tpw > 1 && (long)b * cblocks * ((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)) < 1024) tpw >>= 1;
   dim3 grid(cblocks, (unsigned)((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)), b);
-  hipLaunchKernelGGL((mlp_layer_fwd_kernel<MT, PROLOGUE>), grid, dim3(ML_WAVES * 64), lds, stream, cin,
-                     cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
+  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>), grid, dim3(ML_WAVES * 64), lds, stream,
+                     cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
   return 0;
+}
+
+template <int NT>
+static int dispatch_mlp_fwd(bool prologue, bool vec, int b, int cin, int cout, long e, const float *x,
+                            const float *w, const float *pscale, const float *pshift, float *y,
+                            double *stat_sum, double *stat_sq, hipStream_t stream) {
+  if (prologue)
+    return vec ? launch_mlp_fwd<NT, true, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+               : launch_mlp_fwd<NT, true, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  return vec ? launch_mlp_fwd<NT, false, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+             : launch_mlp_fwd<NT, false, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
 }
 
 extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
@@ -457,16 +483,21 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
   SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
   if (b == 0 || e == 0) return 0;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
-  SIG3D_REQUIRE(sizeof(float) * ((size_t)64 * ldw + 2 * kpad + ML_WAVES * 2 * 64) <= 160 * 1024,
+  SIG3D_REQUIRE(sizeof(float) * ((size_t)32 * ldw + 2 * kpad + ML_WAVES * 2 * 32) <= 160 * 1024,
                 "input channel count too large for the LDS weight tile");
-  // 128-channel tiles (x re-read from L2 half as often) when they fit LDS next to a second workgroup
-  const bool wide = cout >= 128 && sizeof(float) * ((size_t)128 * ldw + 2 * kpad + ML_WAVES * 2 * 128) <= 150 * 1024;
-  if (wide) {
-    return pscale ? launch_mlp_fwd<4, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
-                  : launch_mlp_fwd<4, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
-  }
-  return pscale ? launch_mlp_fwd<2, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
-                : launch_mlp_fwd<2, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  const bool vec = (e % 4 == 0);
+  auto fits = [&](int ct, size_t budget) {
+    return sizeof(float) * ((size_t)ct * ldw + 2 * kpad + ML_WAVES * 2 * ct) <= budget;
+  };
+  // widest channel tile whose weights leave room for a second workgroup on the CU (x is then
+  // re-read from L2 as rarely as possible)
+  if (cout > 64 && fits(128, 76 * 1024))
+    return dispatch_mlp_fwd<4>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  if (cout > 32 && fits(64, 76 * 1024))
+    return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  if (cout > 32 && fits(64, 160 * 1024))
+    return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  return dispatch_mlp_fwd<1>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
 }
 
 extern "C" int sig3d_bn_finalize(int c, double count, float eps, float momentum,

@@ -37,7 +37,7 @@ def test_fused_mlp_max_matches_torch(b, chans, p, s):
     x2 = x.clone().requires_grad_(True)
     g = torch.randn(b, chans[-1], p, device=DEV)
 
-    assert fused_mlp.can_fuse(mlp, x1)
+    assert fused_mlp.can_fuse(mlp, x1, min_positions=0)
     out = fused_mlp.fused_mlp_max(mlp, x1)
     (out * g).sum().backward()
     exp = torch.max(ref(x2), dim=3)[0]
@@ -58,8 +58,9 @@ def test_fused_path_is_taken_by_sa_module_and_falls_back_in_eval():
                                                   use_xyz=True).to(DEV)
     xyz, f = scene(2, 500, seed=1).to(DEV), feats(2, 5, 500).to(DEV)
     calls = []
-    orig = fused_mlp.fused_mlp_max
+    orig, orig_min = fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS
     fused_mlp.fused_mlp_max = lambda m, x: calls.append(1) or orig(m, x)
+    fused_mlp.MIN_POSITIONS = 0
     try:
         mod.train()
         _, a, _ = mod(xyz, f)
@@ -68,5 +69,5 @@ def test_fused_path_is_taken_by_sa_module_and_falls_back_in_eval():
         _, bb, _ = mod(xyz, f)  # eval mode uses running stats through the unfused torch path
         assert calls == [1]
     finally:
-        fused_mlp.fused_mlp_max = orig
+        fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS = orig, orig_min
     assert a.shape == bb.shape == (2, 64, 64)
