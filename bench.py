@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute FPS/ball-query geometry inline instead of one batch ahead")
     args = ap.parse_args()
@@ -133,7 +135,7 @@ def main():
     torch.manual_seed(1234)  # identical initial weights on every rank
     model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
     optimizer = build_optimizer(model)
-    reducer = GradBucketReducer(model.parameters()) if world > 1 else None
+    reducer = GradBucketReducer(model.parameters()) if (world > 1 or args.force_reducer) else None
 
     n_batches = min(4, args.steps + args.warmup)
     batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device) for i in range(n_batches)]
@@ -142,10 +144,10 @@ def main():
     work = torch.cuda.Stream(device)
     KSTEPS = 3
     with torch.cuda.stream(work):
-        use_graph = (world == 1) and not args.no_graph
+        use_graph = not args.no_graph
         if use_graph:
             graphed = GraphedTrainStep(model, optimizer, batches[0],
-                                       prefetch_geometry=not args.no_prefetch)
+                                       prefetch_geometry=not args.no_prefetch, reducer=reducer)
 
             def step(i):
                 return graphed(batches[i % n_batches], batches[(i + 1) % n_batches])
@@ -171,6 +173,8 @@ def main():
         # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
         # issued once more eagerly right after the timed region and bracketed there.
         _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_furthest_point_sampling"])
+        if reducer is not None:
+            reducer.hooks_enabled = True
         for i in range(KSTEPS):
             train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
         torch.cuda.synchronize()

@@ -30,6 +30,7 @@ class GradBucketReducer:
         self._slot = {}            # param -> bucket index
         self._off = {}             # param -> element offset inside its bucket
         self._build(bucket_bytes)
+        self.hooks_enabled = True  # False: no launches from backward (hipGraph capture); use reduce_all()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"  # RCCL has ReduceOp.AVG; gloo needs SUM + scale
@@ -73,6 +74,8 @@ class GradBucketReducer:
         b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if not self.hooks_enabled:
+            return
         b = self.buckets[self._slot[p]]
         if p.grad.data_ptr() != b["flat"].data_ptr() + self._offset(p, b):
             # something replaced .grad (e.g. zero_grad(set_to_none=True)): copy back into the slot
@@ -95,6 +98,19 @@ class GradBucketReducer:
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
+        for b in self.buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                if not self._avg:
+                    b["flat"].div_(self.world)
+
+    def reduce_all(self):
+        """All buckets at once (backward already finished, e.g. it ran as a hipGraph): launch every
+        all-reduce asynchronously, then join.  Stream-ordered after the current stream's work."""
+        for b in self.buckets:
+            b["launched"] = False
+            b["handle"] = None
+            self._launch(b)
         for b in self.buckets:
             if b["handle"] is not None:
                 b["handle"].wait()

@@ -53,7 +53,10 @@ class GraphedTrainStep:
     (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
-                 prefetch_geometry=False, geometry_levels=None):
+                 prefetch_geometry=False, geometry_levels=None, reducer=None):
+        """`reducer` (ddp.GradBucketReducer, data parallel): the step becomes graph A (forward +
+        backward, gradients accumulated into the reducer's flat buckets) -> eager bucketed RCCL
+        all-reduce -> graph B (value clip + AdamW).  No collective is ever captured."""
         stream = torch.cuda.current_stream()
         if stream == torch.cuda.default_stream():
             raise RuntimeError("GraphedTrainStep must be built (and used) inside "
@@ -63,6 +66,10 @@ class GraphedTrainStep:
         self.static_loss = None
         self.static_out = None
         self.graph = torch.cuda.CUDAGraph()
+        self.reducer = reducer
+        self.graph_opt = torch.cuda.CUDAGraph() if reducer is not None else None
+        if reducer is not None:
+            reducer.hooks_enabled = False
         self.prefetch = bool(prefetch_geometry)
         self._primed = False
         self._expected = None
@@ -78,7 +85,7 @@ class GraphedTrainStep:
             self.side = torch.cuda.Stream(pc.device)
             self.plan_cur.compute(self.static_next_xyz)  # geometry of the example batch
 
-        def one_step():
+        def fwd_bwd():
             batch = dict(self.static_batch)
             if self.prefetch:
                 batch["geometry_plan"] = self.plan_cur
@@ -86,25 +93,44 @@ class GraphedTrainStep:
             loss, out = get_loss(out)
             self.static_out = out  # answer_scores, aux_scores, ... of the last replay
             loss.backward()
+            return loss
+
+        def update():
             if max_grad_value is not None and max_grad_value > 0:
                 nn.utils.clip_grad_value_(params, clip_value=max_grad_value)
             optimizer.step()
-            return loss
+
+        def clear_grads():
+            if reducer is not None:
+                reducer.zero_grad()   # gradients live in the flat buckets: zero those in place
+            else:
+                optimizer.zero_grad(set_to_none=True)
 
         for _ in range(warmup):  # library workspaces, autotuning, allocator pools
-            optimizer.zero_grad(set_to_none=True)
-            one_step()
+            clear_grads()
+            fwd_bwd()
+            if reducer is not None:
+                reducer.reduce_all()
+            update()
         torch.cuda.synchronize()
-        optimizer.zero_grad(set_to_none=True)
+        if reducer is None:
+            optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph, stream=stream):
             if self.prefetch:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
                     self.plan_next.compute(self.static_next_xyz)
-            self.static_loss = one_step()
+            if reducer is not None:
+                reducer.zero_grad()
+            self.static_loss = fwd_bwd()
+            if reducer is None:
+                update()
             if self.prefetch:
                 stream.wait_stream(self.side)                    # join
                 self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
+        if reducer is not None:
+            with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph.pool()):
+                update()
         torch.cuda.synchronize()
 
     def prime(self, batch):
@@ -124,4 +150,7 @@ class GraphedTrainStep:
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
         _copy_into(self.static_batch, batch)
         self.graph.replay()
+        if self.reducer is not None:
+            self.reducer.reduce_all()
+            self.graph_opt.replay()
         return self.static_loss

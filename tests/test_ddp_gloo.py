@@ -40,7 +40,7 @@ def _data(rank):
     return torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, deferred):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from situation3d_amd.ddp import GradBucketReducer, init_distributed
@@ -49,13 +49,17 @@ def _worker(rank, world, port, out_dir):
     # tiny buckets: several collectives, exercised in backward order
     reducer = GradBucketReducer(model.parameters(), bucket_bytes=4096)
     assert reducer.num_collectives() >= 3
+    reducer.hooks_enabled = not deferred  # deferred: what the hipGraph step does (reduce_all)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
     x, y = _data(rank)
     for _ in range(2):
         reducer.zero_grad()
         loss = ((model(x) - y) ** 2).mean()
         loss.backward()
-        reducer.finish()
+        if deferred:
+            reducer.reduce_all()
+        else:
+            reducer.finish()
         grads = [p.grad.clone() for p in model.parameters()]
         opt.step()
     torch.save({"grads": grads, "params": [p.detach().clone() for p in model.parameters()]},
@@ -64,9 +68,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_bucket_reducer_world2(tmp_path):
+@pytest.mark.parametrize("deferred", [False, True])
+def test_bucket_reducer_world2(tmp_path, deferred):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), deferred), nprocs=world, join=True)
     r0 = torch.load(tmp_path / "r0.pt")
     r1 = torch.load(tmp_path / "r1.pt")
     for a, b in zip(r0["params"], r1["params"]):
