@@ -168,6 +168,24 @@ int sig3d_situational_transform_grad(int b, int n, const float *pose, const floa
                                      const float *grad_out, float *grad_points,
                                      float *grad_pose, int inverse, void *stream);
 
+/* ---- Blip2T5 pre-stage ------------------------------------------------------------------ */
+
+/* replaces the host-side position-embedding build + add of Blip2T5.forward
+ *   3DLLM_BLIP2-base/lavis/models/blip2_models/blip2_t5.py:106-118
+ * feat (b,n,c), pc (b,n,3) integer-valued floats, table (trows,tw) -> out (b,n,c):
+ * out[...,ch] = feat[...,ch] + scale * table[(long)pc[...,ch/tw]][ch%tw] for ch < 3*tw, else feat.
+ * Reference values: c = 1408, tw = 1408/3 = 469, trows = 256, scale = 0.01.  Indices are clamped
+ * to [0, trows) (the reference would raise on an out-of-range index). */
+int sig3d_pos_embed_add(int b, int n, int c, int tw, int trows, float scale, const float *feat,
+                        const float *pc, const float *table, float *out, void *stream);
+
+/* ---- Q-Former dense-layer helpers ------------------------------------------------------- */
+
+/* Bias gradient of an nn.Linear (backward of Qformer.py:242,311,324 `self.dense(...)` and of the
+ * query/key/value projections :164-178): out[c] = sum_r x[r][c], x (rows, cols) row-major.
+ * Deterministic (no atomics). */
+int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream);
+
 /* ---- Q-Former attention ---------------------------------------------------------------- */
 
 /* replaces BertSelfAttention.forward's core

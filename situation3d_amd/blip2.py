@@ -1,0 +1,86 @@
+"""3D-LLM BLIP-2 point branch up to the T5 projection -- host-side mirror of Blip2T5.forward
+(3DLLM_BLIP2-base/lavis/models/blip2_models/blip2_t5.py:102-129) for the part that is on the
+hot path: point features + 3-axis sinusoidal position embedding -> stripped Q-Former (32 learned
+queries, cross-attention to the point tokens) -> `t5_proj`.
+
+    samples["pc_feat"] (B, N, 1408) f32   per-point features (threedvqa_datasets.py:72-79: N = 5000)
+    samples["pc"]      (B, N, 3)    f32   integer-valued voxel coordinates < 256
+ -> {"inputs_t5" (B, 32, t5_hidden), "atts_t5" (B, 32) i64, "query_output" (B, 32, 768), "loss"}
+
+The frozen Flan-T5-XL that turns `inputs_t5` into the loss (blip2_t5.py:136-183) is out of scope
+(3 B parameters, weights unavailable); plug it in as `language_head(inputs_t5, atts_t5, samples)
+-> loss`.  Without one, "loss" is None.
+
+The reference builds the position term on the CPU in a Python double loop and copies
+B x N x 1408 floats to the GPU every step (blip2_t5.py:106-116); here it is one streaming HIP
+kernel (csrc/pos_embed.hip).  The sinusoid table comes from `positional_encodings`'
+PositionalEncoding1D(1408 // 3) evaluated on 256 positions (blip2_t5.py:93-95); that package is
+neither vendored nor pinned by the reference (environment.yml), so the layout used here
+(interleaved sin/cos, channels rounded up to even then cut to 469) is this build's stated
+reading of it, and the table is an ordinary buffer that a checkpoint may overwrite.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .qformer import init_Qformer
+
+
+def sinusoid_table(n_pos=256, channels=1408 // 3):
+    """PositionalEncoding1D(channels) on positions 0..n_pos-1: (n_pos, channels)."""
+    ch = (channels + 1) // 2 * 2
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+    sin_inp = torch.einsum("i,j->ij", torch.arange(n_pos).float(), inv_freq)
+    emb = torch.stack((sin_inp.sin(), sin_inp.cos()), dim=-1).flatten(-2, -1)
+    return emb[:, :channels].contiguous()
+
+
+class _PosEmbedAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, pc, table, scale):
+        dev = _lib.require_device(feat, pc, table)
+        feat, pc, table = feat.contiguous(), pc.contiguous().float(), table.contiguous()
+        b, n, c = feat.shape
+        out = torch.empty_like(feat)
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_pos_embed_add", b, n, c, table.shape[1], table.shape[0],
+                      ctypes.c_float(scale), _lib.ptr(feat), _lib.ptr(pc), _lib.ptr(table),
+                      _lib.ptr(out), _lib.stream_ptr(dev))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return grad_out, None, None, None  # out = feat + const
+
+
+def add_position_embedding(pc_feat, pc, table, scale=0.01):
+    """blip2_t5.py:106-118 as one kernel."""
+    return _PosEmbedAdd.apply(pc_feat, pc, table, float(scale))
+
+
+class Blip2PointQFormer(nn.Module):
+    def __init__(self, num_query_token=32, point_width=1408, t5_hidden=2048, language_head=None,
+                 qformer_overrides=None):
+        super().__init__()
+        self.Qformer, self.query_tokens = init_Qformer(num_query_token, point_width,
+                                                       **(qformer_overrides or {}))
+        self.Qformer.strip_text_branch()  # blip2_t5.py:63-69
+        self.t5_proj = nn.Linear(self.Qformer.config.hidden_size, t5_hidden)  # blip2_t5.py:91
+        self.register_buffer("pos_embedding", sinusoid_table(256, point_width // 3))
+        self.language_head = language_head
+
+    def forward(self, samples):
+        pc_embeds = add_position_embedding(samples["pc_feat"], samples["pc"], self.pos_embedding, 0.01)
+        image_atts = torch.ones(pc_embeds.size()[:-1], dtype=torch.long, device=pc_embeds.device)
+        query_tokens = self.query_tokens.expand(pc_embeds.shape[0], -1, -1)
+        query_output = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=pc_embeds,
+                                         encoder_attention_mask=image_atts, return_dict=True)
+        inputs_t5 = self.t5_proj(query_output.last_hidden_state)
+        atts_t5 = torch.ones(inputs_t5.size()[:-1], dtype=torch.long, device=pc_embeds.device)
+        loss = None
+        if self.language_head is not None:
+            loss = self.language_head(inputs_t5, atts_t5, samples)
+        return {"loss": loss, "inputs_t5": inputs_t5, "atts_t5": atts_t5,
+                "query_output": query_output.last_hidden_state}

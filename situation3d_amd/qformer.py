@@ -56,6 +56,43 @@ class QFormerConfig:
             setattr(self, k, v)
 
 
+class _LinearFn(torch.autograd.Function):
+    """F.linear with the same library GEMMs, but the bias gradient comes from the deterministic
+    column-sum kernel (sig3d_column_sum) instead of torch's generic reduce kernel (~12 us per
+    416 x 768 input on MI355X, 122 launches per Q-Former forward+backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy2 = gy.reshape(-1, gy.shape[-1])
+        if not gy2.is_contiguous():
+            gy2 = gy2.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy2.mm(weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = gy2.t().mm(x.reshape(-1, x.shape[-1]))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(gy2.shape[1], dtype=gy2.dtype, device=gy2.device)
+            with torch.cuda.device(gy2.device):
+                _lib.call("sig3d_column_sum", gy2.shape[0], gy2.shape[1], _lib.ptr(gy2), _lib.ptr(gb),
+                          _lib.stream_ptr(gy2.device))
+        return gx, gw, gb
+
+
+def linear(layer, x):
+    """`layer(x)` for an nn.Linear on the GPU hot path."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return _LinearFn.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 class _AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale + mask) v on token-major (B, N, H*64) operands."""
 
@@ -183,9 +220,9 @@ class BertSelfAttention(nn.Module):
         kv_src = encoder_hidden_states if is_cross_attention else hidden_states
         if is_cross_attention:
             attention_mask = encoder_attention_mask
-        key = self.key(kv_src)
-        value = self.value(kv_src)
-        query = self.query(hidden_states)
+        key = linear(self.key, kv_src)
+        value = linear(self.value, kv_src)
+        query = linear(self.query, hidden_states)
         mask = _key_mask(attention_mask, query.shape[0], key.shape[1])
         context_layer = fused_attention(query, key, value, mask, self.num_attention_heads)
         return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
@@ -201,7 +238,7 @@ class BertSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+        return self.LayerNorm(self.dropout(linear(self.dense, hidden_states)) + input_tensor)
 
 
 class BertAttention(nn.Module):
@@ -231,7 +268,7 @@ class BertIntermediate(nn.Module):
         self.intermediate_act_fn = nn.GELU()
 
     def forward(self, hidden_states):
-        return self.intermediate_act_fn(self.dense(hidden_states))
+        return self.intermediate_act_fn(linear(self.dense, hidden_states))
 
 
 class BertOutput(nn.Module):
@@ -244,7 +281,7 @@ class BertOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(self.dense(hidden_states)) + input_tensor)
+        return self.LayerNorm(self.dropout(linear(self.dense, hidden_states)) + input_tensor)
 
 
 class BertLayer(nn.Module):
