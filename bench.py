@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
+    ap.add_argument("--torch-adamw", action="store_true",
+                    help="torch.optim.AdamW + clip_grad_value_ instead of the fused flat optimizer")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -134,8 +136,13 @@ def main():
     device = torch.device("cuda", local)
     torch.manual_seed(1234)  # identical initial weights on every rank
     model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
-    optimizer = build_optimizer(model)
-    reducer = GradBucketReducer(model.parameters()) if (world > 1 or args.force_reducer) else None
+    # clip_grad_value_(1.0) + AdamW (lr 2e-5, wd 0.05: scripts/train.sh:7) + zero_grad fused over
+    # flat storage; under data parallelism the same flat gradient buffers are all-reduced in place
+    optimizer = build_optimizer(model, name="adamw" if args.torch_adamw else "flat_adamw")
+    reducer = None
+    if world > 1 or args.force_reducer:
+        reducer = (GradBucketReducer(model.parameters()) if args.torch_adamw
+                   else GradBucketReducer.from_flat(optimizer.flat_grad_buffers()))
 
     n_batches = min(4, args.steps + args.warmup)
     batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device) for i in range(n_batches)]

@@ -186,6 +186,18 @@ int sig3d_pos_embed_add(int b, int n, int c, int tw, int trows, float scale, con
  * Deterministic (no atomics). */
 int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream);
 
+/* ---- optimizer step ---------------------------------------------------------------------- */
+
+/* clip_grad_value_ + AdamW.step() (+ the next zero_grad) of lib/solver.py:618-627 /
+ * situation3d/train/train.py:226-238 over FLAT storage: p, g, m, v are n-element arrays (one set
+ * per parameter group), `step` a device scalar holding the 1-based step count t (advance it with
+ * sig3d_step_increment BEFORE the update of a step).  clip_value <= 0 disables the clamp;
+ * zero_grad != 0 writes zeros back to g.  Same update rule as torch.optim.AdamW. */
+int sig3d_step_increment(float *step, void *stream);
+int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float *step, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float clip_value,
+                     int zero_grad, void *stream);
+
 /* ---- Q-Former attention ---------------------------------------------------------------- */
 
 /* replaces BertSelfAttention.forward's core

@@ -1,0 +1,86 @@
+// optim.hip -- value clip + AdamW over flat parameter storage for gfx950.
+//
+// Replaces, for the training step of the reference's Solver (lib/solver.py:618-627):
+//   nn.utils.clip_grad_value_(model.parameters(), clip_value)   # one clamp pass over all grads
+//   optimizer.step()                                            # torch.optim.AdamW (train.py:226-238)
+//   optimizer.zero_grad()                                       # next iteration (solver.py:620)
+// torch runs this as ~36 multi-tensor launches (pointer tables are limited by kernel-argument
+// size) that reach ~1.8 TB/s; parameters, gradients and both moments live here in FLAT buffers
+// (one per parameter group), so the whole update is ONE streaming kernel per group with 16-byte
+// accesses: read p, g, m, v -- write p, m, v and the zeroed gradient (32 B/element, HBM-bound).
+// The step counter lives on the device (hipGraph replay must not bake it into the graph).
+//
+// Update rule == torch.optim.AdamW (amsgrad=False, maximize=False):
+//   g = clamp(g, -clip, clip);  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "sig3d_common.h"
+
+namespace {
+
+__global__ void step_increment_kernel(float *step) { *step += 1.f; }
+
+__device__ __forceinline__ void adamw_one(float &p, float &g, float &m, float &v, float lr, float b1,
+                                          float b2, float eps, float wd, float clip, float step_size,
+                                          float inv_sqrt_bc2) {
+  float gg = g;
+  if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+  p = p * (1.f - lr * wd);
+  m = b1 * m + (1.f - b1) * gg;
+  v = b2 * v + (1.f - b2) * gg * gg;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(long n, float *__restrict__ p,
+                                                         float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v,
+                                                         const float *__restrict__ step, float lr,
+                                                         float b1, float b2, float eps, float wd,
+                                                         float clip, int zero_grad) {
+  const float t = *step;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
+    float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+    adamw_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, wd, clip, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4 *>(p)[i] = pp;
+    reinterpret_cast<float4 *>(m)[i] = mm;
+    reinterpret_cast<float4 *>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<float4 *>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail (flat buffers are padded, so normally empty)
+    const long i = (n4 << 2) + threadIdx.x;
+    float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    adamw_one(pp, gg, mm, vv, lr, b1, b2, eps, wd, clip, step_size, inv_sqrt_bc2);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int sig3d_step_increment(float *step, void *stream_) {
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step);
+  SIG3D_LAUNCH_CHECK("step_increment_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float *step,
+                                float lr, float beta1, float beta2, float eps, float weight_decay,
+                                float clip_value, int zero_grad, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return 0;
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, p, g, m, v, step,
+                     lr, beta1, beta2, eps, weight_decay, clip_value, zero_grad);
+  SIG3D_LAUNCH_CHECK("adamw_flat_kernel");
+  return 0;
+}

@@ -35,6 +35,29 @@ class GradBucketReducer:
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"  # RCCL has ReduceOp.AVG; gloo needs SUM + scale
 
+    @classmethod
+    def from_flat(cls, flat_buffers, process_group=None, bucket_bytes=64 << 20):
+        """Reducer over gradient storage that is ALREADY flat (optim.FlatAdamW.flat_grad_buffers()):
+        buckets are plain slices of those buffers, reduced in place by reduce_all() / finish();
+        zeroing is the optimizer's job and there are no per-parameter hooks."""
+        self = cls.__new__(cls)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params, self._slot, self._off, self._hooks = [], {}, {}, []
+        self.hooks_enabled = False
+        self.flat_mode = True
+        self.buckets = []
+        for flat in flat_buffers:
+            chunk = max(1, bucket_bytes // flat.element_size())
+            for off in range(0, flat.numel(), chunk):
+                self.buckets.append(dict(flat=flat[off:off + chunk], params=[], pending=0,
+                                         handle=None, launched=False))
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._avg = backend == "nccl"
+        return self
+
+    flat_mode = False
+
     def _build(self, bucket_bytes):
         cur, cur_bytes = [], 0
         groups = []
@@ -60,6 +83,8 @@ class GradBucketReducer:
                                      launched=False))
 
     def zero_grad(self):
+        if self.flat_mode:
+            return  # the optimizer that owns the flat buffers zeroes them (FlatAdamW.step)
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"] = len(b["params"])
@@ -95,6 +120,8 @@ class GradBucketReducer:
 
     def finish(self):
         """Join all collectives (and reduce buckets whose parameters got no gradient)."""
+        if self.flat_mode:
+            return self.reduce_all()
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)

@@ -95,12 +95,16 @@ class GraphedTrainStep:
             loss.backward()
             return loss
 
+        fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
+
         def update():
-            if max_grad_value is not None and max_grad_value > 0:
+            if not fused_opt and max_grad_value is not None and max_grad_value > 0:
                 nn.utils.clip_grad_value_(params, clip_value=max_grad_value)
-            optimizer.step()
+            optimizer.step()  # FlatAdamW: clip + AdamW + zero_grad in one kernel per group
 
         def clear_grads():
+            if fused_opt:
+                return  # flat gradients are zeroed by every step() and start at zero
             if reducer is not None:
                 reducer.zero_grad()   # gradients live in the flat buckets: zero those in place
             else:

@@ -45,7 +45,8 @@ def get_loss(data_dict, situation_loss_tag="__l2__quat__", use_aux_situation=Tru
     return loss, data_dict
 
 
-def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name="adamw"):
+def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name="adamw",
+                    clip_value=1.0):
     no_decay_filter = ("bias", "LayerNorm.weight")
     decay, no_decay = [], []
     for n, p in model.named_parameters():
@@ -53,6 +54,10 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
             continue
         (no_decay if any(nd in n for nd in no_decay_filter) else decay).append(p)
     groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
+    if name == "flat_adamw":
+        # clip_grad_value_(1.0) + AdamW + zero_grad as one streaming kernel per group (optim.py)
+        from .optim import FlatAdamW
+        return FlatAdamW(groups, lr=lr, betas=betas, eps=eps, clip_value=clip_value)
     cls = torch.optim.AdamW if name == "adamw" else torch.optim.Adam
     # fused: one multi-tensor HIP kernel per step instead of ~4 launches per parameter;
     # capturable: step counters live on the device so the step can sit inside a hipGraph
@@ -64,7 +69,10 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
 def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     """One Solver iteration (solver.py:374-402, 618-627).  With a GradBucketReducer the gradient
     all-reduce is launched bucket by bucket from inside backward and joined before clipping."""
-    if reducer is not None:
+    fused = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
+    if fused:
+        pass  # gradients were zeroed by the previous step() (and start at zero)
+    elif reducer is not None:
         reducer.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=False)
@@ -73,7 +81,7 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     loss.backward()
     if reducer is not None:
         reducer.finish()
-    if max_grad_value is not None and max_grad_value > 0:
+    if not fused and max_grad_value is not None and max_grad_value > 0:
         nn.utils.clip_grad_value_(model.parameters(), clip_value=max_grad_value)
-    optimizer.step()
+    optimizer.step()  # FlatAdamW: clip + update + zero_grad in one kernel per group
     return loss
