@@ -198,6 +198,15 @@ int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float
                      float beta1, float beta2, float eps, float weight_decay, float clip_value,
                      int zero_grad, void *stream);
 
+/* Same update driven by a device-resident table of `nchunks` records
+ *   struct { float *p, *g, *m, *v; long long n; float weight_decay; float pad; }   (48 bytes)
+ * one workgroup per record (n <= 65536 recommended): gradients may live wherever autograd
+ * allocated them.  sig3d_gather_table copies g -> m for every record (used to gather scattered
+ * gradients into flat storage before a data-parallel all-reduce). */
+int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr, float beta1,
+                      float beta2, float eps, float clip_value, void *stream);
+int sig3d_gather_table(int nchunks, const void *table, void *stream);
+
 /* ---- Q-Former attention ---------------------------------------------------------------- */
 
 /* replaces BertSelfAttention.forward's core

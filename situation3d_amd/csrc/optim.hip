@@ -62,7 +62,82 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(long n, float *__restri
   }
 }
 
+// ---- pointer-table variants ------------------------------------------------------------------
+// Autograd hands every parameter a freshly allocated gradient tensor (when .grad is None it just
+// adopts the tensor: no kernel).  Keeping .grad as a view of a flat buffer instead costs one tiny
+// accumulate-add launch PER PARAMETER (+315 launches per step for this model), so the gradients
+// stay where autograd put them and the kernels below walk a device-resident table of chunks
+// {p, g, m, v, n, weight_decay}: one workgroup per chunk of <= 65536 elements, ONE launch for the
+// whole model.  Under hipGraph replay all addresses are static, so the table is built once.
+struct OptChunk {
+  float *p;
+  float *g;
+  float *m;
+  float *v;
+  long long n;
+  float wd;
+  float pad;
+};
+
+__global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__restrict__ table,
+                                                          const float *__restrict__ step, float lr,
+                                                          float b1, float b2, float eps, float clip) {
+  const OptChunk c = table[blockIdx.x];
+  const float t = *step;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const bool vec = ((((size_t)c.p | (size_t)c.g | (size_t)c.m | (size_t)c.v) & 15) == 0);
+  const long n4 = vec ? (c.n >> 2) : 0;
+  for (long i = threadIdx.x; i < n4; i += 256) {
+    float4 pp = reinterpret_cast<float4 *>(c.p)[i], gg = reinterpret_cast<const float4 *>(c.g)[i];
+    float4 mm = reinterpret_cast<float4 *>(c.m)[i], vv = reinterpret_cast<float4 *>(c.v)[i];
+    adamw_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+    adamw_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+    reinterpret_cast<float4 *>(c.p)[i] = pp;
+    reinterpret_cast<float4 *>(c.m)[i] = mm;
+    reinterpret_cast<float4 *>(c.v)[i] = vv;
+  }
+  for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
+    float pp = c.p[i], gg = c.g[i], mm = c.m[i], vv = c.v[i];
+    adamw_one(pp, gg, mm, vv, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+    c.p[i] = pp; c.m[i] = mm; c.v[i] = vv;
+  }
+}
+
+// dst (chunk.m field reused as destination) <- src (chunk.g): gather scattered gradients into
+// flat storage for the data-parallel all-reduce
+__global__ __launch_bounds__(256) void gather_table_kernel(const OptChunk *__restrict__ table) {
+  const OptChunk c = table[blockIdx.x];
+  const bool vec = ((((size_t)c.g | (size_t)c.m) & 15) == 0);
+  const long n4 = vec ? (c.n >> 2) : 0;
+  for (long i = threadIdx.x; i < n4; i += 256)
+    reinterpret_cast<float4 *>(c.m)[i] = reinterpret_cast<const float4 *>(c.g)[i];
+  for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) c.m[i] = c.g[i];
+}
+
 }  // namespace
+
+extern "C" int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr,
+                                 float beta1, float beta2, float eps, float clip_value,
+                                 void *stream_) {
+  SIG3D_REQUIRE(nchunks >= 0, "negative size");
+  if (nchunks == 0) return 0;
+  hipLaunchKernelGGL(adamw_table_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream_,
+                     (const OptChunk *)table, step, lr, beta1, beta2, eps, clip_value);
+  SIG3D_LAUNCH_CHECK("adamw_table_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_gather_table(int nchunks, const void *table, void *stream_) {
+  SIG3D_REQUIRE(nchunks >= 0, "negative size");
+  if (nchunks == 0) return 0;
+  hipLaunchKernelGGL(gather_table_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream_,
+                     (const OptChunk *)table);
+  SIG3D_LAUNCH_CHECK("gather_table_kernel");
+  return 0;
+}
 
 extern "C" int sig3d_step_increment(float *step, void *stream_) {
   hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step);

@@ -93,6 +93,8 @@ class GraphedTrainStep:
             loss, out = get_loss(out)
             self.static_out = out  # answer_scores, aux_scores, ... of the last replay
             loss.backward()
+            if reducer is not None and fused_opt:
+                optimizer.gather_grads()  # scattered grads -> the flat buffers the reducer owns
             return loss
 
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW

@@ -1,20 +1,32 @@
-"""FlatAdamW: value clip + AdamW + gradient zeroing as ONE streaming HIP kernel per parameter
-group (csrc/optim.hip), for the update of lib/solver.py:618-627 / train.py:226-238.
+"""FlatAdamW: value clip + AdamW as ONE streaming HIP kernel (csrc/optim.hip), for the update of
+lib/solver.py:618-627 / situation3d/train/train.py:226-238.
 
-Parameters, gradients and both moments of a group live in flat float32 buffers; every
-`p.data` / `p.grad` is a view into them (module state_dict keys and shapes are untouched).
-Because gradients are views of one buffer per group they can be all-reduced in place in a few
-large slices (ddp.GradBucketReducer.from_flat) and they are never re-allocated, which also makes
-the step hipGraph-friendly: the step counter is a device scalar advanced by a captured kernel.
+Storage: parameters and both moments of a parameter group live in flat float32 buffers (every
+`p.data` is a view; module state_dict keys and shapes are untouched).  Gradients are NOT flat:
+autograd hands each parameter a fresh tensor when `.grad is None` (no kernel), whereas a
+persistent flat `.grad` view costs one accumulate-add launch per parameter (+315 launches per
+step for this model, measured).  So `step()` walks a device-resident table of 64 Ki-element
+chunks {p, g, m, v, n, weight_decay} -- one launch for the whole model -- and then drops the
+gradients (`zero_grad(set_to_none=True)` semantics of the reference's Solver loop).
 
-Numerically this is torch.optim.AdamW (amsgrad=False) preceded by clip_grad_value_; the fused
-zeroing replaces the `zero_grad()` at the top of the next iteration.
+Data parallel: `gather_grads()` copies the scattered gradients into flat buffers (one launch),
+`flat_grad_buffers()` exposes them for an in-place bucketed all-reduce
+(ddp.GradBucketReducer.from_flat) and the following `step()` consumes the flat, reduced gradients.
+
+Numerically this is torch.optim.AdamW (amsgrad=False) preceded by clip_grad_value_.  The learning
+rate is read when step() is CALLED: under hipGraph replay it is baked into the captured launch
+(re-capture, or rebuild the optimizer, to change it).
 """
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
+
+_CHUNK = 65536
+_REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
+                 ("pad", "f4")])
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -23,67 +35,128 @@ class FlatAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.clip_value = float(clip_value)
-        self._flat = []
+        self._groups = []
         dev = None
-        for group in self.param_groups:
+        recs, owners = [], []   # static part of the chunk table; owners[i] = index into self._params
+        self._params = []
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
-            if not ps:
-                self._flat.append(None)
-                continue
+            if gi > 0 and (group["lr"], group["betas"], group["eps"]) != \
+                    (self.param_groups[0]["lr"], self.param_groups[0]["betas"], self.param_groups[0]["eps"]):
+                raise RuntimeError("FlatAdamW: groups may differ in weight_decay only")
             for p in ps:
                 if not p.is_cuda or p.dtype != torch.float32:
                     raise RuntimeError("FlatAdamW needs float32 parameters on the GPU")
+            if not ps:
+                self._groups.append(None)
+                continue
             dev = ps[0].device
-            # 4-element (16-byte) alignment of every parameter inside the flat buffers
             offs, total = [], 0
-            for p in ps:
+            for p in ps:  # 16-byte alignment of every parameter inside the flat buffers
                 offs.append(total)
                 total += (p.numel() + 3) // 4 * 4
             flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-            flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+            m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
             for p, off in zip(ps, offs):
                 flat_p[off:off + p.numel()].copy_(p.data.reshape(-1))
                 p.data = flat_p[off:off + p.numel()].view_as(p)
-                p.grad = flat_g[off:off + p.numel()].view_as(p)
-            self._flat.append(dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p),
-                                   v=torch.zeros_like(flat_p), params=ps, offs=offs))
+                p.grad = None
+                pi = len(self._params)
+                self._params.append((p, gi, off))
+                for c0 in range(0, p.numel(), _CHUNK):
+                    n = min(_CHUNK, p.numel() - c0)
+                    byte = 4 * (off + c0)
+                    recs.append((flat_p.data_ptr() + byte, 4 * c0, m.data_ptr() + byte,
+                                 v.data_ptr() + byte, n, group["weight_decay"], 0.0))
+                    owners.append(pi)
+            self._groups.append(dict(p=flat_p, m=m, v=v, g=None, total=total))
+        self._dev = dev
         self._step = torch.zeros((), dtype=torch.float32, device=dev)
+        self._static = np.array(recs, dtype=_REC)          # 'g' holds the byte offset inside the grad
+        self._owners = np.array(owners, dtype=np.int64)
+        self._host = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory()
+        self._host_np = self._host.numpy().view(_REC)
+        self._table = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev)
+        self._gathered = False
 
+    # ---- chunk table ------------------------------------------------------------------------
+    def _upload(self, dst_field_from_flat_g=False):
+        """Fill the per-step columns of the table (gradient pointers) and push it to the device."""
+        gptr = np.zeros(len(self._params), dtype=np.uint64)
+        live = np.zeros(len(self._params), dtype=bool)
+        for i, (p, gi, off) in enumerate(self._params):
+            g = p.grad
+            if g is None:
+                continue
+            if not g.is_contiguous():
+                g = g.contiguous()
+                p.grad = g
+            gptr[i] = g.data_ptr()
+            live[i] = True
+        t = self._host_np
+        t[:] = self._static
+        t["g"] = gptr[self._owners] + self._static["g"]
+        t["n"] = np.where(live[self._owners], self._static["n"], 0)  # params without grad: skipped
+        if dst_field_from_flat_g:  # gather: destination = flat gradient storage (passed in 'm')
+            base = np.zeros(len(self._params), dtype=np.uint64)
+            for i, (p, gi, off) in enumerate(self._params):
+                base[i] = self._groups[gi]["g"].data_ptr() + 4 * off
+            t["m"] = base[self._owners] + self._static["g"]
+        # eager: blocking copy (the pinned staging buffer is rewritten next step); inside a hipGraph
+        # capture the copy becomes a memcpy node reading the (then static) staging buffer
+        self._table.copy_(self._host, non_blocking=torch.cuda.is_current_stream_capturing())
+
+    # ---- public ----------------------------------------------------------------------------------
     def flat_grad_buffers(self):
-        return [f["g"] for f in self._flat if f is not None]
+        for g in self._groups:
+            if g is not None and g["g"] is None:
+                g["g"] = torch.zeros(g["total"], dtype=torch.float32, device=self._dev)
+        return [g["g"] for g in self._groups if g is not None]
 
-    def zero_grad(self, set_to_none=False):
-        """Gradients are zeroed by step() itself; an explicit call zeroes the flat buffers in place
-        (the views must survive, so `set_to_none` is ignored)."""
-        for f in self._flat:
-            if f is not None:
-                f["g"].zero_()
+    def gather_grads(self):
+        """Scattered .grad tensors -> flat gradient buffers (one launch); the next step() then reads
+        the flat (e.g. all-reduced) gradients."""
+        self.flat_grad_buffers()
+        for g in self._groups:
+            if g is not None:
+                g["g"].zero_()  # parameters without a gradient contribute zeros to the all-reduce
+        self._upload(dst_field_from_flat_g=True)
+        with torch.cuda.device(self._dev):
+            _lib.call("sig3d_gather_table", len(self._static), _lib.ptr(self._table),
+                      _lib.stream_ptr(self._dev))
+        self._gathered = True
+        for p, _, _ in self._params:
+            p.grad = None
 
-    def _rebind(self, f):
-        # something (e.g. zero_grad(set_to_none=True) elsewhere) detached a .grad view: restore it
-        for p, off in zip(f["params"], f["offs"]):
-            view = f["g"][off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = view
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-                p.grad = view
+    def zero_grad(self, set_to_none=True):
+        for p, _, _ in self._params:
+            p.grad = None
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        dev = self._step.device
+        dev = self._dev
         stream = _lib.stream_ptr(dev)
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
         with torch.cuda.device(dev):
             _lib.call("sig3d_step_increment", _lib.ptr(self._step), stream)
-            for group, f in zip(self.param_groups, self._flat):
-                if f is None:
-                    continue
-                self._rebind(f)
-                b1, b2 = group["betas"]
-                _lib.call("sig3d_adamw_flat", f["p"].numel(), _lib.ptr(f["p"]), _lib.ptr(f["g"]),
-                          _lib.ptr(f["m"]), _lib.ptr(f["v"]), _lib.ptr(self._step),
-                          ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
-                          ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
-                          ctypes.c_float(self.clip_value), 1, stream)
+            if self._gathered:
+                for group, f in zip(self.param_groups, self._groups):
+                    if f is None:
+                        continue
+                    _lib.call("sig3d_adamw_flat", f["total"], _lib.ptr(f["p"]), _lib.ptr(f["g"]),
+                              _lib.ptr(f["m"]), _lib.ptr(f["v"]), _lib.ptr(self._step),
+                              ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
+                              ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
+                              ctypes.c_float(self.clip_value), 0, stream)
+                self._gathered = False
+            else:
+                self._upload()
+                _lib.call("sig3d_adamw_table", len(self._static), _lib.ptr(self._table),
+                          _lib.ptr(self._step), ctypes.c_float(g0["lr"]), ctypes.c_float(b1),
+                          ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
+                          ctypes.c_float(self.clip_value), stream)
+                for p, _, _ in self._params:
+                    p.grad = None
         return loss

@@ -80,6 +80,8 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     loss, data_dict = get_loss(data_dict)
     loss.backward()
     if reducer is not None:
+        if fused:
+            optimizer.gather_grads()  # scattered grads -> flat buffers (reducer.from_flat slices)
         reducer.finish()
     if not fused and max_grad_value is not None and max_grad_value > 0:
         nn.utils.clip_grad_value_(model.parameters(), clip_value=max_grad_value)

@@ -1,5 +1,7 @@
-"""FlatAdamW (csrc/optim.hip) == clip_grad_value_ + torch.optim.AdamW + zero_grad
-(lib/solver.py:618-627, situation3d/train/train.py:226-238), step for step."""
+"""FlatAdamW (csrc/optim.hip) == clip_grad_value_ + torch.optim.AdamW + zero_grad(set_to_none)
+(lib/solver.py:618-627, situation3d/train/train.py:226-238), step for step -- through the
+pointer-table kernel (scattered gradients), the gather + flat kernel (data-parallel path) and
+inside a hipGraph replay."""
 import copy
 
 import pytest
@@ -12,7 +14,9 @@ DEV = "cuda:0"
 
 def _net():
     torch.manual_seed(0)
-    return nn.Sequential(nn.Linear(37, 64), nn.LayerNorm(64), nn.GELU(), nn.Linear(64, 5)).to(DEV)
+    # 300 x 300 = 90000 elements: more than one 65536-element chunk
+    return nn.Sequential(nn.Linear(37, 300), nn.LayerNorm(300), nn.GELU(), nn.Linear(300, 300),
+                         nn.GELU(), nn.Linear(300, 5)).to(DEV)
 
 
 def _groups(m, wd):
@@ -21,9 +25,10 @@ def _groups(m, wd):
     return [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
 
 
-def test_flat_adamw_matches_torch_adamw_with_value_clip():
+@pytest.mark.parametrize("gather", [False, True])
+def test_flat_adamw_matches_torch_adamw_with_value_clip(gather):
     from situation3d_amd.optim import FlatAdamW
-    a, b = _net(), None
+    a = _net()
     b = copy.deepcopy(a)
     ref = torch.optim.AdamW(_groups(a, 0.05), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
     opt = FlatAdamW(_groups(b, 0.05), lr=1e-2, betas=(0.9, 0.999), eps=1e-8, clip_value=0.05)
@@ -31,17 +36,31 @@ def test_flat_adamw_matches_torch_adamw_with_value_clip():
     for step in range(25):
         x = torch.randn(16, 37, generator=g).to(DEV)
         y = torch.randn(16, 5, generator=g).to(DEV)
-        ref.zero_grad(set_to_none=False)
+        ref.zero_grad(set_to_none=True)
         (10 * (a(x) - y).pow(2).mean()).backward()
         nn.utils.clip_grad_value_(a.parameters(), 0.05)
         ref.step()
-        (10 * (b(x) - y).pow(2).mean()).backward()   # no zero_grad: fused into the previous step()
+        (10 * (b(x) - y).pow(2).mean()).backward()
+        if gather:
+            opt.gather_grads()          # what the data-parallel step does before the all-reduce
+            assert all(p.grad is None for p in b.parameters())
         opt.step()
+        assert all(p.grad is None for p in b.parameters())  # zero_grad(set_to_none=True) semantics
     for (n, p), q in zip(a.named_parameters(), b.parameters()):
         torch.testing.assert_close(q, p, rtol=1e-5, atol=1e-6, msg=lambda m: n + ": " + m)
-        assert q.grad.abs().max() == 0  # zeroed by step()
-    # parameters are views of one flat buffer per group; state_dict keys/shapes unchanged
-    assert [k for k in b.state_dict()] == [k for k in a.state_dict()]
+    assert list(b.state_dict()) == list(a.state_dict())  # keys / shapes untouched by the flat storage
+
+
+def test_flat_adamw_skips_parameters_without_gradient():
+    from situation3d_amd.optim import FlatAdamW
+    a = _net()
+    extra = nn.Linear(4, 4).to(DEV)
+    before = extra.weight.detach().clone()
+    opt = FlatAdamW([{"params": list(a.parameters()) + list(extra.parameters()), "weight_decay": 0.1}],
+                    lr=1e-2)
+    (a(torch.randn(4, 37, device=DEV)).sum()).backward()
+    opt.step()
+    assert torch.equal(extra.weight, before)  # torch.optim.AdamW also skips p.grad is None
 
 
 def test_flat_adamw_inside_graph_replay():
