@@ -203,6 +203,12 @@ def main():
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query")
         fps = kernel_ms("sig3d_furthest_point_sampling")
+        # HBM traffic of the roofline kernel cannot be read from inside this process: it comes from
+        # the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_query_group_fused.json")
+        if os.path.exists(pmc):
+            traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -218,7 +224,8 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),
                          "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
             "kernels_ms_per_step": {"query_group_fused": round(sum(grp) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),

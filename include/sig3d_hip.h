@@ -186,6 +186,29 @@ int sig3d_pos_embed_add(int b, int n, int c, int tw, int trows, float scale, con
  * Deterministic (no atomics). */
 int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream);
 
+/* Tail of BertSelfOutput / BertOutput (Qformer.py:241-246, 323-328) as one row kernel:
+ *   out = LayerNorm(dropout(x + bias) + res) * gamma + beta,   x = dense(...) WITHOUT its bias.
+ * x, res, out, v (rows, cols) with cols <= 1024; v receives the pre-LayerNorm sum, mean / rstd
+ * (rows) the row statistics, mask (rows*cols bytes, required when p_drop > 0) the keep mask.
+ * Dropout bits = hash(*rng_counter, call_id, element index): advance the device counter once per
+ * forward pass (sig3d_counter_increment) so that hipGraph replays draw fresh masks. */
+int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
+                             const unsigned *rng_counter, const float *x, const float *bias,
+                             const float *res, const float *gamma, const float *beta, float eps,
+                             float *out, float *v, float *mean, float *rstd, unsigned char *mask,
+                             void *stream);
+
+/* Backward of the above: dy (rows, cols) -> dx (gradient of x, feeds the dense layer's GEMMs),
+ * dres (gradient of the residual input) and dparams = [d gamma | d beta | d bias] (3*cols floats,
+ * zeroed here). */
+int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const float *dy, const float *v,
+                             const float *mean, const float *rstd, const float *gamma,
+                             const unsigned char *mask, float *dx, float *dres, float *dparams,
+                             void *stream);
+
+/* *counter += 1 (uint32) on the stream: the per-forward seed of the dropout hash. */
+int sig3d_counter_increment(unsigned *counter, void *stream);
+
 /* ---- optimizer step ---------------------------------------------------------------------- */
 
 /* clip_grad_value_ + AdamW.step() (+ the next zero_grad) of lib/solver.py:618-627 /

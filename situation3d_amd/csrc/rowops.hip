@@ -40,7 +40,173 @@ __global__ __launch_bounds__(CS_WAVES * 64) void column_sum_kernel(int rows, int
   }
 }
 
+// ---- bias + dropout + residual + LayerNorm (BertSelfOutput / BertOutput) ----------------------
+// Qformer.py:241-246 / 323-328:   h = dense(x); h = dropout(h); out = LayerNorm(h + input_tensor)
+// torch runs the tail as 3 kernels forward (dropout, add, layer_norm) and 5 backward (three
+// LayerNorm-backward kernels, dropout backward, the bias-gradient reduce); here the bias add moves
+// out of the GEMM epilogue so that the whole tail is ONE row kernel each way, and the backward also
+// yields d gamma, d beta and d bias as column sums (per-lane partials over the rows of a wave,
+// float atomics across waves).  One wave per row, cols <= 64*LN_MAX_PER_LANE.
+constexpr int LN_MAX_PER_LANE = 16;  // hidden sizes up to 1024
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
+    int rows, int cols, float p_drop, unsigned call_id, const unsigned *__restrict__ rng_counter,
+    const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ res,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+    float *__restrict__ out, float *__restrict__ v_out, float *__restrict__ mean_out,
+    float *__restrict__ rstd_out, unsigned char *__restrict__ mask_out) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned seed = mix32((rng_counter ? *rng_counter : 0u) * 0x9E3779B9u + call_id);
+  const unsigned thresh = (unsigned)((double)p_drop * 4294967296.0);
+  const float keep_scale = 1.f / (1.f - p_drop);
+  float v[LN_MAX_PER_LANE];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = 0.f;
+    if (c < cols) {
+      const size_t idx = (size_t)row * cols + c;
+      float u = x[idx] + (bias ? bias[c] : 0.f);
+      bool keep = true;
+      if (p_drop > 0.f) keep = mix32(seed ^ (unsigned)idx * 0x9E3779B9u) >= thresh;
+      u = keep ? u * keep_scale : 0.f;
+      if (mask_out) mask_out[idx] = keep ? 1 : 0;
+      v[i] = u + res[idx];
+      sum += v[i];
+    }
+  }
+  const float mean = wave_allreduce_sum_f32(sum) / cols;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+    if (lane + 64 * i < cols) sq += (v[i] - mean) * (v[i] - mean);
+  const float rstd = rsqrtf(wave_allreduce_sum_f32(sq) / cols + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) {
+      const size_t idx = (size_t)row * cols + c;
+      out[idx] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      v_out[idx] = v[i];
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+__global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
+    int rows, int cols, float p_drop, int rows_per_wave, const float *__restrict__ dy,
+    const float *__restrict__ v, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const unsigned char *__restrict__ mask, float *__restrict__ dx,
+    float *__restrict__ dres, float *__restrict__ dparams) {
+  // dparams = [d gamma | d beta | d bias], 3 * cols floats, zeroed by the launcher
+  float *dgamma = dparams, *dbeta = dparams + cols, *dbias = dparams + 2 * cols;
+  const int lane = lane_id();
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const float keep_scale = 1.f / (1.f - p_drop);
+  float ag[LN_MAX_PER_LANE], ab[LN_MAX_PER_LANE], abias[LN_MAX_PER_LANE], gam[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    ag[i] = ab[i] = abias[i] = 0.f;
+    gam[i] = (lane + 64 * i < cols) ? gamma[lane + 64 * i] : 0.f;
+  }
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int row = wave_global * rows_per_wave + rr;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float g[LN_MAX_PER_LANE], xh[LN_MAX_PER_LANE];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      g[i] = xh[i] = 0.f;
+      if (c < cols) {
+        const size_t idx = (size_t)row * cols + c;
+        const float d = dy[idx];
+        xh[i] = (v[idx] - mu) * rs;
+        g[i] = d * gam[i];
+        c1 += g[i];
+        c2 += g[i] * xh[i];
+        ag[i] += d * xh[i];
+        ab[i] += d;
+      }
+    }
+    c1 = wave_allreduce_sum_f32(c1) / cols;
+    c2 = wave_allreduce_sum_f32(c2) / cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < cols) {
+        const size_t idx = (size_t)row * cols + c;
+        const float dv = rs * (g[i] - c1 - xh[i] * c2);
+        dres[idx] = dv;
+        const float du = (p_drop > 0.f) ? (mask[idx] ? dv * keep_scale : 0.f) : dv;
+        dx[idx] = du;
+        abias[i] += du;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < cols) {
+      unsafeAtomicAdd(dgamma + c, ag[i]);
+      unsafeAtomicAdd(dbeta + c, ab[i]);
+      unsafeAtomicAdd(dbias + c, abias[i]);
+    }
+  }
+}
+
+__global__ void counter_increment_kernel(unsigned *counter) { *counter += 1u; }
+
 }  // namespace
+
+extern "C" int sig3d_counter_increment(unsigned *counter, void *stream_) {
+  hipLaunchKernelGGL(counter_increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, counter);
+  SIG3D_LAUNCH_CHECK("counter_increment_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
+                                        const unsigned *rng_counter, const float *x,
+                                        const float *bias, const float *res, const float *gamma,
+                                        const float *beta, float eps, float *out, float *v,
+                                        float *mean, float *rstd, unsigned char *mask,
+                                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
+  SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
+  SIG3D_REQUIRE(p_drop == 0.f || mask != nullptr, "a mask buffer is required when p_drop > 0");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(dropout_add_ln_fwd_kernel, dim3(sig3d_ceil_div(rows, 4)), dim3(256), 0, stream, rows,
+                     cols, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean,
+                     rstd, mask);
+  SIG3D_LAUNCH_CHECK("dropout_add_ln_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const float *dy,
+                                        const float *v, const float *mean, const float *rstd,
+                                        const float *gamma, const unsigned char *mask, float *dx,
+                                        float *dres, float *dparams, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
+  SIG3D_HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * 3 * cols, stream));
+  if (rows == 0) return 0;
+  const int rpw = rows >= 2048 ? 8 : (rows >= 256 ? 2 : 1);
+  const int waves = sig3d_ceil_div(rows, rpw);
+  hipLaunchKernelGGL(dropout_add_ln_bwd_kernel, dim3(sig3d_ceil_div(waves, 4)), dim3(256), 0, stream, rows,
+                     cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, dparams);
+  SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
+  return 0;
+}
 
 extern "C" int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -292,6 +292,35 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_kernel(
   }
 }
 
+// Max-pool gradient statistics: only the arg-max sample of each group carries gradient, so S1/S2
+// need one gathered y per group (b*c*p values) instead of a pass over the whole (b,c,p,s) tensor.
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_stats_kernel(
+    int c, int P, int S, const float *__restrict__ dOut, const int *__restrict__ arg,
+    const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, double *__restrict__ s1,
+    double *__restrict__ s2) {
+  __shared__ float red[2][BNB_THREADS / 64];
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t grow = ((size_t)bi * c + ch) * P;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  float a1 = 0.f, a2 = 0.f;
+  for (int j = blockIdx.x * BNB_THREADS + threadIdx.x; j < P; j += gridDim.x * BNB_THREADS) {
+    const float yv = y[(grow + j) * S + arg[grow + j]];
+    const float dz = (yv * sc + sh > 0.f) ? dOut[grow + j] : 0.f;
+    a1 += dz;
+    a2 += dz * ((yv - mu) * is);
+  }
+  a1 = wave_allreduce_sum_f32(a1);
+  a2 = wave_allreduce_sum_f32(a2);
+  if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < BNB_THREADS / 64; ++w) t += (double)red[threadIdx.x][w];
+    unsafeAtomicAdd((threadIdx.x ? s2 : s1) + ch, t);
+  }
+}
+
 template <bool TOP>
 __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
     int c, long E, int S, double count, const float *__restrict__ dA, const float *__restrict__ dOut,
@@ -548,8 +577,10 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
     hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
                        count, dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2, dY);
   } else {
-    hipLaunchKernelGGL((bn_relu_bwd_stats_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
-                       dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2);
+    const int P = (int)(e / s);
+    dim3 tgrid(P >= 4 * BNB_THREADS ? 4 : 1, c, b);
+    hipLaunchKernelGGL(bn_relu_bwd_top_stats_kernel, tgrid, dim3(BNB_THREADS), 0, stream, c, P, s, dOut,
+                       arg, y, scale, shift, mean, invstd, s1, s2);
     hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
                        count, dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2, dY);
   }

@@ -93,6 +93,78 @@ def linear(layer, x):
     return layer(x)
 
 
+_rng_counters = {}   # device -> uint32 scalar advanced once per training forward (dropout seed)
+_call_ids = iter(range(1, 1 << 30))
+
+
+def _rng_counter(device):
+    key = (device.type, device.index)
+    if key not in _rng_counters:
+        _rng_counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _rng_counters[key]
+
+
+def advance_dropout_seed(device):
+    """One captured-safe kernel per forward pass: fresh dropout masks on every (graph) replay."""
+    c = _rng_counter(device)
+    with torch.cuda.device(device):
+        _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
+
+
+class _DropoutAddLayerNormFn(torch.autograd.Function):
+    """out = LayerNorm(dropout(x + bias) + residual): the tail of BertSelfOutput / BertOutput
+    (Qformer.py:241-246, 323-328) as one kernel each way (csrc/rowops.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, gamma, beta, p_drop, eps, call_id):
+        dev = x.device
+        cols = x.shape[-1]
+        x2 = x.reshape(-1, cols).contiguous()
+        r2 = residual.reshape(-1, cols).contiguous()
+        rows = x2.shape[0]
+        out = torch.empty_like(x2)
+        v = torch.empty_like(x2)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
+        mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev) if p_drop > 0 else None
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, ctypes.c_float(p_drop),
+                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
+                      _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
+                      _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(v, stats, gamma, mask)
+        ctx.p_drop = p_drop
+        ctx.shape = x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, stats, gamma, mask = ctx.saved_tensors
+        rows, cols = v.shape
+        dy2 = dy.reshape(rows, cols).contiguous()
+        dx = torch.empty_like(v)
+        dres = torch.empty_like(v)
+        dparams = torch.empty((3, cols), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, ctypes.c_float(ctx.p_drop), _lib.ptr(dy2),
+                      _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
+                      _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams),
+                      _lib.stream_ptr(v.device))
+        return (dx.view(ctx.shape), dparams[2], dres.view(ctx.shape), dparams[0], dparams[1], None,
+                None, None)
+
+
+def dense_dropout_add_layer_norm(dense, dropout, layer_norm, hidden_states, input_tensor, call_id):
+    """LayerNorm(dropout(dense(hidden_states)) + input_tensor) -- GEMM (library) + one fused kernel."""
+    if not (hidden_states.is_cuda and hidden_states.dtype == torch.float32
+            and hidden_states.shape[-1] <= 4096 and layer_norm.weight.shape[0] <= 1024):
+        return layer_norm(dropout(dense(hidden_states)) + input_tensor)
+    x = _LinearFn.apply(hidden_states, dense.weight, None)  # bias is added inside the fused tail
+    p = dropout.p if dropout.training else 0.0
+    return _DropoutAddLayerNormFn.apply(x, dense.bias, input_tensor, layer_norm.weight, layer_norm.bias,
+                                        float(p), float(layer_norm.eps), call_id)
+
+
 class _AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale + mask) v on token-major (B, N, H*64) operands."""
 
@@ -236,9 +308,11 @@ class BertSelfOutput(nn.Module):
         self.dense = nn.Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self._call_id = next(_call_ids)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(linear(self.dense, hidden_states)) + input_tensor)
+        return dense_dropout_add_layer_norm(self.dense, self.dropout, self.LayerNorm, hidden_states,
+                                            input_tensor, self._call_id)
 
 
 class BertAttention(nn.Module):
@@ -279,9 +353,11 @@ class BertOutput(nn.Module):
         self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
+        self._call_id = next(_call_ids)
 
     def forward(self, hidden_states, input_tensor):
-        return self.LayerNorm(self.dropout(linear(self.dense, hidden_states)) + input_tensor)
+        return dense_dropout_add_layer_norm(self.dense, self.dropout, self.LayerNorm, hidden_states,
+                                            input_tensor, self._call_id)
 
 
 class BertLayer(nn.Module):
@@ -311,7 +387,14 @@ class BertLayer(nn.Module):
         attention_output = self_attention_outputs[0]
         present_key_value = self_attention_outputs[-1]
         if query_length > 0:
-            query_attention_output = attention_output[:, :query_length, :]
+            # one split instead of two slices (Qformer.py:375,396): same values, but its backward
+            # is a single cat instead of zero-fill + copy + accumulate per slice
+            n_text = attention_output.shape[1] - query_length
+            if n_text > 0:
+                query_attention_output, text_attention_output = torch.split(
+                    attention_output, [query_length, n_text], dim=1)
+            else:
+                query_attention_output = attention_output
             if self.has_cross_attention:
                 assert encoder_hidden_states is not None, \
                     "encoder_hidden_states must be given for cross-attention layers"
@@ -319,8 +402,8 @@ class BertLayer(nn.Module):
                     query_attention_output, attention_mask, head_mask, encoder_hidden_states,
                     encoder_attention_mask)[0]
             layer_output = self.feed_forward_chunk_query(query_attention_output)
-            if attention_output.shape[1] > query_length:
-                layer_output_text = self.feed_forward_chunk(attention_output[:, query_length:, :])
+            if n_text > 0:
+                layer_output_text = self.feed_forward_chunk(text_attention_output)
                 layer_output = torch.cat([layer_output, layer_output_text], dim=1)
         else:
             layer_output = self.feed_forward_chunk(attention_output)
@@ -398,6 +481,9 @@ class BertModel(nn.Module):
             assert query_embeds is not None, \
                 "You have to specify query_embeds when input_ids is None"
         query_length = query_embeds.shape[1] if query_embeds is not None else 0
+        ref = query_embeds if query_embeds is not None else encoder_hidden_states
+        if self.training and ref is not None and ref.is_cuda:
+            advance_dropout_seed(ref.device)  # fused dropout kernels hash (this counter, call id, index)
         embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
                                            query_embeds=query_embeds)
         batch_size, seq_length = embedding_output.shape[:2]

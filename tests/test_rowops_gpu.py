@@ -1,0 +1,87 @@
+"""Row kernels of the Q-Former dense blocks (csrc/rowops.hip): column_sum (bias gradient) and the
+fused bias + dropout + residual + LayerNorm tail of BertSelfOutput / BertOutput
+(Qformer.py:241-246, 323-328), forward and backward, against torch."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_column_sum():
+    from situation3d_amd import _lib as L
+    for rows, cols in [(416, 768), (1, 5), (1000, 3072), (37, 130)]:
+        x = torch.randn(rows, cols, device=DEV)
+        out = torch.empty(cols, device=DEV)
+        L.call("sig3d_column_sum", rows, cols, L.ptr(x), L.ptr(out), L.stream_ptr())
+        torch.testing.assert_close(out, x.sum(0), rtol=1e-5, atol=1e-4)
+
+
+def _fused(x, bias, res, gamma, beta, p, call_id=7):
+    from situation3d_amd.qformer import _DropoutAddLayerNormFn
+    return _DropoutAddLayerNormFn.apply(x, bias, res, gamma, beta, p, 1e-12, call_id)
+
+
+@pytest.mark.parametrize("shape", [(8, 52, 768), (3, 5, 128), (2, 7, 1000)])
+def test_dropout_add_layer_norm_p0_matches_torch(shape):
+    g = torch.Generator().manual_seed(shape[-1])
+    c = shape[-1]
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x, res, bias, gamma, beta, dy = mk(*shape), mk(*shape), mk(c), mk(c) + 1.0, mk(c), mk(*shape)
+    args = [t.clone().requires_grad_(True) for t in (x, bias, res, gamma, beta)]
+    out = _fused(*args, 0.0)
+    out.backward(dy)
+    refs = [t.clone().requires_grad_(True) for t in (x, bias, res, gamma, beta)]
+    exp = F.layer_norm(refs[0] + refs[1] + refs[2], (c,), refs[3], refs[4], 1e-12)
+    exp.backward(dy)
+    torch.testing.assert_close(out, exp, rtol=1e-4, atol=1e-4)
+    for a, r, name in zip(args, refs, ("x", "bias", "residual", "gamma", "beta")):
+        scale = max(1.0, r.grad.abs().max().item())
+        torch.testing.assert_close(a.grad, r.grad, rtol=1e-3, atol=1e-4 * scale, msg=lambda m: name + ": " + m)
+
+
+def test_dropout_add_layer_norm_with_dropout():
+    """p > 0: the mask is a pure function of (device counter, call id, element index); recover it
+    and check values + gradients against torch with that same mask; check the drop rate."""
+    p, c = 0.1, 768
+    g = torch.Generator().manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    shape = (8, 52, c)
+    ones, zeros = torch.ones(shape, device=DEV), torch.zeros(shape, device=DEV)
+    probe = _fused(ones, torch.zeros(c, device=DEV), zeros, torch.ones(c, device=DEV),
+                   torch.zeros(c, device=DEV), p)
+    # recover the keep mask: rows are LayerNorm-ed, kept entries are the larger of two values per row
+    keep = probe > probe.mean(-1, keepdim=True)
+    rate = 1.0 - keep.float().mean().item()
+    n = keep.numel()
+    assert abs(rate - p) < 4 * (p * (1 - p) / n) ** 0.5, rate
+    other = _fused(ones, torch.zeros(c, device=DEV), zeros, torch.ones(c, device=DEV),
+                   torch.zeros(c, device=DEV), p, call_id=8)
+    assert (keep != (other > other.mean(-1, keepdim=True))).float().mean() > 0.05  # per-call streams
+
+    x, res, bias, gamma, beta, dy = mk(*shape), mk(*shape), mk(c), mk(c) + 1.0, mk(c), mk(*shape)
+    args = [t.clone().requires_grad_(True) for t in (x, bias, res, gamma, beta)]
+    out = _fused(*args, p)
+    out.backward(dy)
+    refs = [t.clone().requires_grad_(True) for t in (x, bias, res, gamma, beta)]
+    dropped = (refs[0] + refs[1]) * keep.float() / (1 - p)
+    exp = F.layer_norm(dropped + refs[2], (c,), refs[3], refs[4], 1e-12)
+    exp.backward(dy)
+    torch.testing.assert_close(out, exp, rtol=1e-4, atol=1e-4)
+    for a, r, name in zip(args, refs, ("x", "bias", "residual", "gamma", "beta")):
+        scale = max(1.0, r.grad.abs().max().item())
+        torch.testing.assert_close(a.grad, r.grad, rtol=1e-3, atol=1e-4 * scale, msg=lambda m: name + ": " + m)
+
+
+def test_dropout_seed_advances_per_forward():
+    from situation3d_amd.qformer import advance_dropout_seed
+    c = 256
+    ones = torch.ones(4, 10, c, device=DEV)
+    args = (ones, torch.zeros(c, device=DEV), torch.zeros_like(ones), torch.ones(c, device=DEV),
+            torch.zeros(c, device=DEV), 0.3)
+    a = _fused(*args)
+    b = _fused(*args)
+    assert torch.equal(a, b)  # same counter, same call id: same mask
+    advance_dropout_seed(ones.device)
+    assert not torch.equal(a, _fused(*args))
