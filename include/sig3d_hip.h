@@ -243,14 +243,20 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL). */
 int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
                         const float *k, const float *v, const float *mask, float *out,
-                        float *lse, void *stream);
+                        float *lse, float p_drop, unsigned call_id, const unsigned *rng_counter,
+                        void *stream);
+/* p_drop > 0: attention-probability dropout (Qformer.py:219).  The keep bit of element
+ * (b, head, query, key) is hash(*rng_counter, call_id, index), identical in forward and backward;
+ * advance the device counter once per forward pass (sig3d_counter_increment).  p_drop == 0 is the
+ * eval-mode / deterministic path (rng_counter may be NULL). */
 
 /* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
  * -> dq (b,nq,h*d), dk (b,nk,h*d), dv (b,nk,h*d), token-major like the inputs. */
 int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
                         const float *k, const float *v, const float *mask,
                         const float *out, const float *lse, const float *grad_out,
-                        float *dq, float *dk, float *dv, void *stream);
+                        float *dq, float *dk, float *dv, float p_drop, unsigned call_id,
+                        const unsigned *rng_counter, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,12 +50,46 @@ __device__ __forceinline__ void load_half_row(float (&f)[32], const float *base,
   }
 }
 
+// Attention-probability dropout (Qformer.py:219, nn.Dropout on the softmax output): the keep bit
+// of element (b, head, query, key) is a pure hash of (device counter, call id, that index), so the
+// forward and backward kernels regenerate identical masks in their different tile layouts and
+// nothing (B,H,Nq,Nk)-shaped is ever stored.  Dropout acts on the NORMALISED probabilities:
+// O = sum_k keep_k p_k V_k / ((1-p) l) with l = sum_k p_k over ALL keys, i.e. only the PV numerator
+// is masked; in the backward pass dP is masked the same way and D = rowsum(dO*O) is unchanged.
+struct AttnDropout {
+  unsigned seed;
+  unsigned thresh;   // keep iff hash >= thresh
+  float inv_keep;    // 1 / (1 - p)
+  int on;
+};
+
+__device__ __forceinline__ unsigned at_mix(unsigned x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+__device__ __forceinline__ AttnDropout make_dropout(float p_drop, unsigned call_id,
+                                                    const unsigned *rng_counter) {
+  AttnDropout d;
+  d.on = p_drop > 0.f;
+  d.seed = at_mix((rng_counter ? *rng_counter : 0u) * 0x9E3779B9u + call_id);
+  d.thresh = (unsigned)((double)p_drop * 4294967296.0);
+  d.inv_keep = 1.f / (1.f - p_drop);
+  return d;
+}
+
+__device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base, int key) {
+  // row_base = ((b*h + head)*nq + query) * nk  (wraps mod 2^32 for huge shapes: still a fixed map)
+  return at_mix(d.seed + (row_base + (unsigned)key) * 0x9E3779B9u) >= d.thresh;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
-    int h, int nq, int nk, float scale, const float *__restrict__ q, const float *__restrict__ k,
-    const float *__restrict__ v, const float *__restrict__ mask, float *__restrict__ out,
-    float *__restrict__ lse) {
+    int h, int nq, int nk, float scale, float p_drop, unsigned call_id,
+    const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
+    const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
+    float *__restrict__ out, float *__restrict__ lse) {
   __shared__ float s_o[AT_WAVES][AT_D][32];
   __shared__ float s_m[AT_WAVES][32];
   __shared__ float s_l[AT_WAVES][32];
@@ -72,6 +106,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 
   float qf[32];
   load_half_row(qf, Q, q0 + l31, hs, half, q0 + l31 < nq);
+  const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
+  const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o0 = {0}, o1 = {0};
@@ -101,7 +137,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       p[r] = __expf(p[r] - m_new);
-      rs += p[r];
+      rs += p[r];  // the normaliser sees every key
+      if (drop.on)  // ... the PV numerator only the kept ones
+        p[r] = at_keep(drop, row_base, key0 + mfma_row(r, half)) ? p[r] * drop.inv_keep : 0.f;
     }
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
@@ -166,7 +204,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 // backward: grid (key_splits, h, b), 256 threads.  A wave owns whole 32-key tiles, so dK / dV
 // are plain stores; dQ is reduced in LDS per workgroup (and with atomics across key splits).
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
-    int h, int nq, int nk, float scale, int tiles_per_split, int atomic_dq,
+    int h, int nq, int nk, float scale, int tiles_per_split, int atomic_dq, float p_drop,
+    unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
     const float *__restrict__ grad_out, float *__restrict__ dq, float *__restrict__ dk,
@@ -211,6 +250,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   }
   __syncthreads();
 
+  const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const int ntiles = (nk + 31) / 32;
   const int t_begin = blockIdx.x * tiles_per_split;
   const int t_end = min(ntiles, t_begin + tiles_per_split);
@@ -248,7 +288,16 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qq = q0 + mfma_row(r, half);
-        ds[r] = p[r] * (dpacc[r] - s_D[min(qq, AT_NQ_MAX - 1)]);
+        float dp = dpacc[r];
+        if (drop.on) {  // same keep bit as the forward pass: element (b, head, qq, key0 + l31)
+          const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)nk;
+          const bool keep = at_keep(drop, row_base, key0 + l31);
+          dp = keep ? dp * drop.inv_keep : 0.f;          // d(P_dropped)/dP
+          ds[r] = p[r] * (dp - s_D[min(qq, AT_NQ_MAX - 1)]);
+          p[r] = keep ? p[r] * drop.inv_keep : 0.f;      // dV uses the dropped probabilities
+        } else {
+          ds[r] = p[r] * (dp - s_D[min(qq, AT_NQ_MAX - 1)]);
+        }
       }
       // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
@@ -312,15 +361,17 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
 extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale,
                                    const float *q, const float *k, const float *v,
-                                   const float *mask, float *out, float *lse, void *stream_) {
+                                   const float *mask, float *out, float *lse, float p_drop,
+                                   unsigned call_id, const unsigned *rng_counter, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
   dim3 grid((nq + 31) / 32, h, b);
   hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
-                     q, k, v, mask, out, lse);
+                     p_drop, call_id, rng_counter, q, k, v, mask, out, lse);
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
@@ -329,8 +380,10 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float sc
                                    const float *q, const float *k, const float *v,
                                    const float *mask, const float *out, const float *lse,
                                    const float *grad_out, float *dq, float *dk, float *dv,
+                                   float p_drop, unsigned call_id, const unsigned *rng_counter,
                                    void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
   SIG3D_REQUIRE(nq <= AT_NQ_MAX, "attention backward supports at most 128 query rows");
@@ -352,8 +405,8 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float sc
     SIG3D_HIP_TRY(hipMemsetAsync(dq, 0, sizeof(float) * (size_t)b * h * nq * AT_D, stream));
   dim3 grid(splits, h, b);
   hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
-                     tiles_per_split, splits > 1 ? 1 : 0, q, k, v, mask, out, lse, grad_out, dq, dk,
-                     dv);
+                     tiles_per_split, splits > 1 ? 1 : 0, p_drop, call_id, rng_counter, q, k, v, mask,
+                     out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
   return 0;
 }

@@ -16,9 +16,12 @@ Module tree and parameter names equal the reference's, so a reference checkpoint
 
 softmax(QK^T/sqrt(d) + mask)V runs in sig3d_attention_fwd/bwd (exact-f32 MFMA, scores never
 materialised); the dense layers are plain library GEMMs (torch / hipBLASLt); LayerNorm, GELU and
-hidden-state dropout stay torch ops.  Attention-probability dropout (Qformer.py:219) is applied
-by the reference on the materialised probabilities; the fused kernel does not implement it, so
-`attention_probs_dropout_prob` must be 0 while training through this module (enforced).
+the bias + hidden-state dropout + residual + LayerNorm tails are one fused row kernel each way
+(csrc/rowops.hip).  Attention-probability dropout (Qformer.py:219) is applied INSIDE the attention
+kernels: the keep bit of element (b, head, query, key) is a hash of a device counter (advanced
+once per training forward), a per-module call id and the element index, so forward and backward
+regenerate the same mask and no (B,H,Nq,Nk) tensor is ever stored.  The random stream differs from
+torch's Philox (same distribution, different bits); eval mode is deterministic.
 """
 import ctypes
 import math
@@ -42,7 +45,7 @@ class QFormerConfig:
         self.intermediate_size = 3072
         self.hidden_act = "gelu"
         self.hidden_dropout_prob = 0.1
-        self.attention_probs_dropout_prob = 0.0
+        self.attention_probs_dropout_prob = 0.1
         self.max_position_embeddings = 512
         self.initializer_range = 0.02
         self.layer_norm_eps = 1e-12
@@ -169,7 +172,7 @@ class _AttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale + mask) v on token-major (B, N, H*64) operands."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, num_heads, scale):
+    def forward(ctx, q, k, v, mask, num_heads, scale, p_drop=0.0, call_id=0):
         dev = _lib.require_device(q, k, v, mask)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         b, nq, hd = q.shape
@@ -182,15 +185,16 @@ class _AttentionFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
-                      _lib.ptr(lse), _lib.stream_ptr(dev))
+                      _lib.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
+                      _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
         ctx.save_for_backward(q, k, v, mask, out, lse)
-        ctx.cfg = (num_heads, scale)
+        ctx.cfg = (num_heads, scale, p_drop, call_id)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         q, k, v, mask, out, lse = ctx.saved_tensors
-        num_heads, scale = ctx.cfg
+        num_heads, scale, p_drop, call_id = ctx.cfg
         b, nq, hd = q.shape
         nk = k.shape[1]
         grad_out = grad_out.contiguous()
@@ -199,14 +203,18 @@ class _AttentionFn(torch.autograd.Function):
             _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads,
                       ctypes.c_float(scale), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask),
                       _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), _lib.ptr(dq), _lib.ptr(dk),
-                      _lib.ptr(dv), _lib.stream_ptr(q.device))
-        return dq, dk, dv, None, None, None
+                      _lib.ptr(dv), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
+                      _lib.ptr(_rng_counter(q.device)), _lib.stream_ptr(q.device))
+        return dq, dk, dv, None, None, None, None, None
 
 
-def fused_attention(q, k, v, additive_mask, num_heads):
-    """q (B,Nq,H*64), k/v (B,Nk,H*64), additive_mask (B,Nk) or None -> (B,Nq,H*64)."""
+def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
+    """q (B,Nq,H*64), k/v (B,Nk,H*64), additive_mask (B,Nk) or None -> (B,Nq,H*64).
+    p_drop > 0: dropout on the attention probabilities (Qformer.py:219), mask = hash of the device
+    dropout counter (advance_dropout_seed), `call_id` and the element index."""
     d = q.shape[-1] // num_heads
-    return _AttentionFn.apply(q, k, v, additive_mask, num_heads, 1.0 / math.sqrt(d))
+    return _AttentionFn.apply(q, k, v, additive_mask, num_heads, 1.0 / math.sqrt(d), float(p_drop),
+                              int(call_id))
 
 
 def _key_mask(mask, batch, nk):
@@ -272,6 +280,7 @@ class BertSelfAttention(nn.Module):
         self.key = nn.Linear(kv_in, self.all_head_size)
         self.value = nn.Linear(kv_in, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
+        self._call_id = next(_call_ids)
         if getattr(config, "position_embedding_type", "absolute") != "absolute":
             raise NotImplementedError("relative position embeddings (Qformer.py:189-205) are not "
                                       "used by BLIP-2 and are not on the hot path")
@@ -286,8 +295,6 @@ class BertSelfAttention(nn.Module):
         if head_mask is not None or past_key_value is not None or output_attentions:
             raise NotImplementedError("head_mask / past_key_value / output_attentions need the "
                                       "materialised probabilities; not on the hot path")
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention_probs_dropout_prob must be 0 for the fused kernel")
         is_cross_attention = encoder_hidden_states is not None
         kv_src = encoder_hidden_states if is_cross_attention else hidden_states
         if is_cross_attention:
@@ -296,7 +303,9 @@ class BertSelfAttention(nn.Module):
         value = linear(self.value, kv_src)
         query = linear(self.query, hidden_states)
         mask = _key_mask(attention_mask, query.shape[0], key.shape[1])
-        context_layer = fused_attention(query, key, value, mask, self.num_attention_heads)
+        p_drop = self.dropout.p if self.training else 0.0
+        context_layer = fused_attention(query, key, value, mask, self.num_attention_heads, p_drop,
+                                        self._call_id)
         return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
 
 
