@@ -240,8 +240,12 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  * permute (:140-147) is folded into the kernel's addressing; mask additive (b,nk) or NULL
  * (the reference's (B,1,1,Nk) extended mask, Qformer.py:700-732); d must be 64.
  * out (b,nq,h*d) -- already in the permuted "context_layer" layout of Qformer.py:225-227.
- * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL). */
-int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
+ * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL).
+ * ldq / ldk / ldv: row strides in floats of q, k, v (h*d for dense tensors; 3*h*d when q, k, v are
+ * column slices of ONE fused QKV projection output, which saves two GEMM launches per attention).
+ * In the backward pass dq / dk / dv use the same strides as their inputs. */
+int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
+                        float scale, const float *q,
                         const float *k, const float *v, const float *mask, float *out,
                         float *lse, float p_drop, unsigned call_id, const unsigned *rng_counter,
                         void *stream);
@@ -252,7 +256,8 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale, const 
 
 /* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
  * -> dq (b,nq,h*d), dk (b,nk,h*d), dv (b,nk,h*d), token-major like the inputs. */
-int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale, const float *q,
+int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
+                        float scale, const float *q,
                         const float *k, const float *v, const float *mask,
                         const float *out, const float *lse, const float *grad_out,
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,

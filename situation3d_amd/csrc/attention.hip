@@ -86,7 +86,7 @@ __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base,
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
-    int h, int nq, int nk, float scale, float p_drop, unsigned call_id,
+    int h, int nq, int nk, int ldq, int ldk, int ldv, float scale, float p_drop, unsigned call_id,
     const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
     const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
     float *__restrict__ out, float *__restrict__ lse) {
@@ -97,15 +97,16 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
-  // token-major operands (b, n, h*d): row r of head hi starts at base + r*hs + hi*64
-  const long hs = (long)h * AT_D;
-  const float *Q = q + (size_t)bi * nq * hs + hi * AT_D;
-  const float *K = k + (size_t)bi * nk * hs + hi * AT_D;
-  const float *V = v + (size_t)bi * nk * hs + hi * AT_D;
+  // token-major operands: row r of head hi starts at base + r*ld + hi*64, where ld is the row
+  // stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
+  // projection output)
+  const float *Q = q + (size_t)bi * nq * ldq + hi * AT_D;
+  const float *K = k + (size_t)bi * nk * ldk + hi * AT_D;
+  const float *V = v + (size_t)bi * nk * ldv + hi * AT_D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
 
   float qf[32];
-  load_half_row(qf, Q, q0 + l31, hs, half, q0 + l31 < nq);
+  load_half_row(qf, Q, q0 + l31, ldq, half, q0 + l31 < nq);
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   for (int t = wave; t < ntiles; t += AT_WAVES) {
     const int key0 = t * 32;
     float kf[32];
-    load_half_row(kf, K, min(key0 + l31, nk - 1), hs, half, true);
+    load_half_row(kf, K, min(key0 + l31, nk - 1), ldk, half, true);
     f32x16 st = {0};
 #pragma unroll
     for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
       const int key = min(key0 + mfma_row(s, half), nk - 1);
-      const float a0 = V[(size_t)key * hs + l31];
-      const float a1 = V[(size_t)key * hs + 32 + l31];
+      const float a0 = V[(size_t)key * ldv + l31];
+      const float a1 = V[(size_t)key * ldv + 32 + l31];
       o0 = mfma32(a0, p[s], o0);
       o1 = mfma32(a1, p[s], o1);
     }
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 // backward: grid (key_splits, h, b), 256 threads.  A wave owns whole 32-key tiles, so dK / dV
 // are plain stores; dQ is reduced in LDS per workgroup (and with atomics across key splits).
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
-    int h, int nq, int nk, float scale, int tiles_per_split, int atomic_dq, float p_drop,
+    int h, int nq, int nk, int ldq, int ldk, int ldv, float scale, int tiles_per_split,
+    int atomic_dq, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
@@ -219,11 +221,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int hi = blockIdx.y, bi = blockIdx.z;
   const size_t bh = (size_t)(bi * h + hi);
-  const size_t ostride = (size_t)h * AT_D;
-  const long hs = (long)ostride;
-  const float *Q = q + (size_t)bi * nq * ostride + hi * AT_D;
-  const float *K = k + (size_t)bi * nk * ostride + hi * AT_D;
-  const float *V = v + (size_t)bi * nk * ostride + hi * AT_D;
+  const size_t ostride = (size_t)h * AT_D;  // out / grad_out are dense (b, nq, h*d)
+  const float *Q = q + (size_t)bi * nq * ldq + hi * AT_D;
+  const float *K = k + (size_t)bi * nk * ldk + hi * AT_D;
+  const float *V = v + (size_t)bi * nk * ldv + hi * AT_D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
   const float *O = out + (size_t)bi * nq * ostride + hi * AT_D;        // row q at O + q*ostride
   const float *dO = grad_out + (size_t)bi * nq * ostride + hi * AT_D;
@@ -261,15 +262,15 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     const int krow = min(key0 + l31, nk - 1);
     const bool key_ok = key0 + l31 < nk;
     float kf[32], vf[32];
-    load_half_row(kf, K, krow, hs, half, true);
-    load_half_row(vf, V, krow, hs, half, true);
+    load_half_row(kf, K, krow, ldk, half, true);
+    load_half_row(vf, V, krow, ldv, half, true);
     const float mk = M ? M[krow] : 0.f;
     f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
 
     for (int qt = 0; qt < nqt; ++qt) {
       const int q0 = qt * 32;
       float fr[32];
-      load_half_row(fr, Q, q0 + l31, hs, half, q0 + l31 < nq);
+      load_half_row(fr, Q, q0 + l31, ldq, half, q0 + l31 < nq);
       f32x16 sacc = {0};
 #pragma unroll
       for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       for (int s = 0; s < 16; ++s) {
         const int qq = min(q0 + mfma_row(s, half), nq - 1);
         const float g0 = dO[(size_t)qq * ostride + l31], g1 = dO[(size_t)qq * ostride + 32 + l31];
-        const float x0 = Q[(size_t)qq * hs + l31], x1 = Q[(size_t)qq * hs + 32 + l31];
+        const float x0 = Q[(size_t)qq * ldq + l31], x1 = Q[(size_t)qq * ldq + 32 + l31];
         dvt0 = mfma32(g0, p[s], dvt0);
         dvt1 = mfma32(g1, p[s], dvt1);
         dkt0 = mfma32(x0, ds[s], dkt0);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         const int kk = mfma_row(s, half);
         const int key = min(key0 + kk, nk - 1);
         const float bq = s_T[wave][kk][l31];
-        dqt0 = mfma32(K[(size_t)key * hs + l31], bq, dqt0);
-        dqt1 = mfma32(K[(size_t)key * hs + 32 + l31], bq, dqt1);
+        dqt0 = mfma32(K[(size_t)key * ldk + l31], bq, dqt0);
+        dqt1 = mfma32(K[(size_t)key * ldk + 32 + l31], bq, dqt1);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       }
     }
     if (key_ok) {
-      float *dvp = dv + ((size_t)bi * nk + key0 + l31) * ostride + hi * AT_D;
-      float *dkp = dk + ((size_t)bi * nk + key0 + l31) * ostride + hi * AT_D;
+      float *dvp = dv + ((size_t)bi * nk + key0 + l31) * ldv + hi * AT_D;  // grads mirror the inputs
+      float *dkp = dk + ((size_t)bi * nk + key0 + l31) * ldk + hi * AT_D;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
         const int d = 8 * g + 4 * half;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
     const int qq = i / AT_D, d = i % AT_D;
     const float val = s_dq[qq][d] * scale;
-    float *dst = dq + ((size_t)bi * nq + qq) * ostride + hi * AT_D + d;
+    float *dst = dq + ((size_t)bi * nq + qq) * ldq + hi * AT_D + d;
     if (atomic_dq) unsafeAtomicAdd(dst, val);
     else *dst = val;
   }
@@ -359,25 +360,28 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
 }  // namespace
 
-extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, float scale,
-                                   const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
+                                   float scale, const float *q, const float *k, const float *v,
                                    const float *mask, float *out, float *lse, float p_drop,
                                    unsigned call_id, const unsigned *rng_counter, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
+  SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
+                "row strides must be >= h*d and multiples of 4 floats");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
   dim3 grid((nq + 31) / 32, h, b);
-  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, ldq, ldk,
+                     ldv, scale,
                      p_drop, call_id, rng_counter, q, k, v, mask, out, lse);
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
 
-extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float scale,
-                                   const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
+                                   float scale, const float *q, const float *k, const float *v,
                                    const float *mask, const float *out, const float *lse,
                                    const float *grad_out, float *dq, float *dk, float *dv,
                                    float p_drop, unsigned call_id, const unsigned *rng_counter,
@@ -401,10 +405,13 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, float sc
   }
   const int tiles_per_split = (ntiles + splits - 1) / splits;
   splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
-  if (splits > 1)
-    SIG3D_HIP_TRY(hipMemsetAsync(dq, 0, sizeof(float) * (size_t)b * h * nq * AT_D, stream));
+  SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
+                "row strides must be >= h*d and multiples of 4 floats");
+  if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
+    SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D, (size_t)b * nq, stream));
   dim3 grid(splits, h, b);
-  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, scale,
+  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, ldq, ldk,
+                     ldv, scale,
                      tiles_per_split, splits > 1 ? 1 : 0, p_drop, call_id, rng_counter, q, k, v, mask,
                      out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");

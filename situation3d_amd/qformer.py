@@ -183,7 +183,7 @@ class _AttentionFn(torch.autograd.Function):
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, ctypes.c_float(scale),
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, hd, hd, hd, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
                       _lib.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
@@ -200,12 +200,114 @@ class _AttentionFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         with torch.cuda.device(q.device):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads,
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads, hd, hd, hd,
                       ctypes.c_float(scale), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask),
                       _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), _lib.ptr(dq), _lib.ptr(dk),
                       _lib.ptr(dv), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(q.device)), _lib.stream_ptr(q.device))
         return dq, dk, dv, None, None, None, None, None
+
+
+def _off(t, floats):
+    return ctypes.c_void_p(t.data_ptr() + 4 * floats)
+
+
+class _ProjAttentionFn(torch.autograd.Function):
+    """query/key/value projections + attention core of BertSelfAttention.forward
+    (Qformer.py:150-232) with the projections FUSED into one library GEMM per source tensor:
+      self-attention : [Q|K|V] = hidden @ [Wq;Wk;Wv]^T           (one GEMM instead of three)
+      cross-attention: Q = hidden @ Wq^T,  [K|V] = enc @ [Wk;Wv]^T (two instead of three)
+    The attention kernels read Q, K, V as column slices of those outputs (row stride 3*H*64 /
+    2*H*64) and write dQ, dK, dV into the matching slices of ONE gradient buffer, so the backward
+    is again one dX GEMM, one dW GEMM and one column-sum per source -- no cat / split / accumulate
+    kernels.  Parameters stay separate tensors (state_dict keys unchanged)."""
+
+    @staticmethod
+    def forward(ctx, hidden, kv_src, wq, bq, wk, bk, wv, bv, mask, num_heads, p_drop, call_id):
+        dev = hidden.device
+        b, nq, c = hidden.shape
+        hd = wq.shape[0]
+        d = hd // num_heads
+        scale = 1.0 / math.sqrt(d)
+        x2 = hidden.reshape(b * nq, c)
+        if kv_src is None:  # self-attention
+            w_all = torch.cat([wq, wk, wv], 0)
+            b_all = torch.cat([bq, bk, bv], 0)
+            proj = torch.addmm(b_all, x2, w_all.t()).view(b, nq, 3 * hd)
+            qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
+            kvproj, e2 = None, None
+        else:
+            nk = kv_src.shape[1]
+            e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+            w_all = torch.cat([wk, wv], 0)
+            b_all = torch.cat([bk, bv], 0)
+            proj = torch.addmm(bq, x2, wq.t()).view(b, nq, hd)
+            kvproj = torch.addmm(b_all, e2, w_all.t()).view(b, nk, 2 * hd)
+            qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
+        out = torch.empty((b, nq, hd), dtype=torch.float32, device=dev)
+        lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
+        if mask is not None:
+            mask = mask.contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, ldq, ldk, ldv, ctypes.c_float(scale),
+                      qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse), ctypes.c_float(p_drop),
+                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
+        ctx.save_for_backward(hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse)
+        ctx.cfg = (num_heads, scale, p_drop, call_id, hd, nk)
+        # key / value for the reference's "present_key_value" are views of the projections
+        kview = (proj[..., hd:2 * hd] if kv_src is None else kvproj[..., :hd]).detach()
+        vview = (proj[..., 2 * hd:] if kv_src is None else kvproj[..., hd:]).detach()
+        ctx.mark_non_differentiable(kview, vview)
+        return out, kview, vview
+
+    @staticmethod
+    def backward(ctx, grad_out, _gk, _gv):
+        hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse = ctx.saved_tensors
+        num_heads, scale, p_drop, call_id, hd, nk = ctx.cfg
+        dev = hidden.device
+        b, nq, c = hidden.shape
+        d = hd // num_heads
+        grad_out = grad_out.contiguous()
+        x2 = hidden.reshape(b * nq, c)
+        self_attn = kv_src is None
+        dproj = torch.empty_like(proj)
+        if self_attn:
+            qp, kp, vp = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd)
+            dqp, dkp, dvp = _off(dproj, 0), _off(dproj, hd), _off(dproj, 2 * hd)
+            ldq = ldk = ldv = 3 * hd
+        else:
+            dkv = torch.empty_like(kvproj)
+            qp, kp, vp = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd)
+            dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
+            ldq, ldk, ldv = hd, 2 * hd, 2 * hd
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, ldq, ldk, ldv, ctypes.c_float(scale),
+                      qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), dqp,
+                      dkp, dvp, ctypes.c_float(p_drop), ctypes.c_uint(call_id),
+                      _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
+
+        def colsum(t2):
+            o = torch.empty(t2.shape[1], dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("sig3d_column_sum", t2.shape[0], t2.shape[1], _lib.ptr(t2), _lib.ptr(o),
+                          _lib.stream_ptr(dev))
+            return o
+
+        dp2 = dproj.view(b * nq, -1)
+        if self_attn:
+            g_hidden = dp2.mm(w_all).view(b, nq, c)
+            gw = dp2.t().mm(x2)          # (3*hd, c)
+            gb = colsum(dp2)
+            return (g_hidden, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:],
+                    None, None, None, None)
+        e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+        dkv2 = dkv.view(b * nk, 2 * hd)
+        g_hidden = dp2.mm(wq).view(b, nq, c)
+        gwq, gbq = dp2.t().mm(x2), colsum(dp2)
+        g_enc = dkv2.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
+        gwkv, gbkv = dkv2.t().mm(e2), colsum(dkv2)
+        return (g_hidden, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:], None, None, None,
+                None)
 
 
 def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
@@ -299,6 +401,16 @@ class BertSelfAttention(nn.Module):
         kv_src = encoder_hidden_states if is_cross_attention else hidden_states
         if is_cross_attention:
             attention_mask = encoder_attention_mask
+        if hidden_states.is_cuda and hidden_states.dtype == torch.float32:
+            # fused projections + attention (one GEMM per source tensor, strided Q/K/V slices)
+            nk = kv_src.shape[1]
+            mask = _key_mask(attention_mask, hidden_states.shape[0], nk)
+            p_drop = self.dropout.p if self.training else 0.0
+            context_layer, key, value = _ProjAttentionFn.apply(
+                hidden_states, encoder_hidden_states if is_cross_attention else None,
+                self.query.weight, self.query.bias, self.key.weight, self.key.bias, self.value.weight,
+                self.value.bias, mask, self.num_attention_heads, float(p_drop), self._call_id)
+            return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
         key = linear(self.key, kv_src)
         value = linear(self.value, kv_src)
         query = linear(self.query, hidden_states)

@@ -105,7 +105,8 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     md = mask.to(DEV) if mask is not None else None
     out = torch.empty(b, nq, h * 64, device=DEV)
     lse = torch.empty(b, h, nq, device=DEV)
-    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    ld = h * 64  # dense token-major operands
+    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
            L.ptr(None), L.stream_ptr())
 
@@ -121,7 +122,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd)
     dv = torch.empty_like(vd)
-    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
            L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
     torch.testing.assert_close(untm(dq.cpu()).double(), q64.grad, rtol=1e-4, atol=1e-4)
