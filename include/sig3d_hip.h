@@ -188,23 +188,25 @@ int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *strea
 
 /* Tail of BertSelfOutput / BertOutput (Qformer.py:241-246, 323-328) as one row kernel:
  *   out = LayerNorm(dropout(x + bias) + res) * gamma + beta,   x = dense(...) WITHOUT its bias.
- * x, res, out, v (rows, cols) with cols <= 1024; v receives the pre-LayerNorm sum, mean / rstd
- * (rows) the row statistics, mask (rows*cols bytes, required when p_drop > 0) the keep mask.
+ * x, res, out, v (rows, cols) with cols <= 1024 and rows*cols < 2^32; v receives the
+ * pre-LayerNorm sum, mean / rstd (rows) the row statistics, mask (rows*64 uint16, required when
+ * p_drop > 0) the keep mask: word [r*64 + l] bit i = "column l + 64*i of row r was kept".
  * Dropout bits = hash(*rng_counter, call_id, element index): advance the device counter once per
  * forward pass (sig3d_counter_increment) so that hipGraph replays draw fresh masks. */
 int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
                              const unsigned *rng_counter, const float *x, const float *bias,
                              const float *res, const float *gamma, const float *beta, float eps,
-                             float *out, float *v, float *mean, float *rstd, unsigned char *mask,
+                             float *out, float *v, float *mean, float *rstd, unsigned short *mask,
                              void *stream);
 
 /* Backward of the above: dy (rows, cols) -> dx (gradient of x, feeds the dense layer's GEMMs),
  * dres (gradient of the residual input) and dparams = [d gamma | d beta | d bias] (3*cols floats,
- * zeroed here). */
+ * fully written here).  workspace: 3*cols*ceil(rows/4) floats of scratch (per-workgroup partial
+ * column sums, folded without atomics: deterministic). */
 int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const float *dy, const float *v,
                              const float *mean, const float *rstd, const float *gamma,
-                             const unsigned char *mask, float *dx, float *dres, float *dparams,
-                             void *stream);
+                             const unsigned short *mask, float *dx, float *dres, float *dparams,
+                             float *workspace, void *stream);
 
 /* *counter += 1 (uint32) on the stream: the per-forward seed of the dropout hash. */
 int sig3d_counter_increment(unsigned *counter, void *stream);

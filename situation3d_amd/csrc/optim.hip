@@ -88,18 +88,47 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__rest
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   const bool vec = ((((size_t)c.p | (size_t)c.g | (size_t)c.m | (size_t)c.v) & 15) == 0);
   const long n4 = vec ? (c.n >> 2) : 0;
-  for (long i = threadIdx.x; i < n4; i += 256) {
-    float4 pp = reinterpret_cast<float4 *>(c.p)[i], gg = reinterpret_cast<const float4 *>(c.g)[i];
-    float4 mm = reinterpret_cast<float4 *>(c.m)[i], vv = reinterpret_cast<float4 *>(c.v)[i];
-    adamw_one(pp.x, gg.x, mm.x, vv.x, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
-    adamw_one(pp.y, gg.y, mm.y, vv.y, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
-    adamw_one(pp.z, gg.z, mm.z, vv.z, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
-    adamw_one(pp.w, gg.w, mm.w, vv.w, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
-    reinterpret_cast<float4 *>(c.p)[i] = pp;
-    reinterpret_cast<float4 *>(c.m)[i] = mm;
-    reinterpret_cast<float4 *>(c.v)[i] = vv;
+  // streaming update: nothing here is re-read before it falls out of the 256 MB Infinity Cache
+  // (428 MB of parameters alone), so loads and stores are non-temporal; two float4 quadruples in
+  // flight per lane (8 x 16 B loads) to cover HBM latency with ~6 workgroups per CU
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 *p4 = reinterpret_cast<f32x4 *>(c.p), *m4 = reinterpret_cast<f32x4 *>(c.m);
+  f32x4 *v4 = reinterpret_cast<f32x4 *>(c.v);
+  const f32x4 *g4 = reinterpret_cast<const f32x4 *>(c.g);
+  long i = threadIdx.x;
+  for (; i + 256 < n4; i += 512) {
+    f32x4 pp[2], gg[2], mm[2], vv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pp[u] = __builtin_nontemporal_load(p4 + i + 256 * u);
+      gg[u] = __builtin_nontemporal_load(g4 + i + 256 * u);
+      mm[u] = __builtin_nontemporal_load(m4 + i + 256 * u);
+      vv[u] = __builtin_nontemporal_load(v4 + i + 256 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = pp[u][e], ge = gg[u][e], me = mm[u][e], ve = vv[u][e];
+        adamw_one(pe, ge, me, ve, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+        pp[u][e] = pe; mm[u][e] = me; vv[u][e] = ve;
+      }
+      __builtin_nontemporal_store(pp[u], p4 + i + 256 * u);
+      __builtin_nontemporal_store(mm[u], m4 + i + 256 * u);
+      __builtin_nontemporal_store(vv[u], v4 + i + 256 * u);
+    }
   }
-  for (long i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
+  for (; i < n4; i += 256) {
+    f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], ge = gg[e], me = mm[e], ve = vv[e];
+      adamw_one(pe, ge, me, ve, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  for (i = (n4 << 2) + threadIdx.x; i < c.n; i += 256) {
     float pp = c.p[i], gg = c.g[i], mm = c.m[i], vv = c.v[i];
     adamw_one(pp, gg, mm, vv, lr, b1, b2, eps, c.wd, clip, step_size, inv_sqrt_bc2);
     c.p[i] = pp; c.m[i] = mm; c.v[i] = vv;

@@ -508,8 +508,12 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
-  SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * cout, stream));
-  SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
+  if (stat_sq == stat_sum + cout) {  // the usual (2, cout) allocation: one memset node
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * 2 * cout, stream));
+  } else {
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * cout, stream));
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
+  }
   if (b == 0 || e == 0) return 0;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
   SIG3D_REQUIRE(sizeof(float) * ((size_t)32 * ldw + 2 * kpad + ML_WAVES * 2 * 32) <= 160 * 1024,
@@ -566,8 +570,12 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
   SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && s >= 1, "bad size");
   SIG3D_REQUIRE((dA != nullptr) != (dOut != nullptr && arg != nullptr),
                 "pass either a dense dA or the (dOut, arg) pair of the max-pool");
-  SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * c, stream));
-  SIG3D_HIP_TRY(hipMemsetAsync(s2, 0, sizeof(double) * c, stream));
+  if (s2 == s1 + c) {
+    SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * 2 * c, stream));
+  } else {
+    SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * c, stream));
+    SIG3D_HIP_TRY(hipMemsetAsync(s2, 0, sizeof(double) * c, stream));
+  }
   if (b == 0 || e == 0) return 0;
   const double count = (double)b * (double)e;
   dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);

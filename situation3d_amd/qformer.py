@@ -128,7 +128,7 @@ class _DropoutAddLayerNormFn(torch.autograd.Function):
         out = torch.empty_like(x2)
         v = torch.empty_like(x2)
         stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
-        mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev) if p_drop > 0 else None
+        mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
         with torch.cuda.device(dev):
             _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, ctypes.c_float(p_drop),
                       ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
@@ -148,10 +148,11 @@ class _DropoutAddLayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(v)
         dres = torch.empty_like(v)
         dparams = torch.empty((3, cols), dtype=torch.float32, device=v.device)
+        work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
         with torch.cuda.device(v.device):
             _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, ctypes.c_float(ctx.p_drop), _lib.ptr(dy2),
                       _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
-                      _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams),
+                      _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work),
                       _lib.stream_ptr(v.device))
         return (dx.view(ctx.shape), dparams[2], dres.view(ctx.shape), dparams[0], dparams[1], None,
                 None, None)
