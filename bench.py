@@ -23,7 +23,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from situation3d_amd import _lib  # noqa: E402
+from situation3d_amd import _lib, gemm_tuning  # noqa: E402
 from situation3d_amd.ddp import GradBucketReducer, init_distributed  # noqa: E402
 from situation3d_amd.graph_step import GraphedTrainStep  # noqa: E402
 from situation3d_amd.model import SIG3DQFormer  # noqa: E402
@@ -126,6 +126,8 @@ def main():
                     help="torch.optim.AdamW + clip_grad_value_ instead of the fused flat optimizer")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="library GEMMs with the default heuristic instead of the tuned solutions")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute FPS/ball-query geometry inline instead of one batch ahead")
     args = ap.parse_args()
@@ -134,6 +136,9 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
     device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if not args.no_gemm_tuning:
+        gemm_tuning.enable(tune_missing=True)  # committed winners; unseen shapes tuned in warm-up
     torch.manual_seed(1234)  # identical initial weights on every rank
     model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
     # clip_grad_value_(1.0) + AdamW (lr 2e-5, wd 0.05: scripts/train.sh:7) + zero_grad fused over
@@ -231,6 +236,7 @@ def main():
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
                                     "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},
             "launch_mode": "hipGraph replay" if use_graph else "eager",
+            "library_gemms": "default heuristic" if args.no_gemm_tuning else "tuned (TunableOp)",
             "final_loss": round(final_loss, 5),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -32,6 +32,7 @@ replay; outputs (loss, answer_scores, ...) are read from static buffers after it
 import torch
 import torch.nn as nn
 
+from . import gemm_tuning
 from .geometry import GeometryPlan
 from .trainer import get_loss
 
@@ -121,7 +122,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if reducer is None:
             optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph, stream=stream):
+        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream):
             if self.prefetch:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
@@ -135,7 +136,8 @@ class GraphedTrainStep:
                 stream.wait_stream(self.side)                    # join
                 self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
         if reducer is not None:
-            with torch.cuda.graph(self.graph_opt, stream=stream, pool=self.graph.pool()):
+            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
+                                                           pool=self.graph.pool()):
                 update()
         torch.cuda.synchronize()
 
