@@ -245,9 +245,16 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL).
  * ldq / ldk / ldv: row strides in floats of q, k, v (h*d for dense tensors; 3*h*d when q, k, v are
  * column slices of ONE fused QKV projection output, which saves two GEMM launches per attention).
- * In the backward pass dq / dk / dv use the same strides as their inputs. */
-int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
-                        float scale, const float *q,
+ * In the backward pass dq / dk / dv use the same strides as their inputs.
+ * q_seg / k_seg: token -> storage row map of the query-side tensors (q, out, grad_out, dq) and of
+ * the key-side tensors (k, v, dk, dv).  seg == n (or 0): plain (b, n) order, row = bi*n + i.
+ * seg < n: two-segment order -- the first `seg` tokens of every batch element are stored first
+ * (row = bi*seg + i), the remaining n-seg tokens of every batch element after them
+ * (row = b*seg + bi*(n-seg) + i-seg).  The Q-Former keeps [query tokens | text tokens] that way so
+ * that the per-part feed-forward blocks of BertLayer.forward (Qformer.py:375-405) work on
+ * contiguous row ranges.  mask (b,nk) and lse (b,h,nq) are always indexed by (batch, token). */
+int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq, int ldk,
+                        int ldv, float scale, const float *q,
                         const float *k, const float *v, const float *mask, float *out,
                         float *lse, float p_drop, unsigned call_id, const unsigned *rng_counter,
                         void *stream);
@@ -258,8 +265,8 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, i
 
 /* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
  * -> dq (b,nq,h*d), dk (b,nk,h*d), dv (b,nk,h*d), token-major like the inputs. */
-int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
-                        float scale, const float *q,
+int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq, int ldk,
+                        int ldv, float scale, const float *q,
                         const float *k, const float *v, const float *mask,
                         const float *out, const float *lse, const float *grad_out,
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,

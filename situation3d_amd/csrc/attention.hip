@@ -50,6 +50,17 @@ __device__ __forceinline__ void load_half_row(float (&f)[32], const float *base,
   }
 }
 
+// Token (batch bi, position i) -> storage row of a token-major operand.
+//   plain layout   (seg == n): row = bi*n + i                      -- a dense (b, n, ...) tensor
+//   two segments   (seg <  n): the first `seg` tokens of EVERY batch element are stored together
+//                  (nb*seg rows), the remaining n-seg tokens of every batch element after them.
+// The Q-Former keeps [all query tokens | all text tokens] in that order (qformer.py): the query /
+// text split of BertLayer.forward (Qformer.py:375-405) is then a pair of contiguous row ranges
+// instead of strided slices that must be copied for the feed-forward GEMMs.
+__device__ __forceinline__ long tok_row(int i, int bi, int n, int seg, int nb) {
+  return i < seg ? (long)bi * seg + i : (long)nb * seg + (long)bi * (n - seg) + (i - seg);
+}
+
 // Attention-probability dropout (Qformer.py:219, nn.Dropout on the softmax output): the keep bit
 // of element (b, head, query, key) is a pure hash of (device counter, call id, that index), so the
 // forward and backward kernels regenerate identical masks in their different tile layouts and
@@ -86,8 +97,8 @@ __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base,
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
-    int h, int nq, int nk, int ldq, int ldk, int ldv, float scale, float p_drop, unsigned call_id,
-    const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
+    int h, int nq, int nk, int q_seg, int k_seg, int ldq, int ldk, int ldv, float scale, float p_drop,
+    unsigned call_id, const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
     const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
     float *__restrict__ out, float *__restrict__ lse) {
   __shared__ float s_o[AT_WAVES][AT_D][32];
@@ -96,17 +107,17 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
-  // token-major operands: row r of head hi starts at base + r*ld + hi*64, where ld is the row
-  // stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
-  // projection output)
-  const float *Q = q + (size_t)bi * nq * ldq + hi * AT_D;
-  const float *K = k + (size_t)bi * nk * ldk + hi * AT_D;
-  const float *V = v + (size_t)bi * nk * ldv + hi * AT_D;
+  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z, nb = gridDim.z;
+  // token-major operands: storage row r of head hi starts at base + r*ld + hi*64, where ld is the
+  // row stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
+  // projection output) and r = tok_row(token, batch)
+  const float *Q = q + hi * AT_D;
+  const float *K = k + hi * AT_D;
+  const float *V = v + hi * AT_D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
 
   float qf[32];
-  load_half_row(qf, Q, q0 + l31, ldq, half, q0 + l31 < nq);
+  load_half_row(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, nb), ldq, half, q0 + l31 < nq);
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
 
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   for (int t = wave; t < ntiles; t += AT_WAVES) {
     const int key0 = t * 32;
     float kf[32];
-    load_half_row(kf, K, min(key0 + l31, nk - 1), ldk, half, true);
+    load_half_row(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, nb), ldk, half, true);
     f32x16 st = {0};
 #pragma unroll
     for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
@@ -152,9 +163,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
-      const int key = min(key0 + mfma_row(s, half), nk - 1);
-      const float a0 = V[(size_t)key * ldv + l31];
-      const float a1 = V[(size_t)key * ldv + 32 + l31];
+      const long key = tok_row(min(key0 + mfma_row(s, half), nk - 1), bi, nk, k_seg, nb);
+      const float a0 = V[key * ldv + l31];
+      const float a1 = V[key * ldv + 32 + l31];
       o0 = mfma32(a0, p[s], o0);
       o1 = mfma32(a1, p[s], o1);
     }
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
         res[i] = acc * inv;
       }
       // context_layer.permute(0,2,1,3).view(B, Nq, 768)  (Qformer.py:225-227)
-      float *o = out + ((size_t)bi * nq + q0 + qq) * (size_t)(h * AT_D) + hi * AT_D + dg * 8;
+      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, nb) * (long)(h * AT_D) + hi * AT_D + dg * 8;
       *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
       *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
       if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
@@ -205,8 +216,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 // backward: grid (key_splits, h, b), 256 threads.  A wave owns whole 32-key tiles, so dK / dV
 // are plain stores; dQ is reduced in LDS per workgroup (and with atomics across key splits).
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
-    int h, int nq, int nk, int ldq, int ldk, int ldv, float scale, int tiles_per_split,
-    int atomic_dq, float p_drop,
+    int h, int nq, int nk, int q_seg, int k_seg, int ldq, int ldk, int ldv, float scale,
+    int tiles_per_split, int atomic_dq, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
@@ -219,23 +230,25 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int hi = blockIdx.y, bi = blockIdx.z;
+  const int hi = blockIdx.y, bi = blockIdx.z, nb = gridDim.z;
   const size_t bh = (size_t)(bi * h + hi);
-  const size_t ostride = (size_t)h * AT_D;  // out / grad_out are dense (b, nq, h*d)
-  const float *Q = q + (size_t)bi * nq * ldq + hi * AT_D;
-  const float *K = k + (size_t)bi * nk * ldk + hi * AT_D;
-  const float *V = v + (size_t)bi * nk * ldv + hi * AT_D;
+  const long ostride = (long)h * AT_D;  // out / grad_out are dense rows of h*d floats
+  const float *Q = q + hi * AT_D;       // storage row r at Q + r*ldq, r = tok_row(token, batch)
+  const float *K = k + hi * AT_D;
+  const float *V = v + hi * AT_D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
-  const float *O = out + (size_t)bi * nq * ostride + hi * AT_D;        // row q at O + q*ostride
-  const float *dO = grad_out + (size_t)bi * nq * ostride + hi * AT_D;
+  const float *O = out + hi * AT_D;
+  const float *dO = grad_out + hi * AT_D;
+  auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, nb); };
+  auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, nb); };
 
   // D[q] = sum_d dO[q][d] * O[q][d]; two threads per row
   {
     const int qq = threadIdx.x >> 1, hh = threadIdx.x & 1;
     float part = 0.f;
     if (qq < nq) {
-      const float4 *a = reinterpret_cast<const float4 *>(dO + (size_t)qq * ostride + hh * 32);
-      const float4 *c = reinterpret_cast<const float4 *>(O + (size_t)qq * ostride + hh * 32);
+      const float4 *a = reinterpret_cast<const float4 *>(dO + qrow(qq) * ostride + hh * 32);
+      const float4 *c = reinterpret_cast<const float4 *>(O + qrow(qq) * ostride + hh * 32);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float4 x = a[i], y = c[i];
@@ -262,15 +275,16 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     const int krow = min(key0 + l31, nk - 1);
     const bool key_ok = key0 + l31 < nk;
     float kf[32], vf[32];
-    load_half_row(kf, K, krow, ldk, half, true);
-    load_half_row(vf, V, krow, ldv, half, true);
+    load_half_row(kf, K, krow_of(krow), ldk, half, true);
+    load_half_row(vf, V, krow_of(krow), ldv, half, true);
     const float mk = M ? M[krow] : 0.f;
     f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
 
     for (int qt = 0; qt < nqt; ++qt) {
       const int q0 = qt * 32;
       float fr[32];
-      load_half_row(fr, Q, q0 + l31, ldq, half, q0 + l31 < nq);
+      const long my_qrow = qrow(min(q0 + l31, nq - 1));
+      load_half_row(fr, Q, my_qrow, ldq, half, q0 + l31 < nq);
       f32x16 sacc = {0};
 #pragma unroll
       for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq, AT_NQ_MAX - 1)]);
         p[r] = (key_ok && qq < nq) ? e : 0.f;
       }
-      load_half_row(fr, dO, q0 + l31, (long)ostride, half, q0 + l31 < nq);
+      load_half_row(fr, dO, my_qrow, ostride, half, q0 + l31 < nq);
       f32x16 dpacc = {0};
 #pragma unroll
       for (int s = 0; s < 32; ++s) dpacc = mfma32(fr[s], vf[s], dpacc);  // dP[q][key]
@@ -303,9 +317,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int qq = min(q0 + mfma_row(s, half), nq - 1);
-        const float g0 = dO[(size_t)qq * ostride + l31], g1 = dO[(size_t)qq * ostride + 32 + l31];
-        const float x0 = Q[(size_t)qq * ldq + l31], x1 = Q[(size_t)qq * ldq + 32 + l31];
+        const long qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
+        const float g0 = dO[qq * ostride + l31], g1 = dO[qq * ostride + 32 + l31];
+        const float x0 = Q[qq * ldq + l31], x1 = Q[qq * ldq + 32 + l31];
         dvt0 = mfma32(g0, p[s], dvt0);
         dvt1 = mfma32(g1, p[s], dvt1);
         dkt0 = mfma32(x0, ds[s], dkt0);
@@ -320,10 +334,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const int kk = mfma_row(s, half);
-        const int key = min(key0 + kk, nk - 1);
+        const long key = krow_of(min(key0 + kk, nk - 1));
         const float bq = s_T[wave][kk][l31];
-        dqt0 = mfma32(K[(size_t)key * ldk + l31], bq, dqt0);
-        dqt1 = mfma32(K[(size_t)key * ldk + 32 + l31], bq, dqt1);
+        dqt0 = mfma32(K[key * ldk + l31], bq, dqt0);
+        dqt1 = mfma32(K[key * ldk + 32 + l31], bq, dqt1);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -336,8 +350,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       }
     }
     if (key_ok) {
-      float *dvp = dv + ((size_t)bi * nk + key0 + l31) * ldv + hi * AT_D;  // grads mirror the inputs
-      float *dkp = dk + ((size_t)bi * nk + key0 + l31) * ldk + hi * AT_D;
+      float *dvp = dv + krow_of(key0 + l31) * ldv + hi * AT_D;  // grads mirror the inputs
+      float *dkp = dk + krow_of(key0 + l31) * ldk + hi * AT_D;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
         const int d = 8 * g + 4 * half;
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
     const int qq = i / AT_D, d = i % AT_D;
     const float val = s_dq[qq][d] * scale;
-    float *dst = dq + ((size_t)bi * nq + qq) * ldq + hi * AT_D + d;
+    float *dst = dq + qrow(qq) * ldq + hi * AT_D + d;
     if (atomic_dq) unsafeAtomicAdd(dst, val);
     else *dst = val;
   }
@@ -360,28 +374,29 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
 }  // namespace
 
-extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
-                                   float scale, const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq,
+                                   int ldk, int ldv, float scale, const float *q, const float *k, const float *v,
                                    const float *mask, float *out, float *lse, float p_drop,
                                    unsigned call_id, const unsigned *rng_counter, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
+  SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
   SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
                 "row strides must be >= h*d and multiples of 4 floats");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
   dim3 grid((nq + 31) / 32, h, b);
-  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, ldq, ldk,
-                     ldv, scale,
+  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
+                     ldq, ldk, ldv, scale,
                      p_drop, call_id, rng_counter, q, k, v, mask, out, lse);
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
 
-extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq, int ldk, int ldv,
-                                   float scale, const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq,
+                                   int ldk, int ldv, float scale, const float *q, const float *k, const float *v,
                                    const float *mask, const float *out, const float *lse,
                                    const float *grad_out, float *dq, float *dk, float *dv,
                                    float p_drop, unsigned call_id, const unsigned *rng_counter,
@@ -391,6 +406,7 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq,
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
   SIG3D_REQUIRE(nq <= AT_NQ_MAX, "attention backward supports at most 128 query rows");
+  SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
   const int ntiles = (nk + 31) / 32;
@@ -410,8 +426,8 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int ldq,
   if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
     SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D, (size_t)b * nq, stream));
   dim3 grid(splits, h, b);
-  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, ldq, ldk,
-                     ldv, scale,
+  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
+                     ldq, ldk, ldv, scale,
                      tiles_per_split, splits > 1 ? 1 : 0, p_drop, call_id, rng_counter, q, k, v, mask,
                      out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");

@@ -110,7 +110,9 @@ class SIG3DQFormer(nn.Module):
                           attention_mask=torch.cat([ones, q["attention_mask"]], dim=1))
         out = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=tokens,
                                 encoder_attention_mask=None, return_dict=True, **kwargs)
-        fused = out.last_hidden_state[:, :query_tokens.shape[1], :]
+        fused = getattr(out, "query_hidden_state", None)   # two-segment layout: a free view
+        if fused is None:
+            fused = out.last_hidden_state[:, :query_tokens.shape[1], :]
         data_dict["att_feat_ori"] = fused
         pooled = fused.mean(dim=1)
         data_dict["aux_scores"] = self.aux_reg(pooled)

@@ -184,7 +184,7 @@ class _AttentionFn(torch.autograd.Function):
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, hd, hd, hd, ctypes.c_float(scale),
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, nq, nk, hd, hd, hd, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
                       _lib.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
@@ -201,7 +201,7 @@ class _AttentionFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         with torch.cuda.device(q.device):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads, hd, hd, hd,
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads, nq, nk, hd, hd, hd,
                       ctypes.c_float(scale), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask),
                       _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), _lib.ptr(dq), _lib.ptr(dk),
                       _lib.ptr(dv), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
@@ -213,6 +213,26 @@ def _off(t, floats):
     return ctypes.c_void_p(t.data_ptr() + 4 * floats)
 
 
+def _stacked(ts):
+    """[W0; W1; ...] as ONE tensor.  Zero-copy when the pieces sit back to back in memory -- which is
+    how optim.FlatAdamW lays the query/key/value weights (and their biases) out -- else torch.cat."""
+    first = ts[0]
+    ptr = first.data_ptr()
+    adjacent = True
+    for t in ts:
+        if not t.is_contiguous() or t.data_ptr() != ptr or t.shape[1:] != first.shape[1:]:
+            adjacent = False
+            break
+        ptr += 4 * t.numel()
+    if adjacent:
+        rows = sum(t.shape[0] for t in ts)
+        need = first.storage_offset() + rows * (first.numel() // first.shape[0])
+        if need <= first.untyped_storage().nbytes() // 4:
+            return first.as_strided((rows,) + tuple(first.shape[1:]), first.stride(),
+                                    first.storage_offset())
+    return torch.cat(list(ts), 0)
+
+
 class _ProjAttentionFn(torch.autograd.Function):
     """query/key/value projections + attention core of BertSelfAttention.forward
     (Qformer.py:150-232) with the projections FUSED into one library GEMM per source tensor:
@@ -221,52 +241,72 @@ class _ProjAttentionFn(torch.autograd.Function):
     The attention kernels read Q, K, V as column slices of those outputs (row stride 3*H*64 /
     2*H*64) and write dQ, dK, dV into the matching slices of ONE gradient buffer, so the backward
     is again one dX GEMM, one dW GEMM and one column-sum per source -- no cat / split / accumulate
-    kernels.  Parameters stay separate tensors (state_dict keys unchanged)."""
+    kernels.  Parameters stay separate tensors (state_dict keys unchanged); the stacked weight is a
+    zero-copy view when they are adjacent in memory (_stacked).
+
+    layout=None: hidden is (B, N, C) in plain token order.  layout=(B, N, seg): hidden is the 2-D
+    (B*N, C) row matrix in TWO-SEGMENT order ([first `seg` tokens of every batch element | the
+    rest], see sig3d_attention_fwd) and so is the result (self-attention only)."""
 
     @staticmethod
-    def forward(ctx, hidden, kv_src, wq, bq, wk, bk, wv, bv, mask, num_heads, p_drop, call_id):
+    def forward(ctx, hidden, kv_src, wq, bq, wk, bk, wv, bv, mask, num_heads, p_drop, call_id,
+                layout=None):
         dev = hidden.device
-        b, nq, c = hidden.shape
+        if layout is None:
+            b, nq, c = hidden.shape
+            seg = nq
+        else:
+            b, nq, seg = layout
+            c = hidden.shape[-1]
         hd = wq.shape[0]
         d = hd // num_heads
         scale = 1.0 / math.sqrt(d)
         x2 = hidden.reshape(b * nq, c)
         if kv_src is None:  # self-attention
-            w_all = torch.cat([wq, wk, wv], 0)
-            b_all = torch.cat([bq, bk, bv], 0)
-            proj = torch.addmm(b_all, x2, w_all.t()).view(b, nq, 3 * hd)
+            w_all = _stacked((wq, wk, wv))
+            b_all = _stacked((bq, bk, bv))
+            proj = torch.addmm(b_all, x2, w_all.t())            # (B*N, 3*hd)
             qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
-            kvproj, e2 = None, None
+            kvproj, kseg = None, seg
         else:
+            assert layout is None, "two-segment layout is for self-attention"
             nk = kv_src.shape[1]
+            kseg = nk
             e2 = kv_src.reshape(b * nk, kv_src.shape[2])
-            w_all = torch.cat([wk, wv], 0)
-            b_all = torch.cat([bk, bv], 0)
-            proj = torch.addmm(bq, x2, wq.t()).view(b, nq, hd)
-            kvproj = torch.addmm(b_all, e2, w_all.t()).view(b, nk, 2 * hd)
+            w_all = _stacked((wk, wv))
+            b_all = _stacked((bk, bv))
+            proj = torch.addmm(bq, x2, wq.t())                  # (B*N, hd)
+            kvproj = torch.addmm(b_all, e2, w_all.t())          # (B*Nk, 2*hd)
             qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
-        out = torch.empty((b, nq, hd), dtype=torch.float32, device=dev)
+        out = torch.empty((b * nq, hd), dtype=torch.float32, device=dev)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, ldq, ldk, ldv, ctypes.c_float(scale),
-                      qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse), ctypes.c_float(p_drop),
-                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
+                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
+                      ctypes.c_float(p_drop), ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)),
+                      _lib.stream_ptr(dev))
         ctx.save_for_backward(hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse)
-        ctx.cfg = (num_heads, scale, p_drop, call_id, hd, nk)
+        ctx.cfg = (num_heads, scale, p_drop, call_id, hd, nk, b, nq, seg, kseg)
         # key / value for the reference's "present_key_value" are views of the projections
-        kview = (proj[..., hd:2 * hd] if kv_src is None else kvproj[..., :hd]).detach()
-        vview = (proj[..., 2 * hd:] if kv_src is None else kvproj[..., hd:]).detach()
+        if kv_src is None:
+            kview, vview = proj[:, hd:2 * hd], proj[:, 2 * hd:]
+        else:
+            kview, vview = kvproj[:, :hd], kvproj[:, hd:]
+        if layout is None:
+            out = out.view(b, nq, hd)
+            kview, vview = kview.view(b, nk, hd), vview.view(b, nk, hd)
+        kview, vview = kview.detach(), vview.detach()
         ctx.mark_non_differentiable(kview, vview)
         return out, kview, vview
 
     @staticmethod
     def backward(ctx, grad_out, _gk, _gv):
         hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse = ctx.saved_tensors
-        num_heads, scale, p_drop, call_id, hd, nk = ctx.cfg
+        num_heads, scale, p_drop, call_id, hd, nk, b, nq, seg, kseg = ctx.cfg
         dev = hidden.device
-        b, nq, c = hidden.shape
+        c = hidden.shape[-1]
         d = hd // num_heads
         grad_out = grad_out.contiguous()
         x2 = hidden.reshape(b * nq, c)
@@ -282,9 +322,9 @@ class _ProjAttentionFn(torch.autograd.Function):
             dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
             ldq, ldk, ldv = hd, 2 * hd, 2 * hd
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, ldq, ldk, ldv, ctypes.c_float(scale),
-                      qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), dqp,
-                      dkp, dvp, ctypes.c_float(p_drop), ctypes.c_uint(call_id),
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
+                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
+                      _lib.ptr(grad_out), dqp, dkp, dvp, ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
 
         def colsum(t2):
@@ -294,21 +334,19 @@ class _ProjAttentionFn(torch.autograd.Function):
                           _lib.stream_ptr(dev))
             return o
 
-        dp2 = dproj.view(b * nq, -1)
         if self_attn:
-            g_hidden = dp2.mm(w_all).view(b, nq, c)
-            gw = dp2.t().mm(x2)          # (3*hd, c)
-            gb = colsum(dp2)
+            g_hidden = dproj.mm(w_all).view(hidden.shape)
+            gw = dproj.t().mm(x2)          # (3*hd, c)
+            gb = colsum(dproj)
             return (g_hidden, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:],
-                    None, None, None, None)
+                    None, None, None, None, None)
         e2 = kv_src.reshape(b * nk, kv_src.shape[2])
-        dkv2 = dkv.view(b * nk, 2 * hd)
-        g_hidden = dp2.mm(wq).view(b, nq, c)
-        gwq, gbq = dp2.t().mm(x2), colsum(dp2)
-        g_enc = dkv2.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
-        gwkv, gbkv = dkv2.t().mm(e2), colsum(dkv2)
+        g_hidden = dproj.mm(wq).view(hidden.shape)
+        gwq, gbq = dproj.t().mm(x2), colsum(dproj)
+        g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
+        gwkv, gbkv = dkv.t().mm(e2), colsum(dkv)
         return (g_hidden, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:], None, None, None,
-                None)
+                None, None)
 
 
 def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
@@ -349,7 +387,7 @@ class BertEmbeddings(nn.Module):
         self.config = config
 
     def forward(self, input_ids=None, position_ids=None, query_embeds=None,
-                past_key_values_length=0):
+                past_key_values_length=0, segmented=False):
         seq_length = input_ids.size()[1] if input_ids is not None else 0
         if position_ids is None:
             position_ids = self.position_ids[
@@ -359,7 +397,11 @@ class BertEmbeddings(nn.Module):
             if self.position_embedding_type == "absolute":
                 embeddings = embeddings + self.position_embeddings(position_ids)
             if query_embeds is not None:
-                embeddings = torch.cat((query_embeds, embeddings), dim=1)
+                if segmented:  # (B*Tq + B*Tt, C): [all query rows | all text rows]
+                    c = embeddings.shape[-1]
+                    embeddings = torch.cat((query_embeds.reshape(-1, c), embeddings.reshape(-1, c)), dim=0)
+                else:
+                    embeddings = torch.cat((query_embeds, embeddings), dim=1)
         else:
             embeddings = query_embeds
         return self.dropout(self.LayerNorm(embeddings))
@@ -422,6 +464,16 @@ class BertSelfAttention(nn.Module):
         return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
 
 
+def _segmented_self_attention(module, rows, attention_mask, batch, n_tokens, seg):
+    """BertSelfAttention over the two-segment row matrix (B*N, C) -> (B*N, H*64), same order."""
+    mask = _key_mask(attention_mask, batch, n_tokens)
+    p_drop = module.dropout.p if module.training else 0.0
+    return _ProjAttentionFn.apply(rows, None, module.query.weight, module.query.bias, module.key.weight,
+                                  module.key.bias, module.value.weight, module.value.bias, mask,
+                                  module.num_attention_heads, float(p_drop), module._call_id,
+                                  (batch, n_tokens, seg))[0]
+
+
 class BertSelfOutput(nn.Module):
     """Qformer.py:235-246"""
 
@@ -451,6 +503,10 @@ class BertAttention(nn.Module):
         self_outputs = self.self(hidden_states, attention_mask, head_mask, encoder_hidden_states,
                                  encoder_attention_mask, past_key_value, output_attentions)
         return (self.output(self_outputs[0], hidden_states),) + self_outputs[1:]
+
+    def forward_segmented(self, rows, attention_mask, batch, n_tokens, seg):
+        ctx = _segmented_self_attention(self.self, rows, attention_mask, batch, n_tokens, seg)
+        return self.output(ctx, rows)
 
 
 class BertIntermediate(nn.Module):
@@ -531,11 +587,57 @@ class BertLayer(nn.Module):
             layer_output = self.feed_forward_chunk(attention_output)
         return (layer_output, present_key_value)
 
+    def forward_segmented(self, rows, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                          batch, query_length, text_length):
+        """Same computation as forward() on the two-segment row matrix
+        rows = [B*query_length query rows | B*text_length text rows]  (B*(Tq+Tt), C):
+        the query / text split (Qformer.py:375,396) and the final cat (:402) are contiguous row
+        ranges -- torch.split is a pair of views (its backward ONE cat), torch.cat one copy (its
+        backward two views) -- where the (B, N, C) layout pays a strided copy per slice, per
+        residual and per gradient (5 copies + 1 cat forward, ~2x that backward, per layer)."""
+        rq = batch * query_length
+        attention_output = self.attention.forward_segmented(
+            rows, attention_mask, batch, query_length + text_length, query_length)
+        query_rows, text_rows = torch.split(attention_output, [rq, batch * text_length], dim=0)
+        if self.has_cross_attention:
+            assert encoder_hidden_states is not None, \
+                "encoder_hidden_states must be given for cross-attention layers"
+            query_rows = self.crossattention(
+                query_rows.view(batch, query_length, -1), None, None, encoder_hidden_states,
+                encoder_attention_mask)[0].reshape(rq, -1)
+        return torch.cat([self.feed_forward_chunk_query(query_rows),
+                          self.feed_forward_chunk(text_rows)], dim=0)
+
     def feed_forward_chunk(self, attention_output):
         return self.output(self.intermediate(attention_output), attention_output)
 
     def feed_forward_chunk_query(self, attention_output):
         return self.output_query(self.intermediate_query(attention_output), attention_output)
+
+
+class _SegmentedOutput:
+    """Encoder result kept as the two-segment row matrix.  `query_hidden_state` (B, Tq, C) -- what
+    BLIP-2 consumes (`last_hidden_state[:, :query_length]`, blip2_t5.py / model.py) -- is a free
+    view; the full (B, Tq+Tt, C) `last_hidden_state` is assembled on first access."""
+
+    def __init__(self, rows, batch, tq, tt):
+        self.rows, self._shape = rows, (batch, tq, tt)
+        self._full = None
+        self.past_key_values = self.hidden_states = self.attentions = self.cross_attentions = None
+        self.pooler_output = None
+
+    @property
+    def query_hidden_state(self):
+        b, tq, _ = self._shape
+        return self.rows[:b * tq].view(b, tq, -1)
+
+    @property
+    def last_hidden_state(self):
+        if self._full is None:
+            b, tq, tt = self._shape
+            self._full = torch.cat([self.rows[:b * tq].view(b, tq, -1),
+                                    self.rows[b * tq:].view(b, tt, -1)], dim=1)
+        return self._full
 
 
 class BertEncoder(nn.Module):
@@ -549,7 +651,15 @@ class BertEncoder(nn.Module):
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
                 use_cache=None, output_attentions=False, output_hidden_states=False,
-                return_dict=True, query_length=0):
+                return_dict=True, query_length=0, segments=None):
+        if segments is not None:
+            # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
+            batch, tq, tt = segments
+            for layer_module in self.layer:
+                hidden_states = layer_module.forward_segmented(
+                    hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                    batch, tq, tt)
+            return _SegmentedOutput(hidden_states, batch, tq, tt)
         all_hidden_states = () if output_hidden_states else None
         for layer_module in self.layer:
             if output_hidden_states:
@@ -576,6 +686,7 @@ class BertModel(nn.Module):
         self.config = config
         self.embeddings = BertEmbeddings(config)
         self.encoder = BertEncoder(config)
+        self.segmented_layout = True  # False: keep (B, N, C) tensors between layers (same values)
         self.apply(self._init_weights)
 
     def _init_weights(self, module):
@@ -606,9 +717,18 @@ class BertModel(nn.Module):
         ref = query_embeds if query_embeds is not None else encoder_hidden_states
         if self.training and ref is not None and ref.is_cuda:
             advance_dropout_seed(ref.device)  # fused dropout kernels hash (this counter, call id, index)
+        # hot path: queries + text on the GPU -> two-segment row layout through the whole stack
+        segments = None
+        if (input_ids is not None and query_embeds is not None and query_embeds.is_cuda
+                and query_embeds.dtype == torch.float32 and input_ids.shape[1] > 0
+                and not output_hidden_states and return_dict is not False and self.segmented_layout):
+            segments = (query_embeds.shape[0], query_length, input_ids.shape[1])
         embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
-                                           query_embeds=query_embeds)
-        batch_size, seq_length = embedding_output.shape[:2]
+                                           query_embeds=query_embeds, segmented=segments is not None)
+        if segments is not None:
+            batch_size, seq_length = segments[0], segments[1] + segments[2]
+        else:
+            batch_size, seq_length = embedding_output.shape[:2]
         device = embedding_output.device
         if attention_mask is None:
             attention_mask = torch.ones((batch_size, seq_length), device=device)
@@ -625,7 +745,9 @@ class BertModel(nn.Module):
                            encoder_hidden_states=encoder_hidden_states,
                            encoder_attention_mask=encoder_extended_attention_mask,
                            output_hidden_states=bool(output_hidden_states), return_dict=True,
-                           query_length=query_length)
+                           query_length=query_length, segments=segments)
+        if segments is not None:
+            return enc
         if return_dict is False:
             return (enc.last_hidden_state, None)
         return SimpleNamespace(last_hidden_state=enc.last_hidden_state, pooler_output=None,

@@ -106,7 +106,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     out = torch.empty(b, nq, h * 64, device=DEV)
     lse = torch.empty(b, h, nq, device=DEV)
     ld = h * 64  # dense token-major operands
-    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
            L.ptr(None), L.stream_ptr())
 
@@ -122,9 +122,46 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd)
     dv = torch.empty_like(vd)
-    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, nq, nk, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
            L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
     torch.testing.assert_close(untm(dq.cpu()).double(), q64.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(untm(dk.cpu()).double(), k64.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(untm(dv.cpu()).double(), v64.grad, rtol=1e-4, atol=1e-4)
+
+
+def _to_segments(t, seg):
+    """(b, n, c) plain token order -> (b*n, c) two-segment row matrix (include/sig3d_hip.h)."""
+    b, n, c = t.shape
+    return torch.cat([t[:, :seg].reshape(b * seg, c), t[:, seg:].reshape(b * (n - seg), c)], 0).contiguous()
+
+
+@pytest.mark.parametrize("b,h,n,seg", [(8, 12, 52, 32), (3, 2, 40, 1), (2, 4, 33, 32), (2, 1, 7, 7)])
+def test_attention_two_segment_layout_matches_plain(b, h, n, seg):
+    """q_seg / k_seg only re-map token -> storage row: results must equal the plain-layout call
+    bit for bit after un-permuting the rows (same arithmetic, same order)."""
+    L = _lib()
+    g = torch.Generator().manual_seed(n * 7 + seg)
+    ld = h * 64
+    q, k, v, go = (torch.randn(b, n, ld, generator=g).to(DEV) for _ in range(4))
+    keep = (torch.rand(b, n, generator=g) > 0.2).float()
+    keep[:, 0] = 1.0
+    mask = ((1.0 - keep) * -10000.0).to(DEV)
+    scale = ctypes.c_float(0.125)
+
+    def run(qs, ks, q, k, v, go):
+        out, lse = torch.empty_like(q), torch.empty(b, h, n, device=DEV)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        L.call("sig3d_attention_fwd", b, h, n, n, 64, qs, ks, ld, ld, ld, scale, L.ptr(q), L.ptr(k), L.ptr(v),
+               L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None),
+               L.stream_ptr())
+        L.call("sig3d_attention_bwd", b, h, n, n, 64, qs, ks, ld, ld, ld, scale, L.ptr(q), L.ptr(k), L.ptr(v),
+               L.ptr(mask), L.ptr(out), L.ptr(lse), L.ptr(go), L.ptr(dq), L.ptr(dk), L.ptr(dv),
+               ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
+        return out, lse, dq, dk, dv
+
+    plain = run(n, n, q, k, v, go)
+    segd = run(seg, seg, *(_to_segments(t, seg) for t in (q, k, v, go)))
+    assert torch.equal(plain[1], segd[1])  # lse is indexed by (batch, head, token) in both
+    for name, a, c in zip(("out", "dq", "dk", "dv"), (plain[0],) + plain[2:], (segd[0],) + segd[2:]):
+        assert torch.equal(_to_segments(a.view(b, n, ld), seg), c.view(b * n, ld)), name

@@ -147,8 +147,12 @@ def test_qformer_queries_only_matches_reference():
     assert n >= 8
 
 
-def test_qformer_with_question_tokens_matches_reference():
+@pytest.mark.parametrize("segmented", [True, False])
+def test_qformer_with_question_tokens_matches_reference(segmented):
+    """segmented=True: the two-segment [query rows | text rows] layout of the hot path;
+    False: (B, N, C) tensors between layers.  Both against the reference's golden outputs."""
     model, g = _qformer()
+    model.bert.segmented_layout = segmented
     query = g["query_embeds"].to(DEV).requires_grad_(True)
     enc = g["encoder_hidden_states"].to(DEV).requires_grad_(True)
     out = model.bert(input_ids=g["t.input_ids"].to(DEV), attention_mask=g["t.attention_mask"].to(DEV),
