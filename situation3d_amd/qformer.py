@@ -114,27 +114,57 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
+def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id):
+    """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask."""
+    dev = x2.device
+    rows, cols = x2.shape
+    out = torch.empty_like(x2)
+    v = torch.empty_like(x2)
+    stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
+    mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
+    with torch.cuda.device(dev):
+        _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, ctypes.c_float(p_drop),
+                  ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
+                  _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
+                  _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
+                  _lib.stream_ptr(dev))
+    return out, v, stats, mask
+
+
+def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop):
+    """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
+    dparams = [d gamma | d beta | d bias]."""
+    rows, cols = v.shape
+    dx = torch.empty_like(v)
+    dres = torch.empty_like(v)
+    dparams = torch.empty((3, cols), dtype=torch.float32, device=v.device)
+    work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, ctypes.c_float(p_drop), _lib.ptr(dy2),
+                  _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
+                  _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work),
+                  _lib.stream_ptr(v.device))
+    return dx, dres, dparams
+
+
+def _colsum(t2):
+    o = torch.empty(t2.shape[1], dtype=torch.float32, device=t2.device)
+    with torch.cuda.device(t2.device):
+        _lib.call("sig3d_column_sum", t2.shape[0], t2.shape[1], _lib.ptr(t2), _lib.ptr(o),
+                  _lib.stream_ptr(t2.device))
+    return o
+
+
 class _DropoutAddLayerNormFn(torch.autograd.Function):
     """out = LayerNorm(dropout(x + bias) + residual): the tail of BertSelfOutput / BertOutput
     (Qformer.py:241-246, 323-328) as one kernel each way (csrc/rowops.hip)."""
 
     @staticmethod
     def forward(ctx, x, bias, residual, gamma, beta, p_drop, eps, call_id):
-        dev = x.device
         cols = x.shape[-1]
         x2 = x.reshape(-1, cols).contiguous()
         r2 = residual.reshape(-1, cols).contiguous()
-        rows = x2.shape[0]
-        out = torch.empty_like(x2)
-        v = torch.empty_like(x2)
-        stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
-        mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
-        with torch.cuda.device(dev):
-            _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, ctypes.c_float(p_drop),
-                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
-                      _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
-                      _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
-                      _lib.stream_ptr(dev))
+        out, v, stats, mask = _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id)
         ctx.save_for_backward(v, stats, gamma, mask)
         ctx.p_drop = p_drop
         ctx.shape = x.shape
@@ -144,16 +174,8 @@ class _DropoutAddLayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         v, stats, gamma, mask = ctx.saved_tensors
         rows, cols = v.shape
-        dy2 = dy.reshape(rows, cols).contiguous()
-        dx = torch.empty_like(v)
-        dres = torch.empty_like(v)
-        dparams = torch.empty((3, cols), dtype=torch.float32, device=v.device)
-        work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
-        with torch.cuda.device(v.device):
-            _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, ctypes.c_float(ctx.p_drop), _lib.ptr(dy2),
-                      _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
-                      _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work),
-                      _lib.stream_ptr(v.device))
+        dx, dres, dparams = _ln_tail_bwd(dy.reshape(rows, cols).contiguous(), v, stats, gamma, mask,
+                                         ctx.p_drop)
         return (dx.view(ctx.shape), dparams[2], dres.view(ctx.shape), dparams[0], dparams[1], None,
                 None, None)
 
@@ -299,6 +321,7 @@ class _ProjAttentionFn(torch.autograd.Function):
             kview, vview = kview.view(b, nk, hd), vview.view(b, nk, hd)
         kview, vview = kview.detach(), vview.detach()
         ctx.mark_non_differentiable(kview, vview)
+        ctx.set_materialize_grads(False)  # no zero-filled gradients for the key / value views
         return out, kview, vview
 
     @staticmethod
@@ -327,13 +350,7 @@ class _ProjAttentionFn(torch.autograd.Function):
                       _lib.ptr(grad_out), dqp, dkp, dvp, ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
 
-        def colsum(t2):
-            o = torch.empty(t2.shape[1], dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.call("sig3d_column_sum", t2.shape[0], t2.shape[1], _lib.ptr(t2), _lib.ptr(o),
-                          _lib.stream_ptr(dev))
-            return o
-
+        colsum = _colsum
         if self_attn:
             g_hidden = dproj.mm(w_all).view(hidden.shape)
             gw = dproj.t().mm(x2)          # (3*hd, c)
@@ -347,6 +364,118 @@ class _ProjAttentionFn(torch.autograd.Function):
         gwkv, gbkv = dkv.t().mm(e2), colsum(dkv)
         return (g_hidden, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:], None, None, None,
                 None, None)
+
+
+class _AttentionBlockFn(torch.autograd.Function):
+    """BertAttention as ONE autograd node on 2-D row matrices (Qformer.py:249-299):
+        LayerNorm(dropout(dense(attention(x, kv))) + x)
+    = _ProjAttentionFn + the BertSelfOutput tail.  Besides sparing autograd bookkeeping, the block
+    form lets the two gradient paths into x (residual and Q/K/V projections) meet inside a GEMM
+    epilogue (addmm with beta = 1) instead of an extra accumulate kernel, and hands no key/value
+    side outputs to autograd.  layout = (B, N, seg) as in _ProjAttentionFn (seg == N: plain)."""
+
+    @staticmethod
+    def forward(ctx, x, kv_src, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask, num_heads, p_attn,
+                p_hidden, eps, id_attn, id_out, layout):
+        x = x.contiguous()
+        dev = x.device
+        b, nq, seg = layout
+        hd = wq.shape[0]
+        d = hd // num_heads
+        scale = 1.0 / math.sqrt(d)
+        if kv_src is None:  # self-attention
+            w_all = _stacked((wq, wk, wv))
+            proj = torch.addmm(_stacked((bq, bk, bv)), x, w_all.t())      # (B*N, 3*hd)
+            qp, kp, vp, ldq, ldk, ldv, nk, kseg = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq, seg
+            kvproj, e2 = None, None
+        else:
+            nk = kv_src.shape[1]
+            kseg = nk
+            e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+            w_all = _stacked((wk, wv))
+            proj = torch.addmm(bq, x, wq.t())                             # (B*N, hd)
+            kvproj = torch.addmm(_stacked((bk, bv)), e2, w_all.t())       # (B*Nk, 2*hd)
+            qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
+        att = torch.empty((b * nq, hd), dtype=torch.float32, device=dev)
+        lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
+        if mask is not None:
+            mask = mask.contiguous()
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
+                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
+                      ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
+                      _lib.stream_ptr(dev))
+        y = att.mm(wo.t())
+        out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out)
+        ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)
+        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, kseg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep = ctx.saved_tensors
+        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, kseg = ctx.cfg
+        dev = x.device
+        d = hd // num_heads
+        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden)
+        gwo = dyo.t().mm(att)
+        datt = dyo.mm(wo)
+        self_attn = kv_src is None
+        dproj = torch.empty_like(proj)
+        if self_attn:
+            qp, kp, vp = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd)
+            dqp, dkp, dvp = _off(dproj, 0), _off(dproj, hd), _off(dproj, 2 * hd)
+            ldq = ldk = ldv = 3 * hd
+        else:
+            dkv = torch.empty_like(kvproj)
+            qp, kp, vp = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd)
+            dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
+            ldq, ldk, ldv = hd, 2 * hd, 2 * hd
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
+                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
+                      _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
+                      _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
+        tail = (gwo, dparams[2], dparams[0], dparams[1]) + (None,) * 8
+        if self_attn:
+            gx = torch.addmm(dres, dproj, w_all)       # residual + projection paths in one epilogue
+            gw = dproj.t().mm(x)                       # (3*hd, c)
+            gb = _colsum(dproj)
+            return (gx, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:]) + tail
+        e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+        gx = torch.addmm(dres, dproj, wq)
+        gwq, gbq = dproj.t().mm(x), _colsum(dproj)
+        g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
+        gwkv, gbkv = dkv.t().mm(e2), _colsum(dkv)
+        return (gx, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:]) + tail
+
+
+class _FFNBlockFn(torch.autograd.Function):
+    """BertIntermediate + BertOutput as ONE autograd node on a 2-D row matrix (Qformer.py:302-328):
+        LayerNorm(dropout(dense2(gelu(dense1(x)))) + x)
+    Library GEMMs + erf-GELU + the fused LayerNorm tail; in the backward pass the residual gradient
+    enters the dense1 input-gradient GEMM as its beta = 1 addend (no accumulate kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_drop, eps, call_id):
+        x = x.contiguous()
+        pre = torch.addmm(b1, x, w1.t())
+        act = torch.nn.functional.gelu(pre)
+        y = act.mm(w2.t())
+        out, v, stats, keep = _ln_tail_fwd(y, b2, x, gamma, beta, p_drop, eps, call_id)
+        ctx.save_for_backward(x, w1, w2, pre, act, v, stats, gamma, keep)
+        ctx.p_drop = p_drop
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pre, act, v, stats, gamma, keep = ctx.saved_tensors
+        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop)
+        gw2 = dyo.t().mm(act)
+        gpre = torch.ops.aten.gelu_backward(dyo.mm(w2), pre)
+        gw1 = gpre.t().mm(x)
+        gx = torch.addmm(dres, gpre, w1)
+        return gx, gw1, _colsum(gpre), gw2, dparams[2], dparams[0], dparams[1], None, None, None
 
 
 def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
@@ -464,14 +593,12 @@ class BertSelfAttention(nn.Module):
         return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
 
 
-def _segmented_self_attention(module, rows, attention_mask, batch, n_tokens, seg):
-    """BertSelfAttention over the two-segment row matrix (B*N, C) -> (B*N, H*64), same order."""
-    mask = _key_mask(attention_mask, batch, n_tokens)
-    p_drop = module.dropout.p if module.training else 0.0
-    return _ProjAttentionFn.apply(rows, None, module.query.weight, module.query.bias, module.key.weight,
-                                  module.key.bias, module.value.weight, module.value.bias, mask,
-                                  module.num_attention_heads, float(p_drop), module._call_id,
-                                  (batch, n_tokens, seg))[0]
+def _ffn_rows(intermediate, output, rows):
+    """BertIntermediate + BertOutput on a contiguous (rows, C) matrix as one autograd node."""
+    p = output.dropout.p if output.training else 0.0
+    return _FFNBlockFn.apply(rows, intermediate.dense.weight, intermediate.dense.bias, output.dense.weight,
+                             output.dense.bias, output.LayerNorm.weight, output.LayerNorm.bias, float(p),
+                             float(output.LayerNorm.eps), output._call_id)
 
 
 class BertSelfOutput(nn.Module):
@@ -504,9 +631,22 @@ class BertAttention(nn.Module):
                                  encoder_attention_mask, past_key_value, output_attentions)
         return (self.output(self_outputs[0], hidden_states),) + self_outputs[1:]
 
-    def forward_segmented(self, rows, attention_mask, batch, n_tokens, seg):
-        ctx = _segmented_self_attention(self.self, rows, attention_mask, batch, n_tokens, seg)
-        return self.output(ctx, rows)
+    def forward_rows(self, rows, attention_mask, layout, encoder_hidden_states=None,
+                     encoder_attention_mask=None):
+        """rows (B*N, C) in the token order `layout` = (B, N, seg) -> same shape and order."""
+        att, outp = self.self, self.output
+        batch, n_tokens, _ = layout
+        if encoder_hidden_states is not None:
+            mask = _key_mask(encoder_attention_mask, batch, encoder_hidden_states.shape[1])
+        else:
+            mask = _key_mask(attention_mask, batch, n_tokens)
+        p_attn = att.dropout.p if att.training else 0.0
+        p_hidden = outp.dropout.p if outp.training else 0.0
+        return _AttentionBlockFn.apply(
+            rows, encoder_hidden_states, att.query.weight, att.query.bias, att.key.weight, att.key.bias,
+            att.value.weight, att.value.bias, outp.dense.weight, outp.dense.bias, outp.LayerNorm.weight,
+            outp.LayerNorm.bias, mask, att.num_attention_heads, float(p_attn), float(p_hidden),
+            float(outp.LayerNorm.eps), att._call_id, outp._call_id, layout)
 
 
 class BertIntermediate(nn.Module):
@@ -596,17 +736,17 @@ class BertLayer(nn.Module):
         backward two views) -- where the (B, N, C) layout pays a strided copy per slice, per
         residual and per gradient (5 copies + 1 cat forward, ~2x that backward, per layer)."""
         rq = batch * query_length
-        attention_output = self.attention.forward_segmented(
-            rows, attention_mask, batch, query_length + text_length, query_length)
+        attention_output = self.attention.forward_rows(
+            rows, attention_mask, (batch, query_length + text_length, query_length))
         query_rows, text_rows = torch.split(attention_output, [rq, batch * text_length], dim=0)
         if self.has_cross_attention:
             assert encoder_hidden_states is not None, \
                 "encoder_hidden_states must be given for cross-attention layers"
-            query_rows = self.crossattention(
-                query_rows.view(batch, query_length, -1), None, None, encoder_hidden_states,
-                encoder_attention_mask)[0].reshape(rq, -1)
-        return torch.cat([self.feed_forward_chunk_query(query_rows),
-                          self.feed_forward_chunk(text_rows)], dim=0)
+            query_rows = self.crossattention.forward_rows(
+                query_rows, None, (batch, query_length, query_length), encoder_hidden_states,
+                encoder_attention_mask)
+        return torch.cat([_ffn_rows(self.intermediate_query, self.output_query, query_rows),
+                          _ffn_rows(self.intermediate, self.output, text_rows)], dim=0)
 
     def feed_forward_chunk(self, attention_output):
         return self.output(self.intermediate(attention_output), attention_output)
