@@ -438,12 +438,12 @@ class _AttentionBlockFn(torch.autograd.Function):
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
         tail = (gwo, dparams[2], dparams[0], dparams[1]) + (None,) * 8
         if self_attn:
-            gx = torch.addmm(dres, dproj, w_all)       # residual + projection paths in one epilogue
+            gx = dres.addmm_(dproj, w_all)             # residual + projection paths in one epilogue
             gw = dproj.t().mm(x)                       # (3*hd, c)
             gb = _colsum(dproj)
             return (gx, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:]) + tail
         e2 = kv_src.reshape(b * nk, kv_src.shape[2])
-        gx = torch.addmm(dres, dproj, wq)
+        gx = dres.addmm_(dproj, wq)
         gwq, gbq = dproj.t().mm(x), _colsum(dproj)
         g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
         gwkv, gbkv = dkv.t().mm(e2), _colsum(dkv)
@@ -474,7 +474,7 @@ class _FFNBlockFn(torch.autograd.Function):
         gw2 = dyo.t().mm(act)
         gpre = torch.ops.aten.gelu_backward(dyo.mm(w2), pre)
         gw1 = gpre.t().mm(x)
-        gx = torch.addmm(dres, gpre, w1)
+        gx = dres.addmm_(gpre, w1)   # in place: torch.addmm would first copy dres into a new result
         return gx, gw1, _colsum(gpre), gw2, dparams[2], dparams[0], dparams[1], None, None, None
 
 
