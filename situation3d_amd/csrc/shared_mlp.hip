@@ -220,12 +220,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long groups, int c
                                                               int *__restrict__ arg) {
   // 16 lanes (one DPP row) per group of S samples: coalesced 64-byte segments, row reduction.
   // groups are ordered (b, c, p): channel = (g / P) % c.
-  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  // 32-bit index math (the launcher checks groups < 2^31): a 64-bit divide costs more VALU work
+  // than the four loads this thread issues
+  const unsigned g = (blockIdx.x * 256u + threadIdx.x) >> 4;
   const int sub = threadIdx.x & 15;
-  const long gc = g < groups ? g : groups - 1;
-  const int ch = (int)((gc / P) % c);
+  const unsigned gc = g < (unsigned)groups ? g : (unsigned)groups - 1u;
+  const int ch = (int)((gc / (unsigned)P) % (unsigned)c);
   const float sc = scale[ch], sh = shift[ch];
-  const float *row = y + gc * S;
+  const float *row = y + (size_t)gc * S;
   float best = -1.f;  // relu output is >= 0, so any sample beats -1
   int bi = 0;
   for (int s = sub; s < S; s += 16) {
@@ -241,6 +243,43 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long groups, int c
   }
 }
 
+// nsample = 4*LPG (16 / 32 / 64, every level of the reference's backbones): one float4 per lane
+// and LPG lanes per group, so a group is ONE coalesced 16*LPG-byte segment read by a single load
+// instruction (the generic kernel above walks a group in S/16 dependent round trips).  Ties go to
+// the smaller sample index at every step: first maximum, like max_pool2d.
+template <int LPG>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_vec_kernel(unsigned groups, int c, int P,
+                                                                  const float *__restrict__ y,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift,
+                                                                  float *__restrict__ out,
+                                                                  int *__restrict__ arg) {
+  const unsigned tid = blockIdx.x * 256u + threadIdx.x;
+  const unsigned g = tid / LPG;
+  const int sub = (int)(tid % LPG);
+  const unsigned gc = g < groups ? g : groups - 1u;
+  const int ch = (int)((gc / (unsigned)P) % (unsigned)c);
+  const float sc = scale[ch], sh = shift[ch];
+  const float4 v = reinterpret_cast<const float4 *>(y + (size_t)gc * (4 * LPG))[sub];
+  const float r[4] = {fmaxf(0.f, v.x * sc + sh), fmaxf(0.f, v.y * sc + sh), fmaxf(0.f, v.z * sc + sh),
+                      fmaxf(0.f, v.w * sc + sh)};
+  float best = r[0];
+  int bi = 4 * sub;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (r[q] > best) { best = r[q]; bi = 4 * sub + q; }
+#pragma unroll
+  for (int off = 1; off < LPG; off <<= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (sub == 0 && g < groups) {
+    out[g] = best;
+    arg[g] = bi;
+  }
+}
+
 
 // ---- backward: BatchNorm(train) + ReLU ------------------------------------------------------
 // With z = y*scale + shift, a = relu(z), xhat = (y - mean)*invstd and upstream gradient dA:
@@ -248,15 +287,16 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long groups, int c
 //   dY = gamma*invstd * (dZ - S1/n - xhat*S2/n)
 // TOP = true: dA is not a dense tensor but the max-pool gradient, i.e. dOut[b,c,j] routed to the
 // arg-max sample of each group (and only where the pooled output is > 0).
+// `grow` = index of the first group of this (b, c) row, e = position inside the row (< 2^31)
 template <bool TOP>
 __device__ __forceinline__ float upstream_grad(const float *__restrict__ dA, const float *__restrict__ dOut,
-                                               const int *__restrict__ arg, size_t row, long e, int S,
-                                               long groups_per_row) {
+                                               const int *__restrict__ arg, size_t row, size_t grow,
+                                               unsigned e, unsigned S, int s_shift) {
   if (!TOP) return dA[row + e];
-  const long j = e / S;
+  // nsample is a power of two in every reference config: shift instead of a divide per element
+  const unsigned j = s_shift >= 0 ? e >> s_shift : e / S;
   const int s = (int)(e - j * S);
-  const size_t g = (row / ((size_t)groups_per_row * S)) * groups_per_row + j;
-  return (arg[g] == s) ? dOut[g] : 0.f;
+  return (arg[grow + j] == s) ? dOut[grow + j] : 0.f;
 }
 
 constexpr int BNB_THREADS = 256;
@@ -271,12 +311,14 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_kernel(
   __shared__ float red[2][BNB_THREADS / 64];
   const int ch = blockIdx.y, bi = blockIdx.z;
   const size_t row = ((size_t)bi * c + ch) * E;
+  const size_t grow = ((size_t)bi * c + ch) * (size_t)(E / S);
+  const int s_shift = (S & (S - 1)) == 0 ? __builtin_ctz(S) : -1;
   const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
-  const long e0 = (long)blockIdx.x * BNB_CHUNK, e1 = min(E, e0 + BNB_CHUNK);
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = (unsigned)min(E, (long)e0 + BNB_CHUNK);
   float a1 = 0.f, a2 = 0.f;
-  for (long e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
     const float yv = y[row + e];
-    const float g = upstream_grad<TOP>(dA, dOut, arg, row, e, S, E / S);
+    const float g = upstream_grad<TOP>(dA, dOut, arg, row, grow, e, (unsigned)S, s_shift);
     const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
     a1 += dz;
     a2 += dz * ((yv - mu) * is);
@@ -329,12 +371,58 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
     const double *__restrict__ s1, const double *__restrict__ s2, float *__restrict__ dY) {
   const int ch = blockIdx.y, bi = blockIdx.z;
   const size_t row = ((size_t)bi * c + ch) * E;
+  const size_t grow = ((size_t)bi * c + ch) * (size_t)(E / S);
+  const int s_shift = (S & (S - 1)) == 0 ? __builtin_ctz(S) : -1;
   const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
   const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
-  const long e0 = (long)blockIdx.x * BNB_CHUNK, e1 = min(E, e0 + BNB_CHUNK);
-  for (long e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = (unsigned)min(E, (long)e0 + BNB_CHUNK);
+  if (e1 - e0 == (unsigned)BNB_CHUNK && (E & 3) == 0 && (!TOP || (S & 3) == 0)) {
+    // full chunk: float4 per thread, all loads of the 8 iterations issued before the first use.
+    // TOP: the 4 positions of a float4 share one group (S % 4 == 0) -> ONE unconditional
+    // (arg, dOut) pair per float4, selected afterwards (a load under `arg == s ?` serialises).
+    constexpr int ITERS = BNB_CHUNK / 4 / BNB_THREADS;
+    const float4 *y4 = reinterpret_cast<const float4 *>(y + row + e0);
+    const float4 *a4 = TOP ? nullptr : reinterpret_cast<const float4 *>(dA + row + e0);
+    float4 *o4 = reinterpret_cast<float4 *>(dY + row + e0);
+    float4 yv[ITERS], g[ITERS];
+    int sel[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const unsigned q = it * BNB_THREADS + threadIdx.x;
+      yv[it] = y4[q];
+      if (TOP) {
+        const unsigned e = e0 + 4 * q;
+        const unsigned j = s_shift >= 0 ? e >> s_shift : e / (unsigned)S;
+        sel[it] = arg[grow + j] - (int)(e - j * (unsigned)S);  // 0..3: which lane of the float4
+        g[it].x = dOut[grow + j];
+      } else {
+        g[it] = a4[q];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const unsigned q = it * BNB_THREADS + threadIdx.x;
+      float4 gg = g[it];
+      if (TOP) {
+        const float d = g[it].x;
+        gg.x = sel[it] == 0 ? d : 0.f;
+        gg.y = sel[it] == 1 ? d : 0.f;
+        gg.z = sel[it] == 2 ? d : 0.f;
+        gg.w = sel[it] == 3 ? d : 0.f;
+      }
+      const float4 v = yv[it];
+      float4 o;
+      o.x = sc * (((v.x * sc + sh > 0.f) ? gg.x : 0.f) - m1 - (v.x - mu) * is * m2);
+      o.y = sc * (((v.y * sc + sh > 0.f) ? gg.y : 0.f) - m1 - (v.y - mu) * is * m2);
+      o.z = sc * (((v.z * sc + sh > 0.f) ? gg.z : 0.f) - m1 - (v.z - mu) * is * m2);
+      o.w = sc * (((v.w * sc + sh > 0.f) ? gg.w : 0.f) - m1 - (v.w - mu) * is * m2);
+      o4[q] = o;
+    }
+    return;
+  }
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
     const float yv = y[row + e];
-    const float g = upstream_grad<TOP>(dA, dOut, arg, row, e, S, E / S);
+    const float g = upstream_grad<TOP>(dA, dOut, arg, row, grow, e, (unsigned)S, s_shift);
     const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
     dY[row + e] = sc * (dz - m1 - (yv - mu) * is * m2);  // sc == gamma * invstd
   }
@@ -553,8 +641,19 @@ extern "C" int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y,
   SIG3D_REQUIRE(b >= 0 && c >= 1 && p >= 0 && s >= 1, "bad size");
   const long groups = (long)b * c * p;
   if (groups == 0) return 0;
-  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0,
-                     stream, groups, c, p, s, y, scale, shift, out, arg);
+  SIG3D_REQUIRE(groups < (1L << 27), "b*c*p must be below 2^27 (32-bit thread indexing)");
+  if (s == 64)
+    hipLaunchKernelGGL(bn_relu_maxpool_vec_kernel<16>, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256),
+                       0, stream, (unsigned)groups, c, p, y, scale, shift, out, arg);
+  else if (s == 32)
+    hipLaunchKernelGGL(bn_relu_maxpool_vec_kernel<8>, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256),
+                       0, stream, (unsigned)groups, c, p, y, scale, shift, out, arg);
+  else if (s == 16)
+    hipLaunchKernelGGL(bn_relu_maxpool_vec_kernel<4>, dim3((unsigned)((groups * 4 + 255) / 256)), dim3(256),
+                       0, stream, (unsigned)groups, c, p, y, scale, shift, out, arg);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0,
+                       stream, groups, c, p, s, y, scale, shift, out, arg);
   SIG3D_LAUNCH_CHECK("bn_relu_maxpool_kernel");
   return 0;
 }
@@ -570,6 +669,7 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
   SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && s >= 1, "bad size");
   SIG3D_REQUIRE((dA != nullptr) != (dOut != nullptr && arg != nullptr),
                 "pass either a dense dA or the (dOut, arg) pair of the max-pool");
+  SIG3D_REQUIRE(e < (1L << 31) && e % s == 0, "positions per row must be a multiple of s and < 2^31");
   if (s2 == s1 + c) {
     SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * 2 * c, stream));
   } else {

@@ -19,7 +19,8 @@ def _close(a, b, name, tol=1e-4):
 
 @pytest.mark.parametrize("b,chans,p,s", [(2, [6, 64, 64, 128], 100, 64), (3, [131, 128, 128, 256], 64, 32),
                                          (2, [259, 128, 128, 256], 33, 16), (1, [9, 32], 5, 7),
-                                         (2, [35, 64, 32], 17, 12)])
+                                         (2, [35, 64, 32], 17, 12),
+                                         (1, [6, 32, 64], 300, 64)])  # rows of 19200 positions: full 8192-chunks + tail
 def test_fused_mlp_max_matches_torch(b, chans, p, s):
     from situation3d_amd.pointnet2 import fused_mlp
     from situation3d_amd.pointnet2.pytorch_utils import SharedMLP
@@ -71,3 +72,27 @@ def test_fused_path_is_taken_by_sa_module_and_falls_back_in_eval():
     finally:
         fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS = orig, orig_min
     assert a.shape == bb.shape == (2, 64, 64)
+
+
+@pytest.mark.parametrize("s", [64, 32, 16, 24])
+def test_bn_relu_maxpool_first_maximum_on_ties(s):
+    """Ball-query padding repeats the first neighbour, so tied maxima are the common case: the arg-max
+    must be the FIRST maximal sample (F.max_pool2d semantics), the value max(relu(y*scale+shift))."""
+    import torch.nn.functional as F
+    from situation3d_amd import _lib as L
+    b, c, p = 2, 5, 37
+    g = torch.Generator().manual_seed(s)
+    y = torch.randn(b, c, p, s, generator=g)
+    y[..., s // 3:] = y[..., :1]            # padded tail = copies of sample 0
+    y[:, :, ::3, 1] = y[:, :, ::3, 0]       # and an early tie
+    scale = torch.tensor([1.0, 0.5, -1.0, 2.0, 1.0])
+    shift = torch.tensor([0.0, 0.1, 0.2, -50.0, 0.3])   # channel 3: everything below zero after BN
+    z = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    exp, idx = F.max_pool2d(z, [1, s], return_indices=True)     # CPU: first maximum
+    out = torch.empty(b, c, p, device=DEV)
+    arg = torch.empty(b, c, p, dtype=torch.int32, device=DEV)
+    yd, sd, hd = y.to(DEV), scale.to(DEV), shift.to(DEV)
+    L.call("sig3d_bn_relu_maxpool", b, c, p, s, L.ptr(yd), L.ptr(sd), L.ptr(hd), L.ptr(out), L.ptr(arg),
+           L.stream_ptr())
+    assert torch.equal(out.cpu(), exp.squeeze(-1))
+    assert torch.equal(arg.cpu().long(), idx.squeeze(-1) % s)

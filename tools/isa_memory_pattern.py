@@ -33,7 +33,7 @@ for ln in lines:
     elif t.startswith("v_mfma"): out.append("M")
     elif t.startswith("s_waitcnt") and "vmcnt" in t: out.append("W" + re.search(r"vmcnt\((\d+)\)", t).group(1))
     elif t.startswith("s_cbranch"): out.append("|")
-    elif t.startswith("s_endpgm"):
+    elif t.startswith(".Lfunc_end"):
         if filt in cur:
             s = "".join(out)
             s = re.sub(r"(L+)", lambda m: "L%d " % len(m.group(1)), s)
