@@ -29,12 +29,15 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
   const int l1 = min(l0 + GP_CSLAB, c);
   if (VEC4) {
     const int4 ii = *reinterpret_cast<const int4 *>(ip);
-    for (int l = l0; l < l1; ++l) {
-      const float *row = points + ((size_t)bi * c + l) * n;
-      float4 v;
-      v.x = row[ii.x]; v.y = row[ii.y]; v.z = row[ii.z]; v.w = row[ii.w];
-      *reinterpret_cast<float4 *>(out + ((size_t)bi * c + l) * total + e) = v;
+    float4 v[GP_CSLAB];
+#pragma unroll
+    for (int t = 0; t < GP_CSLAB; ++t) {  // gathers first (channel clamped), stores afterwards
+      const float *row = points + ((size_t)bi * c + min(l0 + t, c - 1)) * n;
+      v[t].x = row[ii.x]; v[t].y = row[ii.y]; v[t].z = row[ii.z]; v[t].w = row[ii.w];
     }
+#pragma unroll
+    for (int t = 0; t < GP_CSLAB; ++t)
+      if (l0 + t < l1) *reinterpret_cast<float4 *>(out + ((size_t)bi * c + l0 + t) * total + e) = v[t];
   } else {
     const int ii = *ip;
     for (int l = l0; l < l1; ++l)
@@ -103,17 +106,34 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_lds_kernel(
     } else {
       ii[0] = *ip;
     }
-    for (int l = 0; l < nl; ++l) {
-      const float *gp = grad_out + ((size_t)bi * c_total + c_off + l0 + l) * total + e;
-      float *row = s_acc + (size_t)l * n;
+    // four channels per round: their loads are issued together (unconditionally, channel index
+    // clamped) before the first ds_add -- one load -> wait -> atomics per channel made the kernel a
+    // chain of ~1.4 us round trips (0.6 TB/s at SA2, 64 workgroups x 128 rounds at SA4)
+    for (int l = 0; l < nl; l += 4) {
       if (VEC4) {
-        const float4 g = *reinterpret_cast<const float4 *>(gp);
-        atomicAdd(row + ii[0], g.x);
-        atomicAdd(row + ii[1], g.y);
-        atomicAdd(row + ii[2], g.z);
-        atomicAdd(row + ii[3], g.w);
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          g[u] = *reinterpret_cast<const float4 *>(
+              grad_out + ((size_t)bi * c_total + c_off + l0 + min(l + u, nl - 1)) * total + e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (l + u < nl) {
+            float *row = s_acc + (size_t)(l + u) * n;
+            atomicAdd(row + ii[0], g[u].x);
+            atomicAdd(row + ii[1], g[u].y);
+            atomicAdd(row + ii[2], g[u].z);
+            atomicAdd(row + ii[3], g[u].w);
+          }
+        }
       } else {
-        atomicAdd(row + ii[0], *gp);
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          g[u] = grad_out[((size_t)bi * c_total + c_off + l0 + min(l + u, nl - 1)) * total + e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (l + u < nl) atomicAdd(s_acc + (size_t)(l + u) * n + ii[0], g[u]);
       }
     }
   }
@@ -173,13 +193,23 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
     slab -= 1;
   }
   const int l0 = slab * GP_CSLAB;
-  const int l1 = min(l0 + GP_CSLAB, c);
   const int c_off = use_xyz ? 3 : 0;
-  for (int l = l0; l < l1; ++l) {
-    const float *row = features + ((size_t)bi * c + l) * n;
-    float *o = out + ((size_t)bi * c_total + c_off + l) * total + e;
-    if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(row[ii[0]], row[ii[1]], row[ii[2]], row[ii[3]]);
-    else *o = row[ii[0]];
+  // all GP_CSLAB x V gathers of the slab are issued before the first store (channel clamped, store
+  // predicated): 32 independent loads per lane instead of 4 per dependent round
+  float v[GP_CSLAB][V];
+#pragma unroll
+  for (int t = 0; t < GP_CSLAB; ++t) {
+    const float *row = features + ((size_t)bi * c + min(l0 + t, c - 1)) * n;
+#pragma unroll
+    for (int q = 0; q < V; ++q) v[t][q] = row[ii[q]];
+  }
+#pragma unroll
+  for (int t = 0; t < GP_CSLAB; ++t) {
+    if (l0 + t < c) {
+      float *o = out + ((size_t)bi * c_total + c_off + l0 + t) * total + e;
+      if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+      else *o = v[t][0];
+    }
   }
 }
 
@@ -212,13 +242,15 @@ static int launch_group_grad(int b, int c, int n, long total, int c_total, int c
   if (total > 0 && n <= GG_LDS_FLOATS) {
     int cslab = GG_LDS_FLOATS / n;
     if (cslab > c) cslab = c;
+    // narrower channel slabs (down to one 4-channel round) until >= 1024 workgroups exist: idx is
+    // re-read once per slab (4 B/element, cached), the flush traffic does not change
+    while (cslab > 4 && (long)sig3d_ceil_div(c, cslab) * b < 1024) cslab = (cslab / 2 + 3) / 4 * 4;
     const int slabs = sig3d_ceil_div(c, cslab);
-    // split the (npoints*nsample) range until the grid covers the chip (>= 512 workgroups),
-    // keeping at least 4 sweeps of the workgroup per block
+    // then split the (npoints*nsample) range, keeping at least 4 sweeps of the workgroup per block
     const long per_sweep = (long)GP_THREADS * (vec ? 4 : 1);
     long max_splits = total / (4 * per_sweep);
     if (max_splits < 1) max_splits = 1;
-    long splits = (512 + (long)slabs * b - 1) / ((long)slabs * b);
+    long splits = (1024 + (long)slabs * b - 1) / ((long)slabs * b);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long e_per_block = (total + splits - 1) / splits;
