@@ -28,6 +28,19 @@ constexpr int AT_D = 64;       // head size (Qformer.py:112: 768 / 12)
 constexpr int AT_WAVES = 4;    // waves per workgroup, each streams every 4th key tile
 constexpr int AT_NQ_MAX = 128; // backward keeps per-row statistics / dQ of one head in LDS
 
+// Phase timing for tools/attn_timing.py (compiled in only with -DSIG3D_ATTN_TIMING): workgroup
+// (0,0,0), lane 0 of the wave that passes a mark stores the 100 MHz real-time counter.
+#ifdef SIG3D_ATTN_TIMING
+__device__ unsigned long long g_at_marks[2][4][16];  // [fwd/bwd][wave][mark]
+#define AT_MARK(kind, id)                                                                   \
+  do {                                                                                      \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)   \
+      g_at_marks[kind][threadIdx.x >> 6][id] = __builtin_amdgcn_s_memrealtime();            \
+  } while (0)
+#else
+#define AT_MARK(kind, id) do { } while (0)
+#endif
+
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -114,7 +127,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const float *Q = q + hi * AT_D;
   const float *K = k + hi * AT_D;
   const float *V = v + hi * AT_D;
-  const float *M = mask ? mask + (size_t)bi * nk : nullptr;
+  // no mask: the (unconditional) mask loads read any valid address -- the K base -- and are dropped
+  const float *Mz = mask ? mask + (size_t)bi * nk : k;
+  const bool has_mask = mask != nullptr;
 
   float qf[32];
   load_half_row(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, nb), ldq, half, q0 + l31 < nq);
@@ -126,8 +141,21 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const int ntiles = (nk + 31) / 32;
   for (int t = wave; t < ntiles; t += AT_WAVES) {
     const int key0 = t * 32;
-    float kf[32];
+    // every global operand of this key tile is requested up front -- K rows, the 16 additive mask
+    // values and the 32 V^T operands of the PV product -- and the scheduler is fenced so that it
+    // cannot sink the loads down to their uses again (it did: 8 + 16 + 16 dependent round trips
+    // per tile, the whole kernel was load latency)
+    float kf[32], mk[16], va0[16], va1[16];
     load_half_row(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, nb), ldk, half, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(key0 + mfma_row(r, half), nk - 1);
+      mk[r] = Mz[key];
+      const long krow = tok_row(key, bi, nk, k_seg, nb);
+      va0[r] = V[krow * ldv + l31];
+      va1[r] = V[krow * ldv + 32 + l31];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 st = {0};
 #pragma unroll
     for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + mfma_row(r, half);
       float sv = st[r] * scale;                     // Qformer.py:207 (/ sqrt(64) == * 0.125)
-      if (M) sv += M[min(key, nk - 1)];             // Qformer.py:210
+      sv += has_mask ? mk[r] : 0.f;                 // Qformer.py:210
       sv = key < nk ? sv : -INFINITY;
       p[r] = sv;
       tmax = fmaxf(tmax, sv);
@@ -163,11 +191,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
-      const long key = tok_row(min(key0 + mfma_row(s, half), nk - 1), bi, nk, k_seg, nb);
-      const float a0 = V[key * ldv + l31];
-      const float a1 = V[key * ldv + 32 + l31];
-      o0 = mfma32(a0, p[s], o0);
-      o1 = mfma32(a1, p[s], o1);
+      o0 = mfma32(va0[s], p[s], o0);
+      o1 = mfma32(va1[s], p[s], o1);
     }
   }
 
@@ -213,11 +238,16 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: grid (key_splits, h, b), 256 threads.  A wave owns whole 32-key tiles, so dK / dV
-// are plain stores; dQ is reduced in LDS per workgroup (and with atomics across key splits).
+// backward: grid (key_splits, h, b), 256 threads.  Work items are (32-key tile, 32-query tile)
+// pairs.  With >= 4 key tiles per workgroup a wave owns whole key tiles (dK / dV are plain stores
+// from its accumulators); with fewer (self-attention: 52 keys = 2 tiles) the query tiles of a key
+// tile are spread over the otherwise idle waves and their dK / dV partials meet in LDS.
+// dQ: every wave accumulates into its OWN LDS image (plain read-modify-write around the dQ MFMAs,
+// no zero fill: first visit starts from 0) and the images are summed once at the end --
+// ds_add_f32 from four waves onto one image cost 9 us of a 27 us launch (tools/attn_timing.py).
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int ldq, int ldk, int ldv, float scale,
-    int tiles_per_split, int atomic_dq, float p_drop,
+    int tiles_per_split, int atomic_dq, int qsplit_max, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
@@ -226,7 +256,13 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   __shared__ float s_D[AT_NQ_MAX];
   __shared__ float s_lse[AT_NQ_MAX];
   __shared__ float s_T[AT_WAVES][32][33];
-  __shared__ float s_dq[AT_NQ_MAX][AT_D + 1];
+  // dynamic: dQ images [AT_WAVES][nq_pad][AT_D + 1], then (qsplit_max == 2 only) the dK/dV
+  // partials of the q-split mode [2 key slots][64 regs][64 lanes]
+  extern __shared__ __attribute__((aligned(16))) float s_dq[];
+  const int nq_pad = (nq + 31) / 32 * 32;
+  auto dq_img = [&](int w, int qq, int d) -> float & { return s_dq[((size_t)w * nq_pad + qq) * (AT_D + 1) + d]; };
+  float *s_red = s_dq + (size_t)AT_WAVES * nq_pad * (AT_D + 1);
+  auto red = [&](int sl, int r, int ln) -> float & { return s_red[(sl * 64 + r) * 64 + ln]; };
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -242,6 +278,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, nb); };
   auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, nb); };
 
+  AT_MARK(1, 0);
   // D[q] = sum_d dO[q][d] * O[q][d]; two threads per row
   {
     const int qq = threadIdx.x >> 1, hh = threadIdx.x & 1;
@@ -260,34 +297,65 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       s_D[qq] = qq < nq ? part : 0.f;
       s_lse[qq] = qq < nq ? lse[bh * nq + qq] : 0.f;
     }
-    for (int i = threadIdx.x; i < AT_NQ_MAX * (AT_D + 1); i += AT_WAVES * 64) (&s_dq[0][0])[i] = 0.f;
   }
   __syncthreads();
+  AT_MARK(1, 1);
 
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const int ntiles = (nk + 31) / 32;
   const int t_begin = blockIdx.x * tiles_per_split;
   const int t_end = min(ntiles, t_begin + tiles_per_split);
   const int nqt = (nq + 31) / 32;
+  // work assignment (uniform per wave): key slot = wave % nslots, query part = wave / nslots
+  const int nt = t_end - t_begin;
+  const int nslots = nt >= AT_WAVES ? AT_WAVES : max(nt, 1);
+  const int qsplit = nt >= AT_WAVES ? 1 : min(nqt, min(AT_WAVES / nslots, qsplit_max));
+  const int slot = wave % nslots, qpart = wave / nslots;
+  const bool active = qpart < qsplit;
+  unsigned visited = 0;  // bit qt: this wave's dQ image holds q-tile qt
+  f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
 
-  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+  for (int t = t_begin + slot; active && t < t_end; t += nslots) {
     const int key0 = t * 32;
     const int krow = min(key0 + l31, nk - 1);
     const bool key_ok = key0 + l31 < nk;
-    float kf[32], vf[32];
+    float kf[32], vf[32], kop0[16], kop1[16];
     load_half_row(kf, K, krow_of(krow), ldk, half, true);
     load_half_row(vf, V, krow_of(krow), ldv, half, true);
     const float mk = M ? M[krow] : 0.f;
-    f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {  // K^T operands of the dQ product: fixed for the whole key tile
+      const long key = krow_of(min(key0 + mfma_row(s, half), nk - 1));
+      kop0[s] = K[key * ldk + l31];
+      kop1[s] = K[key * ldk + 32 + l31];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dvt0[r] = dvt1[r] = dkt0[r] = dkt1[r] = 0.f;
+    AT_MARK(1, 2);
 
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = qpart; qt < nqt; qt += qsplit) {
       const int q0 = qt * 32;
-      float fr[32];
+      // all global operands of this (key tile, query tile) pair are requested before the first MFMA
+      // and the scheduler is fenced (see the forward kernel): Q and dO rows for S and dP, and the
+      // transposed dO / Q operands of the dV / dK products
+      float fr[32], fdo[32], g0[16], g1[16], x0[16], x1[16];
       const long my_qrow = qrow(min(q0 + l31, nq - 1));
       load_half_row(fr, Q, my_qrow, ldq, half, q0 + l31 < nq);
+      load_half_row(fdo, dO, my_qrow, ostride, half, q0 + l31 < nq);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const long qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
+        g0[s] = dO[qq * ostride + l31];
+        g1[s] = dO[qq * ostride + 32 + l31];
+        x0[s] = Q[qq * ldq + l31];
+        x1[s] = Q[qq * ldq + 32 + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      AT_MARK(1, 3);
       f32x16 sacc = {0};
 #pragma unroll
       for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
+      AT_MARK(1, 4);
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -295,10 +363,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq, AT_NQ_MAX - 1)]);
         p[r] = (key_ok && qq < nq) ? e : 0.f;
       }
-      load_half_row(fr, dO, my_qrow, ostride, half, q0 + l31 < nq);
       f32x16 dpacc = {0};
 #pragma unroll
-      for (int s = 0; s < 32; ++s) dpacc = mfma32(fr[s], vf[s], dpacc);  // dP[q][key]
+      for (int s = 0; s < 32; ++s) dpacc = mfma32(fdo[s], vf[s], dpacc);  // dP[q][key]
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -314,42 +381,47 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
           ds[r] = p[r] * (dp - s_D[min(qq, AT_NQ_MAX - 1)]);
         }
       }
+      AT_MARK(1, 5);
       // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const long qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
-        const float g0 = dO[qq * ostride + l31], g1 = dO[qq * ostride + 32 + l31];
-        const float x0 = Q[qq * ldq + l31], x1 = Q[qq * ldq + 32 + l31];
-        dvt0 = mfma32(g0, p[s], dvt0);
-        dvt1 = mfma32(g1, p[s], dvt1);
-        dkt0 = mfma32(x0, ds[s], dkt0);
-        dkt1 = mfma32(x1, ds[s], dkt1);
+        dvt0 = mfma32(g0[s], p[s], dvt0);
+        dvt1 = mfma32(g1[s], p[s], dvt1);
+        dkt0 = mfma32(x0[s], ds[s], dkt0);
+        dkt1 = mfma32(x1[s], ds[s], dkt1);
       }
+      AT_MARK(1, 6);
       // dQ^T[d][q] = K^T[d][key] dS^T[key][q]: transpose the dS tile through wave-private LDS
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_T[wave][l31][mfma_row(r, half)] = ds[r];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       f32x16 dqt0 = {0}, dqt1 = {0};
+      if ((visited >> qt) & 1u) {  // continue this wave's running dQ of the q-tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dqt0[r] = dq_img(wave, q0 + l31, mfma_row(r, half));
+          dqt1[r] = dq_img(wave, q0 + l31, 32 + mfma_row(r, half));
+        }
+      }
+      visited |= 1u << qt;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int kk = mfma_row(s, half);
-        const long key = krow_of(min(key0 + kk, nk - 1));
-        const float bq = s_T[wave][kk][l31];
-        dqt0 = mfma32(K[key * ldk + l31], bq, dqt0);
-        dqt1 = mfma32(K[key * ldk + 32 + l31], bq, dqt1);
+        const float bq = s_T[wave][mfma_row(s, half)][l31];
+        dqt0 = mfma32(kop0[s], bq, dqt0);
+        dqt1 = mfma32(kop1[s], bq, dqt1);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      if (q0 + l31 < nq) {
+      AT_MARK(1, 7);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          atomicAdd(&s_dq[q0 + l31][mfma_row(r, half)], dqt0[r]);
-          atomicAdd(&s_dq[q0 + l31][32 + mfma_row(r, half)], dqt1[r]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        dq_img(wave, q0 + l31, mfma_row(r, half)) = dqt0[r];
+        dq_img(wave, q0 + l31, 32 + mfma_row(r, half)) = dqt1[r];
       }
+      AT_MARK(1, 8);
     }
-    if (key_ok) {
+    if (key_ok && qsplit == 1) {
       float *dvp = dv + krow_of(key0 + l31) * ldv + hi * AT_D;  // grads mirror the inputs
       float *dkp = dk + krow_of(key0 + l31) * ldk + hi * AT_D;
 #pragma unroll
@@ -362,17 +434,70 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       }
     }
   }
+  AT_MARK(1, 9);
+  if (qsplit > 1) {
+    // q-split mode (at most one key tile per wave): the part-1 wave of a key slot parks its dK / dV
+    // accumulators in LDS, the part-0 wave adds them and stores
+    if (active && qpart == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red(slot, r, lane) = dvt0[r];
+        red(slot, 16 + r, lane) = dvt1[r];
+        red(slot, 32 + r, lane) = dkt0[r];
+        red(slot, 48 + r, lane) = dkt1[r];
+      }
+    }
+    __syncthreads();
+    const int key0 = (t_begin + slot) * 32;
+    if (active && qpart == 0 && t_begin + slot < t_end && key0 + l31 < nk) {
+      float *dvp = dv + krow_of(key0 + l31) * ldv + hi * AT_D;
+      float *dkp = dk + krow_of(key0 + l31) * ldk + hi * AT_D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * half;
+        float a[4], b2[4], c[4], e[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          a[i] = dvt0[r] + red(slot, r, lane);
+          b2[i] = dvt1[r] + red(slot, 16 + r, lane);
+          c[i] = (dkt0[r] + red(slot, 32 + r, lane)) * scale;
+          e[i] = (dkt1[r] + red(slot, 48 + r, lane)) * scale;
+        }
+        *reinterpret_cast<float4 *>(dvp + d) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4 *>(dvp + 32 + d) = make_float4(b2[0], b2[1], b2[2], b2[3]);
+        *reinterpret_cast<float4 *>(dkp + d) = make_float4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<float4 *>(dkp + 32 + d) = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
   __syncthreads();
+  AT_MARK(1, 10);
   for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
     const int qq = i / AT_D, d = i % AT_D;
-    const float val = s_dq[qq][d] * scale;
+    const int qt = qq >> 5;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < AT_WAVES; ++w) {  // waves whose image holds this q-tile (same rule as above)
+      const int wslot = w % nslots, wpart = w / nslots;
+      const bool has = wpart < qsplit && t_begin + wslot < t_end && (qt % qsplit) == wpart;
+      if (has) acc += dq_img(w, qq, d);
+    }
+    const float val = acc * scale;
     float *dst = dq + qrow(qq) * ldq + hi * AT_D + d;
     if (atomic_dq) unsafeAtomicAdd(dst, val);
     else *dst = val;
   }
+  AT_MARK(1, 11);
 }
 
 }  // namespace
+
+#ifdef SIG3D_ATTN_TIMING
+extern "C" int sig3d_debug_attention_marks(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_at_marks), sizeof(unsigned long long) * 2 * 4 * 16);
+}
+#endif
 
 extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq,
                                    int ldk, int ldv, float scale, const float *q, const float *k, const float *v,
@@ -426,9 +551,18 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
     SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D, (size_t)b * nq, stream));
   dim3 grid(splits, h, b);
-  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
+  const int nq_pad = (nq + 31) / 32 * 32;
+  const int qsplit_max = nq_pad <= 64 ? 2 : 1;  // LDS budget: images (+ 32 KiB of dK/dV partials)
+  const size_t lds = sizeof(float) * (AT_WAVES * (size_t)nq_pad * (AT_D + 1) + (qsplit_max == 2 ? 2 * 64 * 64 : 0));
+  static bool attr_done = false;
+  if (!attr_done) {
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
                      ldq, ldk, ldv, scale,
-                     tiles_per_split, splits > 1 ? 1 : 0, p_drop, call_id, rng_counter, q, k, v, mask,
+                     tiles_per_split, splits > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
                      out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
   return 0;
