@@ -48,8 +48,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // lane (row = l31, half) <- 32 contiguous floats base[row*stride + half*32 ...]; zero when !valid
-__device__ __forceinline__ void load_half_row(float (&f)[32], const float *base, long row,
-                                              long stride, int half, bool valid) {
+__device__ __forceinline__ void load_half_row(float (&f)[32], const float *base, unsigned row,
+                                              unsigned stride, int half, bool valid) {
   if (valid) {
     const float4 *p = reinterpret_cast<const float4 *>(base + row * stride + half * 32);
 #pragma unroll
@@ -70,8 +70,11 @@ __device__ __forceinline__ void load_half_row(float (&f)[32], const float *base,
 // The Q-Former keeps [all query tokens | all text tokens] in that order (qformer.py): the query /
 // text split of BertLayer.forward (Qformer.py:375-405) is then a pair of contiguous row ranges
 // instead of strided slices that must be copied for the feed-forward GEMMs.
-__device__ __forceinline__ long tok_row(int i, int bi, int n, int seg, int nb) {
-  return i < seg ? (long)bi * seg + i : (long)nb * seg + (long)bi * (n - seg) + (i - seg);
+// 32-bit on purpose (the launchers check rows * stride < 2^31): the kernels form ~60 operand
+// addresses per tile, and 64-bit row * stride products made address arithmetic cost as much as the
+// memory round trip itself (2 us per tile phase, tools/attn_timing.py).
+__device__ __forceinline__ unsigned tok_row(int i, int bi, int n, int seg, int nb) {
+  return (unsigned)(i < seg ? bi * seg + i : nb * seg + bi * (n - seg) + (i - seg));
 }
 
 // Attention-probability dropout (Qformer.py:219, nn.Dropout on the softmax output): the keep bit
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     for (int r = 0; r < 16; ++r) {
       const int key = min(key0 + mfma_row(r, half), nk - 1);
       mk[r] = Mz[key];
-      const long krow = tok_row(key, bi, nk, k_seg, nb);
-      va0[r] = V[krow * ldv + l31];
-      va1[r] = V[krow * ldv + 32 + l31];
+      const unsigned voff = tok_row(key, bi, nk, k_seg, nb) * (unsigned)ldv + l31;
+      va0[r] = V[voff];
+      va1[r] = V[voff + 32];
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 st = {0};
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
         res[i] = acc * inv;
       }
       // context_layer.permute(0,2,1,3).view(B, Nq, 768)  (Qformer.py:225-227)
-      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, nb) * (long)(h * AT_D) + hi * AT_D + dg * 8;
+      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, nb) * (unsigned)(h * AT_D) + hi * AT_D + dg * 8;
       *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
       *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
       if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int hi = blockIdx.y, bi = blockIdx.z, nb = gridDim.z;
   const size_t bh = (size_t)(bi * h + hi);
-  const long ostride = (long)h * AT_D;  // out / grad_out are dense rows of h*d floats
+  const unsigned ostride = (unsigned)h * AT_D;  // out / grad_out are dense rows of h*d floats
   const float *Q = q + hi * AT_D;       // storage row r at Q + r*ldq, r = tok_row(token, batch)
   const float *K = k + hi * AT_D;
   const float *V = v + hi * AT_D;
@@ -325,9 +328,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     const float mk = M ? M[krow] : 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // K^T operands of the dQ product: fixed for the whole key tile
-      const long key = krow_of(min(key0 + mfma_row(s, half), nk - 1));
-      kop0[s] = K[key * ldk + l31];
-      kop1[s] = K[key * ldk + 32 + l31];
+      const unsigned koff = krow_of(min(key0 + mfma_row(s, half), nk - 1)) * (unsigned)ldk + l31;
+      kop0[s] = K[koff];
+      kop1[s] = K[koff + 32];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) dvt0[r] = dvt1[r] = dkt0[r] = dkt1[r] = 0.f;
@@ -339,16 +342,17 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       // and the scheduler is fenced (see the forward kernel): Q and dO rows for S and dP, and the
       // transposed dO / Q operands of the dV / dK products
       float fr[32], fdo[32], g0[16], g1[16], x0[16], x1[16];
-      const long my_qrow = qrow(min(q0 + l31, nq - 1));
+      const unsigned my_qrow = qrow(min(q0 + l31, nq - 1));
       load_half_row(fr, Q, my_qrow, ldq, half, q0 + l31 < nq);
       load_half_row(fdo, dO, my_qrow, ostride, half, q0 + l31 < nq);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const long qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
-        g0[s] = dO[qq * ostride + l31];
-        g1[s] = dO[qq * ostride + 32 + l31];
-        x0[s] = Q[qq * ldq + l31];
-        x1[s] = Q[qq * ldq + 32 + l31];
+        const unsigned qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
+        const unsigned goff = qq * ostride + l31, xoff = qq * (unsigned)ldq + l31;
+        g0[s] = dO[goff];
+        g1[s] = dO[goff + 32];
+        x0[s] = Q[xoff];
+        x1[s] = Q[xoff + 32];
       }
       __builtin_amdgcn_sched_barrier(0);
       AT_MARK(1, 3);
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       AT_MARK(1, 8);
     }
     if (key_ok && qsplit == 1) {
-      float *dvp = dv + krow_of(key0 + l31) * ldv + hi * AT_D;  // grads mirror the inputs
-      float *dkp = dk + krow_of(key0 + l31) * ldk + hi * AT_D;
+      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * AT_D;  // grads mirror the inputs
+      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * AT_D;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
         const int d = 8 * g + 4 * half;
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     __syncthreads();
     const int key0 = (t_begin + slot) * 32;
     if (active && qpart == 0 && t_begin + slot < t_end && key0 + l31 < nk) {
-      float *dvp = dv + krow_of(key0 + l31) * ldv + hi * AT_D;
-      float *dkp = dk + krow_of(key0 + l31) * ldk + hi * AT_D;
+      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * AT_D;
+      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * AT_D;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 8 * g + 4 * half;
@@ -473,20 +477,28 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   }
   __syncthreads();
   AT_MARK(1, 10);
-  for (int i = threadIdx.x; i < nq * AT_D; i += AT_WAVES * 64) {
-    const int qq = i / AT_D, d = i % AT_D;
+  // sum the waves' images: 4 consecutive features per thread, all LDS reads issued before the adds
+  for (int it = threadIdx.x; it < nq * (AT_D / 4); it += AT_WAVES * 64) {
+    const int qq = it >> 4, d = (it & 15) * 4;
     const int qt = qq >> 5;
-    float acc = 0.f;
+    float part[AT_WAVES][4];
 #pragma unroll
     for (int w = 0; w < AT_WAVES; ++w) {  // waves whose image holds this q-tile (same rule as above)
       const int wslot = w % nslots, wpart = w / nslots;
       const bool has = wpart < qsplit && t_begin + wslot < t_end && (qt % qsplit) == wpart;
-      if (has) acc += dq_img(w, qq, d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[w][i] = has ? dq_img(w, qq, d + i) : 0.f;
     }
-    const float val = acc * scale;
-    float *dst = dq + qrow(qq) * ldq + hi * AT_D + d;
-    if (atomic_dq) unsafeAtomicAdd(dst, val);
-    else *dst = val;
+    float val[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) val[i] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) * scale;
+    float *dst = dq + qrow(qq) * (unsigned)ldq + hi * AT_D + d;
+    if (atomic_dq) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, val[i]);
+    } else {
+      *reinterpret_cast<float4 *>(dst) = make_float4(val[0], val[1], val[2], val[3]);
+    }
   }
   AT_MARK(1, 11);
 }
@@ -512,6 +524,8 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
                 "row strides must be >= h*d and multiples of 4 floats");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
+  SIG3D_REQUIRE((long)b * nq * ldq < (1L << 31) && (long)b * nk * ldk < (1L << 31) && (long)b * nk * ldv < (1L << 31),
+                "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
   dim3 grid((nq + 31) / 32, h, b);
   hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
                      ldq, ldk, ldv, scale,
@@ -534,6 +548,8 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
+  SIG3D_REQUIRE((long)b * nq * ldq < (1L << 31) && (long)b * nk * ldk < (1L << 31) && (long)b * nk * ldv < (1L << 31),
+                "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
   const int ntiles = (nk + 31) / 32;
   // enough workgroups to cover the chip, but at least AT_WAVES tiles per workgroup
   int splits = 1;
