@@ -22,6 +22,8 @@
 // Layout: activations (B, C, E) with E = npoint*nsample contiguous -- the reference's
 // (B, C, npoint, nsample).  MFMA map: rows (M) = output channels, cols (N) = 32 positions (one
 // per lane&31), K = input channels; C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#include <cstdlib>
+
 #include "sig3d_common.h"
 
 namespace {
@@ -30,6 +32,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ML_WAVES = 4;  // waves per workgroup, one 32-position tile each per sweep
 constexpr int ML_KC = 16;    // K-steps (of 2 input channels) per software-pipeline chunk
+constexpr int ML_TRLD = 36;  // row stride of the epilogue transpose buffer (16-byte aligned rows)
+
+// Phase timing for tools/mlp_timing.py (only with -DSIG3D_MLP_TIMING): wave 0 of workgroup
+// (0,0,0) appends the 100 MHz real-time counter at every mark.
+#ifdef SIG3D_MLP_TIMING
+__device__ unsigned long long g_ml_marks[64];
+__device__ int g_ml_nmarks;
+#define ML_MARK(id)                                                                              \
+  do {                                                                                           \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {             \
+      const int n_ = g_ml_nmarks;                                                                \
+      if (n_ < 64) { g_ml_marks[n_] = ((unsigned long long)(id) << 56) | __builtin_amdgcn_s_memrealtime(); g_ml_nmarks = n_ + 1; } \
+    }                                                                                            \
+  } while (0)
+#else
+#define ML_MARK(id) do { } while (0)
+#endif
 
 __device__ __forceinline__ int mrow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -71,16 +90,28 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int co0 = blockIdx.x * CT;
   const int bi = blockIdx.z;
+  float *s_tr = s_red + ML_WAVES * 2 * CT + wave * (16 * ML_TRLD);  // [ML_WAVES][16][ML_TRLD], wave-private
 
-  for (int i = threadIdx.x; i < CT * kpad; i += ML_WAVES * 64) {
-    const int r = i / kpad, c = i % kpad;
-    s_w[r * ldw + c] = (c < cin && co0 + r < cout) ? w[(size_t)(co0 + r) * cin + c] : 0.f;
+  ML_MARK(0);
+  // weight tile -> LDS: a wave takes 8 rows at a time and issues their (clamped, unconditional)
+  // loads together; one load -> wait -> ds_write per element took 20 us per workgroup at 128x128
+  for (int r0 = wave * 8; r0 < CT; r0 += ML_WAVES * 8) {
+    for (int c = lane; c < kpad; c += 64) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = w[(size_t)min(co0 + r0 + j, cout - 1) * cin + min(c, cin - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        s_w[(r0 + j) * ldw + c] = (c < cin && co0 + r0 + j < cout) ? v[j] : 0.f;
+    }
   }
   for (int i = threadIdx.x; i < kpad; i += ML_WAVES * 64) {
     s_ps[i] = (PROLOGUE && i < cin) ? pscale[i] : 1.f;
     s_pb[i] = (PROLOGUE && i < cin) ? pshift[i] : 0.f;
   }
   __syncthreads();
+  ML_MARK(1);
 
   const float *xb = x + (size_t)bi * cin * E;
   float *yb = y + (size_t)bi * cout * E;
@@ -89,47 +120,57 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 
   const int nchunks = kpad / (2 * ML_KC);
-  const long chunk = (long)ML_WAVES * 32 * tiles_per_wave;
-  const long e_begin = (long)blockIdx.y * chunk;
-  for (int t = 0; t < tiles_per_wave; ++t) {
-    const long e0 = e_begin + ((long)t * ML_WAVES + wave) * 32;
-    if (e0 >= E) break;
-    const long e = e0 + l31;
-    const float *xe = xb + (e < E ? e : E - 1);
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
+  // Tiles of 32 positions are dealt round-robin over all waves of the (batch, channel-block) row
+  // of the grid: wave-global index wg = blockIdx.y*ML_WAVES + wave owns tiles wg, wg + stride, ...
+  // The launcher sizes gridDim.y so that the grid is ONE full round of resident workgroups
+  // (weights staged once per workgroup, no tail round, neighbouring waves stream neighbouring tiles).
+  const long n_tiles = (E + 31) / 32;
+  const long tile0 = (long)blockIdx.y * ML_WAVES + wave;
+  const long tile_stride = (long)gridDim.y * ML_WAVES;
+  int my_tiles = 0;
+  for (int t = 0; t < tiles_per_wave; ++t)
+    if (tile0 + (long)t * tile_stride < n_tiles) my_tiles = t + 1;
+  auto e0_of = [&](int t) { return (tile0 + (long)t * tile_stride) * 32; };
+  // The wave's work is ONE stream of (tile, K-chunk) items g = tile*nchunks + chunk with the
+  // operand loads running TWO items ahead of the MFMAs, across tile boundaries: a chunk is only
+  // ~0.9-1.7 us of MFMA work while a load takes ~2 us to return, and the first chunk of every
+  // tile used to be fetched with nothing to overlap it (MFMA pipe < 50 % busy at SA2).
+  const int total = my_tiles * nchunks;
+  f32x16 acc[NT];
 
-    auto load_chunk = [&](float (&buf)[ML_KC], int c) {
+  auto issue = [&](float (&buf)[ML_KC], int g) {
+    const int t = g / nchunks, c = g - t * nchunks;
+    // 32-bit offsets from the uniform batch base (launcher: cin*E, cout*E < 2^31): one VGPR and
+    // one multiply-add per address instead of a 64-bit pair
+    const long e = e0_of(t) + l31;
+    const unsigned eo = (unsigned)(e < E ? e : E - 1);
 #pragma unroll
-      for (int i = 0; i < ML_KC; ++i) {
-        const int k = (c * ML_KC + i) * 2 + half;
-        buf[i] = xe[(size_t)min(k, cin - 1) * E];
-      }
-    };
-    auto mma_chunk = [&](const float (&buf)[ML_KC], int c) {
-#pragma unroll
-      for (int i = 0; i < ML_KC; ++i) {
-        const int k = (c * ML_KC + i) * 2 + half;
-        float a = buf[i];
-        if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
-        a = (k < cin) ? a : 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
-      }
-    };
-    float bufa[ML_KC], bufb[ML_KC];
-    load_chunk(bufa, 0);
-    for (int c = 0; c < nchunks; c += 2) {
-      if (c + 1 < nchunks) load_chunk(bufb, c + 1);
-      mma_chunk(bufa, c);
-      if (c + 1 < nchunks) {
-        if (c + 2 < nchunks) load_chunk(bufa, c + 2);
-        mma_chunk(bufb, c + 1);
-      }
+    for (int i = 0; i < ML_KC; ++i) {
+      const int k = (c * ML_KC + i) * 2 + half;
+      buf[i] = xb[(unsigned)min(k, cin - 1) * (unsigned)E + eo];
     }
+  };
+  auto consume = [&](const float (&buf)[ML_KC], int g) {
+    const int t = g / nchunks, c = g - t * nchunks;
+    ML_MARK(2);
+    if (c == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
+    }
+#pragma unroll
+    for (int i = 0; i < ML_KC; ++i) {
+      const int k = (c * ML_KC + i) * 2 + half;
+      float a = buf[i];
+      if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
+      a = (k < cin) ? a : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
+    }
+    ML_MARK(3);
+    if (c != nchunks - 1) return;
     // epilogue: acc[nt][4g..4g+3] = positions e0 + 8g + 4*half + (0..3) of channel co0+32nt+l31
+    const long e0 = e0_of(t);
     const bool full = e0 + 32 <= E;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -137,24 +178,71 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
       if (co < cout) {
         float *yrow = yb + (size_t)co * E + e0 + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v0 = acc[nt][4 * g], v1 = acc[nt][4 * g + 1], v2 = acc[nt][4 * g + 2], v3 = acc[nt][4 * g + 3];
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float v0 = acc[nt][4 * g4], v1 = acc[nt][4 * g4 + 1], v2 = acc[nt][4 * g4 + 2], v3 = acc[nt][4 * g4 + 3];
           if (VEC && full) {
-            *reinterpret_cast<float4 *>(yrow + 8 * g) = make_float4(v0, v1, v2, v3);
             s1[nt] += (v0 + v1) + (v2 + v3);
             s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
           } else {
             const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (e0 + 8 * g + 4 * half + q < E) {
-                yrow[8 * g + q] = vv[q];
+              if (e0 + 8 * g4 + 4 * half + q < E) {
+                yrow[8 * g4 + q] = vv[q];
                 s1[nt] += vv[q];
                 s2[nt] += vv[q] * vv[q];
               }
           }
         }
       }
+    }
+    if (VEC && full) {
+      // Stores through a wave-private LDS transpose.  In the accumulator layout a lane owns ONE
+      // channel row, so a direct store instruction scatters 64 separate 16-byte pieces over 64
+      // rows and every 128-byte line of y is assembled from 8 partial writes (2.9 TB/s at SA1
+      // L3, epilogues of up to 12 us).  Transposed, 8 lanes write one complete 128-byte row
+      // segment and an instruction covers 8 full lines.
+      const int trow = lane >> 3, tcol = (lane & 7) * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int hrow = 0; hrow < 2; ++hrow) {  // 16 channel rows per pass
+          if ((l31 >> 4) == hrow) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_tr[(l31 & 15) * ML_TRLD + mrow(r, half)] = acc[nt][r];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = trow + 8 * j;
+            const int co = co0 + nt * 32 + hrow * 16 + row;
+            const float4 v = *reinterpret_cast<const float4 *>(s_tr + row * ML_TRLD + tcol);
+            if (co < cout) *reinterpret_cast<float4 *>(yb + ((unsigned)co * (unsigned)E + (unsigned)e0 + tcol)) = v;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+      }
+    }
+    ML_MARK(4);
+  };
+
+  float b0[ML_KC], b1[ML_KC], b2[ML_KC];
+  if (total > 0) issue(b0, 0);
+  if (total > 1) issue(b1, 1);
+  for (int g = 0; g < total; g += 3) {
+    if (g + 2 < total) issue(b2, g + 2);
+    consume(b0, g);
+    if (g + 1 < total) {
+      if (g + 3 < total) issue(b0, g + 3);
+      consume(b1, g + 1);
+    }
+    if (g + 2 < total) {
+      if (g + 4 < total) issue(b1, g + 4);
+      consume(b2, g + 2);
     }
   }
 
@@ -553,6 +641,15 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
 }  // namespace
 
 // ---- C ABI ----------------------------------------------------------------------------------
+#ifdef SIG3D_MLP_TIMING
+extern "C" int sig3d_debug_mlp_marks(unsigned long long *host_out, int *n) {
+  int zero = 0;
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ml_marks), sizeof(unsigned long long) * 64);
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(n, HIP_SYMBOL(g_ml_nmarks), sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_ml_nmarks), &zero, sizeof(int));
+  return (int)e;
+}
+#endif
 
 template <int NT, bool PROLOGUE, bool VEC>
 static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
@@ -560,19 +657,27 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
                           double *stat_sq, hipStream_t stream) {
   constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
-  const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT);
+  const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT + ML_WAVES * 16 * ML_TRLD);
   static bool attr_done = false;  // per template instance
   if (!attr_done) {
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  // enough position chunks to cover the chip a few times over
+  // one full round of resident workgroups: occupancy per CU from LDS and registers (182 / 134 /
+  // 120 VGPRs for NT = 4 / 2 / 1 -> 2 / 3 / 4 waves per SIMD), 256 CUs
   const long wave_tiles = (e + 31) / 32;
   const int cblocks = sig3d_ceil_div(cout, CT);
-  int tpw = 8;
-  while (tpw > 1 && (long)b * cblocks * ((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)) < 1024) tpw >>= 1;
-  dim3 grid(cblocks, (unsigned)((wave_tiles + ML_WAVES * tpw - 1) / (ML_WAVES * tpw)), b);
+  int occ = (int)((160 * 1024) / lds);
+  const int occ_regs = NT == 1 ? 4 : (NT == 2 ? 3 : 2);
+  if (occ > occ_regs) occ = occ_regs;
+  if (occ < 1) occ = 1;
+  long gy = (256L * occ + (long)b * cblocks - 1) / ((long)b * cblocks);
+  const long gy_max = (wave_tiles + ML_WAVES - 1) / ML_WAVES;  // at least one tile per wave
+  if (gy > gy_max) gy = gy_max;
+  if (gy < 1) gy = 1;
+  const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
+  dim3 grid(cblocks, (unsigned)gy, b);
   hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>), grid, dim3(ML_WAVES * 64), lds, stream,
                      cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
@@ -603,18 +708,27 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
     SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
   }
   if (b == 0 || e == 0) return 0;
+  SIG3D_REQUIRE((long)cin * e < (1L << 31) && (long)cout * e < (1L << 31),
+                "cin*e and cout*e must stay below 2^31 (32-bit addressing inside the kernel)");
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
-  SIG3D_REQUIRE(sizeof(float) * ((size_t)32 * ldw + 2 * kpad + ML_WAVES * 2 * 32) <= 160 * 1024,
+  SIG3D_REQUIRE(sizeof(float) * ((size_t)32 * ldw + 2 * kpad + ML_WAVES * 2 * 32 + ML_WAVES * 16 * ML_TRLD) <= 160 * 1024,
                 "input channel count too large for the LDS weight tile");
   const bool vec = (e % 4 == 0);
   auto fits = [&](int ct, size_t budget) {
-    return sizeof(float) * ((size_t)ct * ldw + 2 * kpad + ML_WAVES * 2 * ct) <= budget;
+    return sizeof(float) * ((size_t)ct * ldw + 2 * kpad + ML_WAVES * 2 * ct + ML_WAVES * 16 * ML_TRLD) <= budget;
   };
   // widest channel tile whose weights leave room for a second workgroup on the CU (x is then
   // re-read from L2 as rarely as possible)
-  if (cout > 64 && fits(128, 76 * 1024))
+  static const int forced_nt = [] { const char *v = getenv("SIG3D_MLP_NT"); return v ? atoi(v) : 0; }();
+  if (forced_nt == 4 && fits(128, 160 * 1024))
     return dispatch_mlp_fwd<4>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
-  if (cout > 32 && fits(64, 76 * 1024))
+  if (forced_nt == 2 && fits(64, 160 * 1024))
+    return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  if (forced_nt == 1)
+    return dispatch_mlp_fwd<1>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  if (cout > 64 && fits(128, 80 * 1024))
+    return dispatch_mlp_fwd<4>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  if (cout > 32 && fits(64, 80 * 1024))
     return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
   if (cout > 32 && fits(64, 160 * 1024))
     return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
