@@ -182,9 +182,17 @@ int sig3d_pos_embed_add(int b, int n, int c, int tw, int trows, float scale, con
 /* ---- Q-Former dense-layer helpers ------------------------------------------------------- */
 
 /* Bias gradient of an nn.Linear (backward of Qformer.py:242,311,324 `self.dense(...)` and of the
- * query/key/value projections :164-178): out[c] = sum_r x[r][c], x (rows, cols) row-major.
+ * query/key/value projections :164-178): out[p][c] = sum_r x[p][r][c], x (parts, rows, cols)
+ * row-major, out (parts, cols); parts > 1 serves a batched (strided) pair of layers in one launch.
  * Deterministic (no atomics). */
-int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream);
+int sig3d_column_sum(int parts, int rows, int cols, const float *x, float *out, void *stream);
+
+/* BertIntermediate's bias + erf-GELU (Qformer.py:311-313) on the GEMM output WITHOUT bias:
+ *   gy == NULL: out = gelu(x + bias)            gy != NULL: out = gy * gelu'(x + bias)
+ * x, gy, out (rows, cols), cols % 4 == 0; bias (parts, cols): rows [p*part_rows, (p+1)*part_rows) use
+ * set p (part_rows <= 0: one set). */
+int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x, const float *bias,
+                    const float *gy, float *out, void *stream);
 
 /* Tail of BertSelfOutput / BertOutput (Qformer.py:241-246, 323-328) as one row kernel:
  *   out = LayerNorm(dropout(x + bias) + res) * gamma + beta,   x = dense(...) WITHOUT its bias.
@@ -192,8 +200,10 @@ int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *strea
  * pre-LayerNorm sum, mean / rstd (rows) the row statistics, mask (rows*64 uint16, required when
  * p_drop > 0) the keep mask: word [r*64 + l] bit i = "column l + 64*i of row r was kept".
  * Dropout bits = hash(*rng_counter, call_id, element index): advance the device counter once per
- * forward pass (sig3d_counter_increment) so that hipGraph replays draw fresh masks. */
-int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
+ * forward pass (sig3d_counter_increment) so that hipGraph replays draw fresh masks.
+ * part_rows > 0: bias / gamma / beta are (rows/part_rows, cols) and rows [p*part_rows, (p+1)*part_rows)
+ * use parameter set p (the query and text feed-forward tails of a layer in one launch); <= 0: one set. */
+int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
                              const unsigned *rng_counter, const float *x, const float *bias,
                              const float *res, const float *gamma, const float *beta, float eps,
                              float *out, float *v, float *mean, float *rstd, unsigned short *mask,
@@ -202,8 +212,9 @@ int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
 /* Backward of the above: dy (rows, cols) -> dx (gradient of x, feeds the dense layer's GEMMs),
  * dres (gradient of the residual input) and dparams = [d gamma | d beta | d bias] (3*cols floats,
  * fully written here).  workspace: 3*cols*ceil(rows/4) floats of scratch (per-workgroup partial
- * column sums, folded without atomics: deterministic). */
-int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const float *dy, const float *v,
+ * column sums, folded without atomics: deterministic).  part_rows as in the forward: dparams is then
+ * (parts, 3, cols) and part_rows must be a multiple of 4. */
+int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, const float *dy, const float *v,
                              const float *mean, const float *rstd, const float *gamma,
                              const unsigned short *mask, float *dx, float *dres, float *dparams,
                              float *workspace, void *stream);
@@ -246,15 +257,21 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  * ldq / ldk / ldv: row strides in floats of q, k, v (h*d for dense tensors; 3*h*d when q, k, v are
  * column slices of ONE fused QKV projection output, which saves two GEMM launches per attention).
  * In the backward pass dq / dk / dv use the same strides as their inputs.
- * q_seg / k_seg: token -> storage row map of the query-side tensors (q, out, grad_out, dq) and of
- * the key-side tensors (k, v, dk, dv).  seg == n (or 0): plain (b, n) order, row = bi*n + i.
- * seg < n: two-segment order -- the first `seg` tokens of every batch element are stored first
- * (row = bi*seg + i), the remaining n-seg tokens of every batch element after them
- * (row = b*seg + bi*(n-seg) + i-seg).  The Q-Former keeps [query tokens | text tokens] that way so
- * that the per-part feed-forward blocks of BertLayer.forward (Qformer.py:375-405) work on
- * contiguous row ranges.  mask (b,nk) and lse (b,h,nq) are always indexed by (batch, token). */
-int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq, int ldk,
-                        int ldv, float scale, const float *q,
+ * Token -> storage row map of the query-side tensors (q, out, grad_out, dq: q_seg, q_base2, q_rows)
+ * and of the key-side tensors (k, v, dk, dv: k_seg, k_base2, k_rows):
+ *   seg == n (or 0): plain (b, n) order, row = bi*n + i;
+ *   seg <  n       : two segments -- the first `seg` tokens of every batch element are stored first
+ *                    (row = bi*seg + i), the remaining n-seg tokens of every batch element from row
+ *                    `base2` on (row = base2 + bi*(n-seg) + i-seg; base2 >= b*seg).
+ *   rows > 0       : the tensors have `rows` storage rows; every row that holds no token (the gap
+ *                    before base2, the tail) is ZERO-FILLED in out (forward) and dq / dk / dv (backward).
+ * The Q-Former keeps [query tokens | text tokens] that way, both segments padded to a common row count,
+ * so that the per-part feed-forward blocks of BertLayer.forward (Qformer.py:375-405) are contiguous row
+ * ranges AND batch into one strided GEMM.  mask (b,nk) and lse (b,h,nq) are always indexed by
+ * (batch, token). */
+int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                        int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv, float scale,
+                        const float *q,
                         const float *k, const float *v, const float *mask, float *out,
                         float *lse, float p_drop, unsigned call_id, const unsigned *rng_counter,
                         void *stream);
@@ -265,8 +282,9 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
 
 /* Backward of sig3d_attention_fwd.  grad_out (b,nq,h*d); out/lse from the forward.
  * -> dq (b,nq,h*d), dk (b,nk,h*d), dv (b,nk,h*d), token-major like the inputs. */
-int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq, int ldk,
-                        int ldv, float scale, const float *q,
+int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                        int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv, float scale,
+                        const float *q,
                         const float *k, const float *v, const float *mask,
                         const float *out, const float *lse, const float *grad_out,
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,

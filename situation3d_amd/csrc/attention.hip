@@ -66,15 +66,34 @@ __device__ __forceinline__ void load_half_row(float (&f)[32], const float *base,
 // Token (batch bi, position i) -> storage row of a token-major operand.
 //   plain layout   (seg == n): row = bi*n + i                      -- a dense (b, n, ...) tensor
 //   two segments   (seg <  n): the first `seg` tokens of EVERY batch element are stored together
-//                  (nb*seg rows), the remaining n-seg tokens of every batch element after them.
+//                  (rows [0, b*seg)), the remaining n-seg tokens of every batch element from row
+//                  `base2` on (base2 = b*seg when the segments are packed back to back).
 // The Q-Former keeps [all query tokens | all text tokens] in that order (qformer.py): the query /
 // text split of BertLayer.forward (Qformer.py:375-405) is then a pair of contiguous row ranges
 // instead of strided slices that must be copied for the feed-forward GEMMs.
 // 32-bit on purpose (the launchers check rows * stride < 2^31): the kernels form ~60 operand
 // addresses per tile, and 64-bit row * stride products made address arithmetic cost as much as the
 // memory round trip itself (2 us per tile phase, tools/attn_timing.py).
-__device__ __forceinline__ unsigned tok_row(int i, int bi, int n, int seg, int nb) {
-  return (unsigned)(i < seg ? bi * seg + i : nb * seg + bi * (n - seg) + (i - seg));
+__device__ __forceinline__ unsigned tok_row(int i, int bi, int n, int seg, int base2) {
+  return (unsigned)(i < seg ? bi * seg + i : base2 + bi * (n - seg) + (i - seg));
+}
+
+// Storage rows that hold no token -- the gap between the segments and the tail up to `rows` -- get
+// zeros in columns [hi*64, hi*64+64) of an output tensor (row stride ld): padded layouts (qformer.py
+// pads both segments to a common row count so that per-segment GEMMs batch) must never leak
+// uninitialised memory into the row-wise kernels and weight-gradient GEMMs that follow.
+__device__ __forceinline__ void zero_pad_rows(float *base, unsigned ld, int hi, int nb, int n, int seg,
+                                              int base2, int rows) {
+  if (rows <= 0) return;
+  const bool two = seg > 0 && seg < n;
+  const int end1 = two ? nb * seg : nb * n;
+  const int start2 = two ? base2 : end1, end2 = two ? base2 + nb * (n - seg) : end1;
+  const int npad = (start2 - end1) + max(rows - end2, 0);
+  for (int i = threadIdx.x; i < npad * 16; i += blockDim.x) {
+    int r = i >> 4;
+    r = r < start2 - end1 ? end1 + r : end2 + (r - (start2 - end1));
+    *reinterpret_cast<float4 *>(base + (unsigned)r * ld + hi * AT_D + (i & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 // Attention-probability dropout (Qformer.py:219, nn.Dropout on the softmax output): the keep bit
@@ -113,7 +132,8 @@ __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base,
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
-    int h, int nq, int nk, int q_seg, int k_seg, int ldq, int ldk, int ldv, float scale, float p_drop,
+    int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int ldq, int ldk,
+    int ldv, float scale, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
     const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
     float *__restrict__ out, float *__restrict__ lse) {
@@ -123,7 +143,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z, nb = gridDim.z;
+  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
+  if (blockIdx.x == 0 && bi == 0) zero_pad_rows(out, (unsigned)(h * AT_D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
   // token-major operands: storage row r of head hi starts at base + r*ld + hi*64, where ld is the
   // row stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
   // projection output) and r = tok_row(token, batch)
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const bool has_mask = mask != nullptr;
 
   float qf[32];
-  load_half_row(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, nb), ldq, half, q0 + l31 < nq);
+  load_half_row(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, q_base2), ldq, half, q0 + l31 < nq);
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
 
@@ -149,12 +170,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     // cannot sink the loads down to their uses again (it did: 8 + 16 + 16 dependent round trips
     // per tile, the whole kernel was load latency)
     float kf[32], mk[16], va0[16], va1[16];
-    load_half_row(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, nb), ldk, half, true);
+    load_half_row(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, k_base2), ldk, half, true);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = min(key0 + mfma_row(r, half), nk - 1);
       mk[r] = Mz[key];
-      const unsigned voff = tok_row(key, bi, nk, k_seg, nb) * (unsigned)ldv + l31;
+      const unsigned voff = tok_row(key, bi, nk, k_seg, k_base2) * (unsigned)ldv + l31;
       va0[r] = V[voff];
       va1[r] = V[voff + 32];
     }
@@ -232,7 +253,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
         res[i] = acc * inv;
       }
       // context_layer.permute(0,2,1,3).view(B, Nq, 768)  (Qformer.py:225-227)
-      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, nb) * (unsigned)(h * AT_D) + hi * AT_D + dg * 8;
+      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, q_base2) * (unsigned)(h * AT_D) + hi * AT_D + dg * 8;
       *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
       *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
       if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
@@ -249,8 +270,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 // no zero fill: first visit starts from 0) and the images are summed once at the end --
 // ds_add_f32 from four waves onto one image cost 9 us of a 27 us launch (tools/attn_timing.py).
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
-    int h, int nq, int nk, int q_seg, int k_seg, int ldq, int ldk, int ldv, float scale,
-    int tiles_per_split, int atomic_dq, int qsplit_max, float p_drop,
+    int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int k_rows,
+    int ldq, int ldk, int ldv, float scale, int tiles_per_split, int atomic_dq, int qsplit_max, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
@@ -269,7 +290,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int hi = blockIdx.y, bi = blockIdx.z, nb = gridDim.z;
+  const int hi = blockIdx.y, bi = blockIdx.z;
+  if (blockIdx.x == 0 && bi == 0) {
+    zero_pad_rows(dq, (unsigned)ldq, hi, gridDim.z, nq, q_seg, q_base2, q_rows);
+    zero_pad_rows(dk, (unsigned)ldk, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+    zero_pad_rows(dv, (unsigned)ldv, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+  }
   const size_t bh = (size_t)(bi * h + hi);
   const unsigned ostride = (unsigned)h * AT_D;  // out / grad_out are dense rows of h*d floats
   const float *Q = q + hi * AT_D;       // storage row r at Q + r*ldq, r = tok_row(token, batch)
@@ -278,8 +304,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
   const float *O = out + hi * AT_D;
   const float *dO = grad_out + hi * AT_D;
-  auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, nb); };
-  auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, nb); };
+  auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, q_base2); };
+  auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, k_base2); };
 
   AT_MARK(1, 0);
   // D[q] = sum_d dO[q][d] * O[q][d]; two threads per row
@@ -511,8 +537,9 @@ extern "C" int sig3d_debug_attention_marks(unsigned long long *host_out) {
 }
 #endif
 
-extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq,
-                                   int ldk, int ldv, float scale, const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                                   int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
+                                   float scale, const float *q, const float *k, const float *v,
                                    const float *mask, float *out, float *lse, float p_drop,
                                    unsigned call_id, const unsigned *rng_counter, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -520,22 +547,27 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
   SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
+  SIG3D_REQUIRE((q_seg == 0 || q_seg == nq || q_base2 >= b * q_seg) && (k_seg == 0 || k_seg == nk || k_base2 >= b * k_seg),
+                "the second segment must start at or after the end of the first");
   SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
                 "row strides must be >= h*d and multiples of 4 floats");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
-  SIG3D_REQUIRE((long)b * nq * ldq < (1L << 31) && (long)b * nk * ldk < (1L << 31) && (long)b * nk * ldv < (1L << 31),
+  SIG3D_REQUIRE((long)(b * nq + q_base2 + q_rows) * ldq < (1L << 31) && (long)(b * nk + k_base2 + k_rows) * ldk < (1L << 31) &&
+                    (long)(b * nk + k_base2 + k_rows) * ldv < (1L << 31),
                 "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
   dim3 grid((nq + 31) / 32, h, b);
+  (void)k_rows;
   hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
-                     ldq, ldk, ldv, scale,
+                     q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
                      p_drop, call_id, rng_counter, q, k, v, mask, out, lse);
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
 
-extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int ldq,
-                                   int ldk, int ldv, float scale, const float *q, const float *k, const float *v,
+extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                                   int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
+                                   float scale, const float *q, const float *k, const float *v,
                                    const float *mask, const float *out, const float *lse,
                                    const float *grad_out, float *dq, float *dk, float *dv,
                                    float p_drop, unsigned call_id, const unsigned *rng_counter,
@@ -546,9 +578,12 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
   SIG3D_REQUIRE(nq <= AT_NQ_MAX, "attention backward supports at most 128 query rows");
   SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
+  SIG3D_REQUIRE((q_seg == 0 || q_seg == nq || q_base2 >= b * q_seg) && (k_seg == 0 || k_seg == nk || k_base2 >= b * k_seg),
+                "the second segment must start at or after the end of the first");
   if (b == 0 || h == 0 || nq == 0) return 0;
   SIG3D_REQUIRE(nk >= 1, "attention needs at least one key");
-  SIG3D_REQUIRE((long)b * nq * ldq < (1L << 31) && (long)b * nk * ldk < (1L << 31) && (long)b * nk * ldv < (1L << 31),
+  SIG3D_REQUIRE((long)(b * nq + q_base2 + q_rows) * ldq < (1L << 31) && (long)(b * nk + k_base2 + k_rows) * ldk < (1L << 31) &&
+                    (long)(b * nk + k_base2 + k_rows) * ldv < (1L << 31),
                 "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
   const int ntiles = (nk + 31) / 32;
   // enough workgroups to cover the chip, but at least AT_WAVES tiles per workgroup
@@ -565,7 +600,11 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
                 "row strides must be >= h*d and multiples of 4 floats");
   if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
-    SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D, (size_t)b * nq, stream));
+  {
+    const int q_extent = (q_seg > 0 && q_seg < nq) ? q_base2 + b * (nq - q_seg) : b * nq;
+    SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D,
+                                   (size_t)(q_rows > q_extent ? q_rows : q_extent), stream));
+  }
   dim3 grid(splits, h, b);
   const int nq_pad = (nq + 31) / 32 * 32;
   const int qsplit_max = nq_pad <= 64 ? 2 : 1;  // LDS budget: images (+ 32 KiB of dK/dV partials)
@@ -577,7 +616,7 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
     attr_done = true;
   }
   hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
-                     ldq, ldk, ldv, scale,
+                     q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale,
                      tiles_per_split, splits > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
                      out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");

@@ -13,12 +13,16 @@ namespace {
 
 constexpr int CS_WAVES = 16;
 
+// blockIdx.y = part: x is (parts, rows, cols), out (parts, cols) -- the per-part bias gradients of a
+// batched (strided) GEMM pair in one launch.
 __global__ __launch_bounds__(CS_WAVES * 64) void column_sum_kernel(int rows, int cols,
                                                                    const float *__restrict__ x,
                                                                    float *__restrict__ out) {
   __shared__ float part[CS_WAVES][64];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  x += (size_t)blockIdx.y * rows * cols;
+  out += (size_t)blockIdx.y * cols;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -64,10 +68,15 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ res,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     float *__restrict__ out, float *__restrict__ v_out, float *__restrict__ mean_out,
-    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out) {
+    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows) {
   const int lane = lane_id();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  // rows [p*part_rows, (p+1)*part_rows) use parameter set p: bias / gamma / beta are (parts, cols)
+  const int poff = (row / part_rows) * cols;
+  if (bias) bias += poff;
+  gamma += poff;
+  beta += poff;
   const unsigned seed = mix32((rng_counter ? *rng_counter : 0u) * 0x9E3779B9u + call_id);
   const unsigned thresh = (unsigned)((double)p_drop * 4294967296.0);
   const float keep_scale = 1.f / (1.f - p_drop);
@@ -121,12 +130,14 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     int rows, int cols, float p_drop, int rows_per_wave, const float *__restrict__ dy,
     const float *__restrict__ v, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const unsigned short *__restrict__ mask,
-    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial) {
+    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial, int part_rows) {
   // partial: (gridDim.x, 3*cols) = per-workgroup [d gamma | d beta | d bias] column sums
   __shared__ float part[3][3][64 * PER_LANE];  // waves 1..3 park their sums here
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
   const float keep_scale = 1.f / (1.f - p_drop);
+  // a workgroup never straddles two parts (launcher: part_rows % (4*rows_per_wave) == 0)
+  gamma += ((blockIdx.x * 4 * rows_per_wave) / part_rows) * cols;
   float ag[PER_LANE], ab[PER_LANE], abias[PER_LANE], gam[PER_LANE];
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
@@ -198,6 +209,39 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
 
 inline int ln_bwd_rows_per_wave(int rows) { return rows >= 4096 ? 8 : (rows >= 256 ? 2 : 1); }
 
+// ---- bias + erf-GELU of BertIntermediate (Qformer.py:311-313), forward and backward -------------
+// act = gelu(x + bias[part]),  gx = gy * gelu'(x + bias[part]);  x is the GEMM output WITHOUT bias
+// (kept for the backward pass), bias is (parts, cols), rows [p*part_rows, (p+1)*part_rows) use set p.
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+  const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * u * u);
+  return cdf + u * pdf;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bias_gelu_kernel(long n4, int cols4, int part_rows,
+                                                       const float4 *__restrict__ x,
+                                                       const float4 *__restrict__ bias,
+                                                       const float4 *__restrict__ gy,
+                                                       float4 *__restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int row = (int)(i / cols4), c4 = (int)(i - (long)row * cols4);
+  const float4 b = bias[(row / part_rows) * cols4 + c4];
+  const float4 v = x[i];
+  const float u[4] = {v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w};
+  float4 o;
+  if (BWD) {
+    const float4 g = gy[i];
+    o = make_float4(g.x * gelu_erf_grad(u[0]), g.y * gelu_erf_grad(u[1]), g.z * gelu_erf_grad(u[2]),
+                    g.w * gelu_erf_grad(u[3]));
+  } else {
+    o = make_float4(gelu_erf(u[0]), gelu_erf(u[1]), gelu_erf(u[2]), gelu_erf(u[3]));
+  }
+  out[i] = o;
+}
+
 __global__ void counter_increment_kernel(unsigned *counter) { *counter += 1u; }
 
 }  // namespace
@@ -208,7 +252,7 @@ extern "C" int sig3d_counter_increment(unsigned *counter, void *stream_) {
   return 0;
 }
 
-extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsigned call_id,
+extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
                                         const unsigned *rng_counter, const float *x,
                                         const float *bias, const float *res, const float *gamma,
                                         const float *beta, float eps, float *out, float *v,
@@ -220,19 +264,21 @@ extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, float p_drop, unsign
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(p_drop == 0.f || mask != nullptr, "a mask buffer is required when p_drop > 0");
   if (rows == 0) return 0;
+  if (part_rows <= 0) part_rows = rows;  // one parameter set
   const dim3 grid(sig3d_ceil_div(rows, 4));
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<12>, grid, dim3(256), 0, stream, rows, cols, p_drop,
-                       call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask);
+                       call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask,
+                       part_rows);
   else
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<LN_MAX_PER_LANE>, grid, dim3(256), 0, stream, rows, cols,
                        p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd,
-                       mask);
+                       mask, part_rows);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_fwd_kernel");
   return 0;
 }
 
-extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const float *dy,
+extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, const float *dy,
                                         const float *v, const float *mean, const float *rstd,
                                         const float *gamma, const unsigned short *mask, float *dx,
                                         float *dres, float *dparams, float *workspace,
@@ -245,26 +291,53 @@ extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, float p_drop, const 
     return 0;
   }
   SIG3D_REQUIRE(workspace != nullptr, "workspace of 3*cols*ceil(rows/4) floats is required");
-  const int rpw = ln_bwd_rows_per_wave(rows);
+  int rpw = ln_bwd_rows_per_wave(rows);
+  int parts = 1;
+  if (part_rows > 0 && part_rows < rows) {
+    SIG3D_REQUIRE(rows % part_rows == 0 && part_rows % 4 == 0, "rows must be parts * part_rows, part_rows % 4 == 0");
+    parts = rows / part_rows;
+    while (part_rows % (4 * rpw) != 0) rpw >>= 1;  // workgroups must not straddle parts
+  } else {
+    part_rows = rows;
+  }
   const int blocks = sig3d_ceil_div(sig3d_ceil_div(rows, rpw), 4);
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<12>, dim3(blocks), dim3(256), 0, stream, rows, cols, p_drop,
-                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace);
+                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows);
   else
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<LN_MAX_PER_LANE>, dim3(blocks), dim3(256), 0, stream, rows,
-                       cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace);
+                       cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
-  hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(3 * cols, 64)), dim3(CS_WAVES * 64), 0, stream,
-                     blocks, 3 * cols, workspace, dparams);
+  // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols)
+  hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(3 * cols, 64), parts), dim3(CS_WAVES * 64), 0,
+                     stream, blocks / parts, 3 * cols, workspace, dparams);
   SIG3D_LAUNCH_CHECK("column_sum_kernel");
   return 0;
 }
 
-extern "C" int sig3d_column_sum(int rows, int cols, const float *x, float *out, void *stream_) {
+extern "C" int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x, const float *bias,
+                               const float *gy, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SIG3D_REQUIRE(rows >= 0 && cols >= 0, "negative size");
+  SIG3D_REQUIRE(rows >= 0 && cols >= 4 && cols % 4 == 0, "cols must be a positive multiple of 4");
+  if (rows == 0) return 0;
+  if (part_rows <= 0) part_rows = rows;
+  const long n4 = (long)rows * (cols / 4);
+  const dim3 grid((unsigned)((n4 + 255) / 256));
+  if (gy)
+    hipLaunchKernelGGL(bias_gelu_kernel<true>, grid, dim3(256), 0, stream, n4, cols / 4, part_rows,
+                       (const float4 *)x, (const float4 *)bias, (const float4 *)gy, (float4 *)out);
+  else
+    hipLaunchKernelGGL(bias_gelu_kernel<false>, grid, dim3(256), 0, stream, n4, cols / 4, part_rows,
+                       (const float4 *)x, (const float4 *)bias, (const float4 *)gy, (float4 *)out);
+  SIG3D_LAUNCH_CHECK("bias_gelu_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_column_sum(int parts, int rows, int cols, const float *x, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(parts >= 1 && rows >= 0 && cols >= 0, "negative size");
   if (cols == 0) return 0;
-  hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(cols, 64)), dim3(CS_WAVES * 64), 0, stream,
+  hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(cols, 64), parts), dim3(CS_WAVES * 64), 0, stream,
                      rows, cols, x, out);
   SIG3D_LAUNCH_CHECK("column_sum_kernel");
   return 0;

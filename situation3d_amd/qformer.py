@@ -84,7 +84,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty(gy2.shape[1], dtype=gy2.dtype, device=gy2.device)
             with torch.cuda.device(gy2.device):
-                _lib.call("sig3d_column_sum", gy2.shape[0], gy2.shape[1], _lib.ptr(gy2), _lib.ptr(gb),
+                _lib.call("sig3d_column_sum", 1, gy2.shape[0], gy2.shape[1], _lib.ptr(gy2), _lib.ptr(gb),
                           _lib.stream_ptr(gy2.device))
         return gx, gw, gb
 
@@ -114,8 +114,9 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
-def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id):
-    """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask."""
+def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0):
+    """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask.
+    part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows."""
     dev = x2.device
     rows, cols = x2.shape
     out = torch.empty_like(x2)
@@ -123,7 +124,7 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id):
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
-        _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, ctypes.c_float(p_drop),
+        _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, part_rows, ctypes.c_float(p_drop),
                   ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
                   _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
                   _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
@@ -131,28 +132,39 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id):
     return out, v, stats, mask
 
 
-def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop):
+def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
-    dparams = [d gamma | d beta | d bias]."""
+    dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0)."""
     rows, cols = v.shape
     dx = torch.empty_like(v)
     dres = torch.empty_like(v)
-    dparams = torch.empty((3, cols), dtype=torch.float32, device=v.device)
+    shape = (rows // part_rows, 3, cols) if part_rows > 0 else (3, cols)
+    dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
     work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
     with torch.cuda.device(v.device):
-        _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, ctypes.c_float(p_drop), _lib.ptr(dy2),
+        _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, ctypes.c_float(p_drop), _lib.ptr(dy2),
                   _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
                   _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work),
                   _lib.stream_ptr(v.device))
     return dx, dres, dparams
 
 
-def _colsum(t2):
-    o = torch.empty(t2.shape[1], dtype=torch.float32, device=t2.device)
+def _colsum(t2, parts=1):
+    """Column sums of a contiguous (parts*rows, cols) matrix -> (cols,) or (parts, cols)."""
+    rows, cols = t2.shape[0] // parts, t2.shape[1]
+    o = torch.empty((parts, cols) if parts > 1 else (cols,), dtype=torch.float32, device=t2.device)
     with torch.cuda.device(t2.device):
-        _lib.call("sig3d_column_sum", t2.shape[0], t2.shape[1], _lib.ptr(t2), _lib.ptr(o),
-                  _lib.stream_ptr(t2.device))
+        _lib.call("sig3d_column_sum", parts, rows, cols, _lib.ptr(t2), _lib.ptr(o), _lib.stream_ptr(t2.device))
     return o
+
+
+def _bias_gelu(x2, bias, part_rows, gy=None):
+    """gelu(x + bias) (gy None) or gy * gelu'(x + bias); bias (parts, cols) per block of part_rows rows."""
+    out = torch.empty_like(x2)
+    with torch.cuda.device(x2.device):
+        _lib.call("sig3d_bias_gelu", x2.shape[0], x2.shape[1], part_rows, _lib.ptr(x2), _lib.ptr(bias),
+                  _lib.ptr(gy), _lib.ptr(out), _lib.stream_ptr(x2.device))
+    return out
 
 
 class _DropoutAddLayerNormFn(torch.autograd.Function):
@@ -206,7 +218,7 @@ class _AttentionFn(torch.autograd.Function):
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, nq, nk, hd, hd, hd, ctypes.c_float(scale),
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, nq, nk, 0, 0, 0, 0, hd, hd, hd, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
                       _lib.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
@@ -223,7 +235,7 @@ class _AttentionFn(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         with torch.cuda.device(q.device):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads, nq, nk, hd, hd, hd,
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, hd // num_heads, nq, nk, 0, 0, 0, 0, hd, hd, hd,
                       ctypes.c_float(scale), _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask),
                       _lib.ptr(out), _lib.ptr(lse), _lib.ptr(grad_out), _lib.ptr(dq), _lib.ptr(dk),
                       _lib.ptr(dv), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
@@ -305,8 +317,8 @@ class _ProjAttentionFn(torch.autograd.Function):
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
-                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, b * seg, b * kseg, 0, 0,
+                      ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
                       ctypes.c_float(p_drop), ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)),
                       _lib.stream_ptr(dev))
         ctx.save_for_backward(hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse)
@@ -345,8 +357,8 @@ class _ProjAttentionFn(torch.autograd.Function):
             dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
             ldq, ldk, ldv = hd, 2 * hd, 2 * hd
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
-                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, kseg, b * seg, b * kseg, 0, 0,
+                      ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
                       _lib.ptr(grad_out), dqp, dkp, dvp, ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
 
@@ -372,49 +384,55 @@ class _AttentionBlockFn(torch.autograd.Function):
     = _ProjAttentionFn + the BertSelfOutput tail.  Besides sparing autograd bookkeeping, the block
     form lets the two gradient paths into x (residual and Q/K/V projections) meet inside a GEMM
     epilogue (addmm with beta = 1) instead of an extra accumulate kernel, and hands no key/value
-    side outputs to autograd.  layout = (B, N, seg) as in _ProjAttentionFn (seg == N: plain)."""
+    side outputs to autograd.
+    layout = (B, N, seg, base2, rows): x has `rows` storage rows; tokens [0, seg) of every batch
+    element sit in rows [0, B*seg), the others from row base2 on (sig3d_attention_fwd); rows that
+    hold no token are kept finite (zeros from the attention kernels, row-wise ops elsewhere) and
+    carry zero gradients.  seg == N, rows == B*N: plain (B, N) order."""
 
     @staticmethod
     def forward(ctx, x, kv_src, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask, num_heads, p_attn,
                 p_hidden, eps, id_attn, id_out, layout):
         x = x.contiguous()
         dev = x.device
-        b, nq, seg = layout
+        b, nq, seg, base2, rows = layout
+        assert x.shape[0] == rows
         hd = wq.shape[0]
         d = hd // num_heads
         scale = 1.0 / math.sqrt(d)
         if kv_src is None:  # self-attention
             w_all = _stacked((wq, wk, wv))
             proj = torch.addmm(_stacked((bq, bk, bv)), x, w_all.t())      # (B*N, 3*hd)
-            qp, kp, vp, ldq, ldk, ldv, nk, kseg = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq, seg
+            qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
+            klay = (seg, base2, rows)
             kvproj, e2 = None, None
         else:
             nk = kv_src.shape[1]
-            kseg = nk
+            klay = (nk, 0, 0)
             e2 = kv_src.reshape(b * nk, kv_src.shape[2])
             w_all = _stacked((wk, wv))
             proj = torch.addmm(bq, x, wq.t())                             # (B*N, hd)
             kvproj = torch.addmm(_stacked((bk, bv)), e2, w_all.t())       # (B*Nk, 2*hd)
             qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
-        att = torch.empty((b * nq, hd), dtype=torch.float32, device=dev)
+        att = torch.empty((rows, hd), dtype=torch.float32, device=dev)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
-                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], rows, klay[2],
+                      ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
                       _lib.stream_ptr(dev))
         y = att.mm(wo.t())
         out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out)
         ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)
-        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, kseg)
+        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, rows, klay)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep = ctx.saved_tensors
-        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, kseg = ctx.cfg
+        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, rows, klay = ctx.cfg
         dev = x.device
         d = hd // num_heads
         dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden)
@@ -432,8 +450,8 @@ class _AttentionBlockFn(torch.autograd.Function):
             dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
             ldq, ldk, ldv = hd, 2 * hd, 2 * hd
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, kseg, ldq, ldk, ldv,
-                      ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], rows, klay[2],
+                      ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
         tail = (gwo, dparams[2], dparams[0], dparams[1]) + (None,) * 8
@@ -478,6 +496,54 @@ class _FFNBlockFn(torch.autograd.Function):
         return gx, gw1, _colsum(gpre), gw2, dparams[2], dparams[0], dparams[1], None, None, None
 
 
+def _pair(a, b):
+    """Parameters of the query branch and of the text branch as ONE (2, ...) tensor: a zero-copy view
+    when they are adjacent in memory (trainer.build_optimizer asks optim.FlatAdamW for that), else a copy."""
+    return _stacked((a.unsqueeze(0), b.unsqueeze(0)))
+
+
+class _FFNPairBlockFn(torch.autograd.Function):
+    """The query feed-forward block (intermediate_query / output_query) on rows [0, P) and the text
+    feed-forward block (intermediate / output) on rows [P, 2P) of one padded (2P, C) row matrix
+    (Qformer.py:396-405) as ONE autograd node and HALF the launches: both branches have the same
+    shapes, so every GEMM is one strided-batched GEMM over the (2, ...) parameter pairs, bias + GELU,
+    the LayerNorm tail and the bias-gradient column sums take a `part_rows` argument.
+    Rows without a token (padding of the shorter part) only ever see finite values and zero
+    gradients, so they add exact zeros to the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w1q, b1q, w1t, b1t, w2q, b2q, w2t, b2t, gq, bq, gt, bt, p_drop, eps, call_id):
+        x = x.contiguous()
+        P = x.shape[0] // 2
+        w1, b1, w2, b2 = _pair(w1q, w1t), _pair(b1q, b1t), _pair(w2q, w2t), _pair(b2q, b2t)
+        gamma, beta = _pair(gq, gt), _pair(bq, bt)
+        x3 = x.view(2, P, -1)
+        pre = torch.bmm(x3, w1.transpose(1, 2))                       # (2, P, I), bias added below
+        act = _bias_gelu(pre.view(2 * P, -1), b1, P)                  # (2P, I)
+        y = torch.bmm(act.view(2, P, -1), w2.transpose(1, 2))         # (2, P, C)
+        out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P)
+        ctx.save_for_backward(x, w1, b1, w2, pre, act, v, stats, gamma, keep)
+        ctx.p_drop = p_drop
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, pre, act, v, stats, gamma, keep = ctx.saved_tensors
+        P = x.shape[0] // 2
+        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop, P)
+        dyo3 = dyo.view(2, P, -1)
+        gw2 = torch.bmm(dyo3.transpose(1, 2), act.view(2, P, -1))      # (2, C, I)
+        gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
+        gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1))
+        gb1 = _colsum(gpre, parts=2)                                   # (2, I)
+        gpre3 = gpre.view(2, P, -1)
+        gw1 = torch.bmm(gpre3.transpose(1, 2), x.view(2, P, -1))       # (2, I, C)
+        gx = dres.view(2, P, -1).baddbmm_(gpre3, w1).view(2 * P, -1)   # residual + dense1 input grads
+        # dparams (2, 3, C): [d gamma | d beta | d bias2] per part
+        return (gx, gw1[0], gb1[0], gw1[1], gb1[1], gw2[0], dparams[0, 2], gw2[1], dparams[1, 2],
+                dparams[0, 0], dparams[0, 1], dparams[1, 0], dparams[1, 1], None, None, None)
+
+
 def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
     """q (B,Nq,H*64), k/v (B,Nk,H*64), additive_mask (B,Nk) or None -> (B,Nq,H*64).
     p_drop > 0: dropout on the attention probabilities (Qformer.py:219), mask = hash of the device
@@ -516,7 +582,7 @@ class BertEmbeddings(nn.Module):
         self.config = config
 
     def forward(self, input_ids=None, position_ids=None, query_embeds=None,
-                past_key_values_length=0, segmented=False):
+                past_key_values_length=0, segmented=0):
         seq_length = input_ids.size()[1] if input_ids is not None else 0
         if position_ids is None:
             position_ids = self.position_ids[
@@ -526,9 +592,14 @@ class BertEmbeddings(nn.Module):
             if self.position_embedding_type == "absolute":
                 embeddings = embeddings + self.position_embeddings(position_ids)
             if query_embeds is not None:
-                if segmented:  # (B*Tq + B*Tt, C): [all query rows | all text rows]
+                if segmented:  # (2P, C): [query rows, pad | text rows, pad], see BertLayer.forward_segmented
                     c = embeddings.shape[-1]
-                    embeddings = torch.cat((query_embeds.reshape(-1, c), embeddings.reshape(-1, c)), dim=0)
+                    pieces = []
+                    for part in (query_embeds.reshape(-1, c), embeddings.reshape(-1, c)):
+                        pieces.append(part)
+                        if part.shape[0] < segmented:
+                            pieces.append(part.new_zeros(segmented - part.shape[0], c))
+                    embeddings = torch.cat(pieces, dim=0)
                 else:
                     embeddings = torch.cat((query_embeds, embeddings), dim=1)
         else:
@@ -633,9 +704,10 @@ class BertAttention(nn.Module):
 
     def forward_rows(self, rows, attention_mask, layout, encoder_hidden_states=None,
                      encoder_attention_mask=None):
-        """rows (B*N, C) in the token order `layout` = (B, N, seg) -> same shape and order."""
+        """rows (R, C) in the token order `layout` = (B, N, seg, base2, R) of _AttentionBlockFn ->
+        same shape and order."""
         att, outp = self.self, self.output
-        batch, n_tokens, _ = layout
+        batch, n_tokens = layout[0], layout[1]
         if encoder_hidden_states is not None:
             mask = _key_mask(encoder_attention_mask, batch, encoder_hidden_states.shape[1])
         else:
@@ -728,25 +800,33 @@ class BertLayer(nn.Module):
         return (layer_output, present_key_value)
 
     def forward_segmented(self, rows, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                          batch, query_length, text_length):
-        """Same computation as forward() on the two-segment row matrix
-        rows = [B*query_length query rows | B*text_length text rows]  (B*(Tq+Tt), C):
-        the query / text split (Qformer.py:375,396) and the final cat (:402) are contiguous row
-        ranges -- torch.split is a pair of views (its backward ONE cat), torch.cat one copy (its
-        backward two views) -- where the (B, N, C) layout pays a strided copy per slice, per
-        residual and per gradient (5 copies + 1 cat forward, ~2x that backward, per layer)."""
+                          batch, query_length, text_length, part_rows):
+        """Same computation as forward() on the padded two-segment row matrix (2P, C), P = part_rows:
+            rows [0, B*Tq)      query tokens        rows [B*Tq, P)       padding
+            rows [P, P + B*Tt)  text tokens         rows [P + B*Tt, 2P)  padding
+        The query / text split (Qformer.py:375,396) and the final cat (:402) disappear: self-attention
+        maps tokens to rows inside the kernel, cross-attention works on the leading B*Tq rows, and the
+        two feed-forward branches -- same shapes, different weights -- run as ONE strided-batched GEMM
+        chain over the two P-row halves (_FFNPairBlockFn).  The (B, N, C) layout pays a strided copy
+        per slice, per residual and per gradient, and twice the GEMM launches."""
         rq = batch * query_length
         attention_output = self.attention.forward_rows(
-            rows, attention_mask, (batch, query_length + text_length, query_length))
-        query_rows, text_rows = torch.split(attention_output, [rq, batch * text_length], dim=0)
+            rows, attention_mask, (batch, query_length + text_length, query_length, part_rows, 2 * part_rows))
         if self.has_cross_attention:
             assert encoder_hidden_states is not None, \
                 "encoder_hidden_states must be given for cross-attention layers"
+            query_rows, rest = torch.split(attention_output, [rq, 2 * part_rows - rq], dim=0)
             query_rows = self.crossattention.forward_rows(
-                query_rows, None, (batch, query_length, query_length), encoder_hidden_states,
+                query_rows, None, (batch, query_length, query_length, 0, rq), encoder_hidden_states,
                 encoder_attention_mask)
-        return torch.cat([_ffn_rows(self.intermediate_query, self.output_query, query_rows),
-                          _ffn_rows(self.intermediate, self.output, text_rows)], dim=0)
+            attention_output = torch.cat([query_rows, rest], dim=0)
+        iq, oq, it, ot = self.intermediate_query, self.output_query, self.intermediate, self.output
+        p = oq.dropout.p if oq.training else 0.0
+        return _FFNPairBlockFn.apply(
+            attention_output, iq.dense.weight, iq.dense.bias, it.dense.weight, it.dense.bias,
+            oq.dense.weight, oq.dense.bias, ot.dense.weight, ot.dense.bias, oq.LayerNorm.weight,
+            oq.LayerNorm.bias, ot.LayerNorm.weight, ot.LayerNorm.bias, float(p), float(oq.LayerNorm.eps),
+            oq._call_id)
 
     def feed_forward_chunk(self, attention_output):
         return self.output(self.intermediate(attention_output), attention_output)
@@ -756,12 +836,12 @@ class BertLayer(nn.Module):
 
 
 class _SegmentedOutput:
-    """Encoder result kept as the two-segment row matrix.  `query_hidden_state` (B, Tq, C) -- what
+    """Encoder result kept as the padded two-segment row matrix.  `query_hidden_state` (B, Tq, C) -- what
     BLIP-2 consumes (`last_hidden_state[:, :query_length]`, blip2_t5.py / model.py) -- is a free
     view; the full (B, Tq+Tt, C) `last_hidden_state` is assembled on first access."""
 
-    def __init__(self, rows, batch, tq, tt):
-        self.rows, self._shape = rows, (batch, tq, tt)
+    def __init__(self, rows, batch, tq, tt, part_rows):
+        self.rows, self._shape, self._part_rows = rows, (batch, tq, tt), part_rows
         self._full = None
         self.past_key_values = self.hidden_states = self.attentions = self.cross_attentions = None
         self.pooler_output = None
@@ -775,8 +855,9 @@ class _SegmentedOutput:
     def last_hidden_state(self):
         if self._full is None:
             b, tq, tt = self._shape
+            p = self._part_rows
             self._full = torch.cat([self.rows[:b * tq].view(b, tq, -1),
-                                    self.rows[b * tq:].view(b, tt, -1)], dim=1)
+                                    self.rows[p:p + b * tt].view(b, tt, -1)], dim=1)
         return self._full
 
 
@@ -794,12 +875,12 @@ class BertEncoder(nn.Module):
                 return_dict=True, query_length=0, segments=None):
         if segments is not None:
             # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
-            batch, tq, tt = segments
+            batch, tq, tt, part_rows = segments
             for layer_module in self.layer:
                 hidden_states = layer_module.forward_segmented(
                     hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                    batch, tq, tt)
-            return _SegmentedOutput(hidden_states, batch, tq, tt)
+                    batch, tq, tt, part_rows)
+            return _SegmentedOutput(hidden_states, batch, tq, tt, part_rows)
         all_hidden_states = () if output_hidden_states else None
         for layer_module in self.layer:
             if output_hidden_states:
@@ -862,9 +943,12 @@ class BertModel(nn.Module):
         if (input_ids is not None and query_embeds is not None and query_embeds.is_cuda
                 and query_embeds.dtype == torch.float32 and input_ids.shape[1] > 0
                 and not output_hidden_states and return_dict is not False and self.segmented_layout):
-            segments = (query_embeds.shape[0], query_length, input_ids.shape[1])
+            b_, tt_ = query_embeds.shape[0], input_ids.shape[1]
+            part_rows = (max(b_ * query_length, b_ * tt_) + 7) // 8 * 8
+            segments = (b_, query_length, tt_, part_rows)
         embedding_output = self.embeddings(input_ids=input_ids, position_ids=position_ids,
-                                           query_embeds=query_embeds, segmented=segments is not None)
+                                           query_embeds=query_embeds,
+                                           segmented=segments[3] if segments is not None else 0)
         if segments is not None:
             batch_size, seq_length = segments[0], segments[1] + segments[2]
         else:
@@ -893,6 +977,24 @@ class BertModel(nn.Module):
         return SimpleNamespace(last_hidden_state=enc.last_hidden_state, pooler_output=None,
                                past_key_values=None, hidden_states=enc.hidden_states,
                                attentions=None, cross_attentions=None)
+
+
+def parameter_adjacency_groups(module):
+    """Tuples of parameters the hot path wants back to back in memory (in this order), so that
+    [Wq;Wk;Wv] and the (query branch, text branch) pairs of the feed-forward blocks are zero-copy
+    views (_stacked / _pair).  trainer.build_optimizer passes the order on to optim.FlatAdamW; with any
+    other storage the views silently become copies."""
+    groups = []
+    for m in module.modules():
+        if isinstance(m, BertSelfAttention):
+            groups.append((m.query.weight, m.key.weight, m.value.weight))
+            groups.append((m.query.bias, m.key.bias, m.value.bias))
+        elif isinstance(m, BertLayer):
+            iq, it, oq, ot = m.intermediate_query, m.intermediate, m.output_query, m.output
+            groups += [(iq.dense.weight, it.dense.weight), (iq.dense.bias, it.dense.bias),
+                       (oq.dense.weight, ot.dense.weight), (oq.dense.bias, ot.dense.bias),
+                       (oq.LayerNorm.weight, ot.LayerNorm.weight), (oq.LayerNorm.bias, ot.LayerNorm.bias)]
+    return groups
 
 
 class QFormer(nn.Module):

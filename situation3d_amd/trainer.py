@@ -53,6 +53,33 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
         if not p.requires_grad:
             continue
         (no_decay if any(nd in n for nd in no_decay_filter) else decay).append(p)
+    if name == "flat_adamw":
+        # storage order: keep the parameter sets the Q-Former stacks into one GEMM operand adjacent
+        from .qformer import parameter_adjacency_groups
+        follow = {}
+        for grp in parameter_adjacency_groups(model):
+            for p in grp[1:]:
+                follow[id(p)] = grp
+
+        def ordered(params):
+            present = {id(p) for p in params}
+            out, done = [], set()
+            for p in params:
+                if id(p) in done or (id(p) in follow and id(follow[id(p)][0]) in present):
+                    continue  # emitted together with the head of its group
+                out.append(p)
+                done.add(id(p))
+            # heads pull their followers in right behind them
+            final = []
+            heads = {id(g[0]): g for g in parameter_adjacency_groups(model)}
+            for p in out:
+                final.append(p)
+                for q in heads.get(id(p), ())[1:]:
+                    if id(q) in present:
+                        final.append(q)
+            return final
+
+        decay, no_decay = ordered(decay), ordered(no_decay)
     groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
     if name == "flat_adamw":
         # clip_grad_value_(1.0) + AdamW + zero_grad as one streaming kernel per group (optim.py)

@@ -106,7 +106,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     out = torch.empty(b, nq, h * 64, device=DEV)
     lse = torch.empty(b, h, nq, device=DEV)
     ld = h * 64  # dense token-major operands
-    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
            L.ptr(None), L.stream_ptr())
 
@@ -122,7 +122,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd)
     dv = torch.empty_like(vd)
-    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, nq, nk, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
            L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
     torch.testing.assert_close(untm(dq.cpu()).double(), q64.grad, rtol=1e-4, atol=1e-4)
@@ -130,14 +130,21 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     torch.testing.assert_close(untm(dv.cpu()).double(), v64.grad, rtol=1e-4, atol=1e-4)
 
 
-def _to_segments(t, seg):
-    """(b, n, c) plain token order -> (b*n, c) two-segment row matrix (include/sig3d_hip.h)."""
+def _to_segments(t, seg, base2=None, rows=None, fill=0.0):
+    """(b, n, c) plain token order -> two-segment row matrix (include/sig3d_hip.h); with base2 / rows
+    the segments are padded (rows without a token hold `fill`)."""
     b, n, c = t.shape
-    return torch.cat([t[:, :seg].reshape(b * seg, c), t[:, seg:].reshape(b * (n - seg), c)], 0).contiguous()
+    base2 = b * seg if base2 is None else base2
+    rows = base2 + b * (n - seg) if rows is None else rows
+    out = torch.full((rows, c), fill, dtype=t.dtype, device=t.device)
+    out[:b * seg] = t[:, :seg].reshape(b * seg, c)
+    out[base2:base2 + b * (n - seg)] = t[:, seg:].reshape(b * (n - seg), c)
+    return out
 
 
-@pytest.mark.parametrize("b,h,n,seg", [(8, 12, 52, 32), (3, 2, 40, 1), (2, 4, 33, 32), (2, 1, 7, 7)])
-def test_attention_two_segment_layout_matches_plain(b, h, n, seg):
+@pytest.mark.parametrize("b,h,n,seg,pad", [(8, 12, 52, 32, 0), (3, 2, 40, 1, 0), (2, 4, 33, 32, 0), (2, 1, 7, 7, 0),
+                                           (8, 12, 52, 32, 96), (2, 3, 40, 10, 5)])
+def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad):
     """q_seg / k_seg only re-map token -> storage row: results must equal the plain-layout call
     bit for bit after un-permuting the rows (same arithmetic, same order)."""
     L = _lib()
@@ -149,19 +156,24 @@ def test_attention_two_segment_layout_matches_plain(b, h, n, seg):
     mask = ((1.0 - keep) * -10000.0).to(DEV)
     scale = ctypes.c_float(0.125)
 
-    def run(qs, ks, q, k, v, go):
-        out, lse = torch.empty_like(q), torch.empty(b, h, n, device=DEV)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        L.call("sig3d_attention_fwd", b, h, n, n, 64, qs, ks, ld, ld, ld, scale, L.ptr(q), L.ptr(k), L.ptr(v),
-               L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None),
-               L.stream_ptr())
-        L.call("sig3d_attention_bwd", b, h, n, n, 64, qs, ks, ld, ld, ld, scale, L.ptr(q), L.ptr(k), L.ptr(v),
-               L.ptr(mask), L.ptr(out), L.ptr(lse), L.ptr(go), L.ptr(dq), L.ptr(dk), L.ptr(dv),
-               ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
+    def run(qs, ks, base2, rows, q, k, v, go):
+        nan = float("nan")   # outputs start as NaN: every row, padding included, must be written
+        out, lse = torch.full_like(q, nan), torch.empty(b, h, n, device=DEV)
+        dq, dk, dv = torch.full_like(q, nan), torch.full_like(k, nan), torch.full_like(v, nan)
+        L.call("sig3d_attention_fwd", b, h, n, n, 64, qs, ks, base2, base2, rows, rows, ld, ld, ld, scale,
+               L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0),
+               ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
+        L.call("sig3d_attention_bwd", b, h, n, n, 64, qs, ks, base2, base2, rows, rows, ld, ld, ld, scale,
+               L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), L.ptr(go), L.ptr(dq), L.ptr(dk),
+               L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
         return out, lse, dq, dk, dv
 
-    plain = run(n, n, q, k, v, go)
-    segd = run(seg, seg, *(_to_segments(t, seg) for t in (q, k, v, go)))
+    plain = run(n, n, 0, 0, q, k, v, go)
+    # padded variant: `pad` extra rows after each segment, garbage (1e30) in the inputs' padding rows
+    base2 = b * seg + pad
+    rows = base2 + b * (n - seg) + pad
+    segd = run(seg, seg, base2, rows if pad else 0, *(_to_segments(t, seg, base2, rows, fill=1e30) for t in (q, k, v, go)))
     assert torch.equal(plain[1], segd[1])  # lse is indexed by (batch, head, token) in both
     for name, a, c in zip(("out", "dq", "dk", "dv"), (plain[0],) + plain[2:], (segd[0],) + segd[2:]):
-        assert torch.equal(_to_segments(a.view(b, n, ld), seg), c.view(b * n, ld)), name
+        # token rows identical bit for bit; rows without a token are exact zeros
+        assert torch.equal(_to_segments(a.view(b, n, ld), seg, base2, rows, fill=0.0), c.view(rows, ld)), name

@@ -14,8 +14,12 @@ def test_column_sum():
     for rows, cols in [(416, 768), (1, 5), (1000, 3072), (37, 130)]:
         x = torch.randn(rows, cols, device=DEV)
         out = torch.empty(cols, device=DEV)
-        L.call("sig3d_column_sum", rows, cols, L.ptr(x), L.ptr(out), L.stream_ptr())
+        L.call("sig3d_column_sum", 1, rows, cols, L.ptr(x), L.ptr(out), L.stream_ptr())
         torch.testing.assert_close(out, x.sum(0), rtol=1e-5, atol=1e-4)
+    x = torch.randn(3, 40, 200, device=DEV)      # parts: (3, 40, 200) -> (3, 200)
+    out = torch.empty(3, 200, device=DEV)
+    L.call("sig3d_column_sum", 3, 40, 200, L.ptr(x), L.ptr(out), L.stream_ptr())
+    torch.testing.assert_close(out, x.sum(1), rtol=1e-5, atol=1e-4)
 
 
 def _fused(x, bias, res, gamma, beta, p, call_id=7):
@@ -85,3 +89,52 @@ def test_dropout_seed_advances_per_forward():
     assert torch.equal(a, b)  # same counter, same call id: same mask
     advance_dropout_seed(ones.device)
     assert not torch.equal(a, _fused(*args))
+
+
+def test_bias_gelu_matches_torch():
+    """erf-GELU of BertIntermediate (Qformer.py:311-313) with per-part biases, forward and backward."""
+    from situation3d_amd.qformer import _bias_gelu
+    g = torch.Generator().manual_seed(5)
+    rows, cols, part = 48, 256, 16
+    x = (torch.randn(rows, cols, generator=g) * 2).to(DEV)
+    bias = torch.randn(rows // part, cols, generator=g).to(DEV)
+    gy = torch.randn(rows, cols, generator=g).to(DEV)
+    u = (x.double() + bias.double().repeat_interleave(part, 0)).requires_grad_(True)
+    ref = F.gelu(u)
+    ref.backward(gy.double())
+    # tolerance: 1e-4 (north star); erff / expf differ from the double reference by ~1e-7
+    torch.testing.assert_close(_bias_gelu(x, bias, part).double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(_bias_gelu(x, bias, part, gy=gy).double(), u.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_ffn_pair_block_equals_two_single_blocks(p_drop):
+    """_FFNPairBlockFn on a (2P, C) matrix == the query block on rows [0,P) and the text block on rows
+    [P,2P) run separately through torch (same dropout masks: recovered from the kernel's own output)."""
+    from situation3d_amd.qformer import _FFNPairBlockFn
+    g = torch.Generator().manual_seed(11)
+    P, C, I = 24, 128, 256
+    mk = lambda *s_: (torch.randn(*s_, generator=g) * 0.3).to(DEV)
+    params = [mk(I, C), mk(I), mk(I, C), mk(I), mk(C, I), mk(C), mk(C, I), mk(C), mk(C) + 1, mk(C), mk(C) + 1, mk(C)]
+    x, dy = mk(2 * P, C), mk(2 * P, C)
+    a = [t.clone().requires_grad_(True) for t in [x] + params]
+    out = _FFNPairBlockFn.apply(*a, p_drop, 1e-12, 77)
+    out.backward(dy)
+    r = [t.clone().double().requires_grad_(True) for t in [x] + params]
+    xr, (w1q, b1q, w1t, b1t, w2q, b2q, w2t, b2t, gq, bq, gt, bt) = r[0], r[1:]
+    outs = []
+    for rows, w1, b1, w2, b2, ga, be in ((slice(0, P), w1q, b1q, w2q, b2q, gq, bq), (slice(P, 2 * P), w1t, b1t, w2t, b2t, gt, bt)):
+        h = F.linear(F.gelu(F.linear(xr[rows], w1, b1)), w2, b2)
+        if p_drop > 0:  # recover the keep mask: probe the kernel with a constant input (same call id)
+            from situation3d_amd.qformer import _ln_tail_fwd
+            ones = torch.ones(2 * P, C, device=DEV)
+            probe = _ln_tail_fwd(ones, torch.zeros(2, C, device=DEV), torch.zeros_like(ones), torch.ones(2, C, device=DEV),
+                                 torch.zeros(2, C, device=DEV), p_drop, 1e-12, 77, P)[1]   # v = dropout(1)
+            h = h * (probe[rows] > 0).double() / (1 - p_drop)
+        outs.append(F.layer_norm(h + xr[rows], (C,), ga, be, 1e-12))
+    ref = torch.cat(outs, 0)
+    ref.backward(dy.double())
+    torch.testing.assert_close(out.double(), ref.detach(), rtol=1e-4, atol=1e-4)
+    for t, rr, name in zip(a, r, ["x", "w1q", "b1q", "w1t", "b1t", "w2q", "b2q", "w2t", "b2t", "gq", "bq", "gt", "bt"]):
+        scale = max(1.0, rr.grad.abs().max().item())
+        torch.testing.assert_close(t.grad.double(), rr.grad, rtol=1e-3, atol=1e-4 * scale, msg=lambda m: name + ": " + m)
