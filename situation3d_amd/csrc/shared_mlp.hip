@@ -532,14 +532,13 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     int cin, int cout, long E, int steps_per_wave, int nblk_n, const float *__restrict__ dY,
     const float *__restrict__ x, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ dW) {
-  __shared__ float s_tile[4][32][33];
+  // one private image of the 2x2 tile block per wave (plain stores), summed once at the end: four
+  // waves doing ds_add_f32 onto ONE image cost ~10 us per workgroup (cf. the attention backward)
+  __shared__ float s_tile[DW_WAVES][4][32][33];
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int bi = blockIdx.z;
   const int co0 = (blockIdx.y / nblk_n) * 64, ci0 = (blockIdx.y % nblk_n) * 64;
-
-  for (int i = threadIdx.x; i < 4 * 32 * 33; i += DW_WAVES * 64) (&s_tile[0][0][0])[i] = 0.f;
-  __syncthreads();
 
   // per-lane row pointers / prologue constants of the two A rows (co) and two B rows (ci)
   const float *arow[2];
@@ -623,18 +622,19 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
       }
     }
   }
-  // combine the workgroup's waves in LDS, then one global atomic per element
+  // combine the workgroup's waves through LDS, then one global atomic per element
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) atomicAdd(&s_tile[i * 2 + j][mrow(r, half)][l31], acc[i][j][r]);
+      for (int r = 0; r < 16; ++r) s_tile[wave][i * 2 + j][mrow(r, half)][l31] = acc[i][j][r];
   __syncthreads();
   for (int idx = threadIdx.x; idx < 4 * 32 * 32; idx += DW_WAVES * 64) {
     const int tile = idx >> 10, r = (idx >> 5) & 31, c = idx & 31;
     const int co = co0 + 32 * (tile >> 1) + r, ci = ci0 + 32 * (tile & 1) + c;
-    if (co < cout && ci < cin) unsafeAtomicAdd(dW + (size_t)co * cin + ci, s_tile[tile][r][c]);
+    const float v = (s_tile[0][tile][r][c] + s_tile[1][tile][r][c]) + (s_tile[2][tile][r][c] + s_tile[3][tile][r][c]);
+    if (co < cout && ci < cin) unsafeAtomicAdd(dW + (size_t)co * cin + ci, v);
   }
 }
 
@@ -815,10 +815,11 @@ static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, cons
                          const float *pscale, const float *pshift, float *dW, hipStream_t stream) {
   const int nblk_m = sig3d_ceil_div(cout, 64), nblk_n = sig3d_ceil_div(cin, 64);
   const long n_steps = (e + 31) / 32;
-  // ~4096 waves in flight, at least 8 steps per wave
-  long waves_per_block_row = 4096 / ((long)b * nblk_m * nblk_n);
-  if (waves_per_block_row < DW_WAVES) waves_per_block_row = DW_WAVES;
-  long spw = (n_steps + waves_per_block_row - 1) / waves_per_block_row;
+  // ONE round of resident workgroups (2 per CU: 216 VGPRs, 68 KB of LDS images): longer position
+  // ranges per wave amortise the reduction epilogue and leave no tail round; >= 8 steps per wave
+  long wgs_per_block_row = (2L * 256) / ((long)b * nblk_m * nblk_n);
+  if (wgs_per_block_row < 1) wgs_per_block_row = 1;
+  long spw = (n_steps + wgs_per_block_row * DW_WAVES - 1) / (wgs_per_block_row * DW_WAVES);
   if (spw < 8) spw = 8;
   const long wgs = (n_steps + spw * DW_WAVES - 1) / (spw * DW_WAVES);
   dim3 grid((unsigned)wgs, nblk_m * nblk_n, b);

@@ -134,8 +134,9 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(None), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
                               _lib.ptr(dY), stream)
-                grads[3 * k + 1] = sums[1].to(torch.float32)   # d gamma
-                grads[3 * k + 2] = sums[0].to(torch.float32)   # d beta
+                sums32 = sums.to(torch.float32)                # one conversion launch for both rows
+                grads[3 * k + 1] = sums32[1]                   # d gamma
+                grads[3 * k + 2] = sums32[0]                   # d beta
                 prev = ys[k - 1] if k > 0 else x
                 pps = affs[k - 1][0] if k > 0 else None
                 ppb = affs[k - 1][1] if k > 0 else None
