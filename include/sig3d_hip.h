@@ -138,6 +138,14 @@ int sig3d_bn_finalize(int c, double count, float eps, float momentum, const doub
 int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y, const float *scale,
                           const float *shift, float *out, int *arg, void *stream);
 
+/* Stand-alone pieces for layers whose 1x1 convolution runs as a library GEMM (small levels, where
+ * a few thousand positions do not fill the MFMA kernel): per-channel sum(y), sum(y^2) of y (b,c,e)
+ * as doubles (zeroed here; feed sig3d_bn_finalize), and out = relu(y*scale + shift). */
+int sig3d_channel_stats(int b, int c, long e, const float *y, double *stat_sum, double *stat_sq,
+                        void *stream);
+int sig3d_bn_relu_apply(int b, int c, long e, const float *y, const float *scale, const float *shift,
+                        float *out, void *stream);
+
 /* Backward of BatchNorm(train)+ReLU of one layer: y (b,c,e) raw conv output, upstream gradient
  * either dense dA (b,c,e) or -- for the last layer -- the max-pool gradient given as
  * dOut (b,c,e/s) + arg (b,c,e/s) (pass dA = NULL).  Produces s1 = sum dZ (= d beta) and

@@ -516,6 +516,68 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
   }
 }
 
+// ---- stand-alone batch statistics / BN+ReLU apply (small levels: the 1x1 conv is a library GEMM) ----
+// sum(y), sum(y^2) per channel of y (B, C, E); same launch geometry as the backward statistics.
+__global__ __launch_bounds__(BNB_THREADS) void channel_stats_kernel(int c, long E, const float *__restrict__ y,
+                                                                    double *__restrict__ s1,
+                                                                    double *__restrict__ s2) {
+  __shared__ float red[2][BNB_THREADS / 64];
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t row = ((size_t)bi * c + ch) * E;
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = (unsigned)min(E, (long)e0 + BNB_CHUNK);
+  float a1 = 0.f, a2 = 0.f;
+  if (e1 - e0 == (unsigned)BNB_CHUNK && (E & 3) == 0) {
+    const float4 *y4 = reinterpret_cast<const float4 *>(y + row + e0);
+    float4 v[BNB_CHUNK / 4 / BNB_THREADS];
+#pragma unroll
+    for (int it = 0; it < BNB_CHUNK / 4 / BNB_THREADS; ++it) v[it] = y4[it * BNB_THREADS + threadIdx.x];
+#pragma unroll
+    for (int it = 0; it < BNB_CHUNK / 4 / BNB_THREADS; ++it) {
+      a1 += (v[it].x + v[it].y) + (v[it].z + v[it].w);
+      a2 += (v[it].x * v[it].x + v[it].y * v[it].y) + (v[it].z * v[it].z + v[it].w * v[it].w);
+    }
+  } else {
+    for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+      const float yv = y[row + e];
+      a1 += yv;
+      a2 += yv * yv;
+    }
+  }
+  a1 = wave_allreduce_sum_f32(a1);
+  a2 = wave_allreduce_sum_f32(a2);
+  if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < BNB_THREADS / 64; ++w) t += (double)red[threadIdx.x][w];
+    unsafeAtomicAdd((threadIdx.x ? s2 : s1) + ch, t);
+  }
+}
+
+// out = relu(y * scale[c] + shift[c])  (BatchNorm2d(train) + ReLU of a middle layer)
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_apply_kernel(int c, long E, const float *__restrict__ y,
+                                                                    const float *__restrict__ scale,
+                                                                    const float *__restrict__ shift,
+                                                                    float *__restrict__ out) {
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t row = ((size_t)bi * c + ch) * E;
+  const float sc = scale[ch], sh = shift[ch];
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = (unsigned)min(E, (long)e0 + BNB_CHUNK);
+  if (e1 - e0 == (unsigned)BNB_CHUNK && (E & 3) == 0) {
+    const float4 *y4 = reinterpret_cast<const float4 *>(y + row + e0);
+    float4 *o4 = reinterpret_cast<float4 *>(out + row + e0);
+    float4 v[BNB_CHUNK / 4 / BNB_THREADS];
+#pragma unroll
+    for (int it = 0; it < BNB_CHUNK / 4 / BNB_THREADS; ++it) v[it] = y4[it * BNB_THREADS + threadIdx.x];
+#pragma unroll
+    for (int it = 0; it < BNB_CHUNK / 4 / BNB_THREADS; ++it)
+      o4[it * BNB_THREADS + threadIdx.x] = make_float4(fmaxf(0.f, v[it].x * sc + sh), fmaxf(0.f, v[it].y * sc + sh),
+                                                       fmaxf(0.f, v[it].z * sc + sh), fmaxf(0.f, v[it].w * sc + sh));
+    return;
+  }
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) out[row + e] = fmaxf(0.f, y[row + e] * sc + sh);
+}
+
 // ---- backward: weight gradient dW[co][ci] = sum_{b,e} dY[b,co,e] * a[b,ci,e] ----------------
 // a = x (first layer) or relu(x*pscale + pshift) (x = previous layer's raw conv output).
 // A reduction over ALL positions with a small (cout x cin) result: no LDS, no barriers.  One
@@ -772,6 +834,34 @@ extern "C" int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y,
   return 0;
 }
 
+
+extern "C" int sig3d_channel_stats(int b, int c, long e, const float *y, double *stat_sum,
+                                   double *stat_sq, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && e < (1L << 31), "bad size");
+  if (stat_sq == stat_sum + c) {
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * 2 * c, stream));
+  } else {
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * c, stream));
+    SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * c, stream));
+  }
+  if (b == 0 || e == 0) return 0;
+  dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
+  hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(BNB_THREADS), 0, stream, c, e, y, stat_sum, stat_sq);
+  SIG3D_LAUNCH_CHECK("channel_stats_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_bn_relu_apply(int b, int c, long e, const float *y, const float *scale,
+                                   const float *shift, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && e < (1L << 31), "bad size");
+  if (b == 0 || e == 0) return 0;
+  dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, grid, dim3(BNB_THREADS), 0, stream, c, e, y, scale, shift, out);
+  SIG3D_LAUNCH_CHECK("bn_relu_apply_kernel");
+  return 0;
+}
 
 // ---- backward entry points -----------------------------------------------------------------
 

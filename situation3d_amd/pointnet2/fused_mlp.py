@@ -42,16 +42,15 @@ def _layers(mlp):
     return out or None
 
 
-# Below this many (batch x npoint x nsample) positions a layer is a few tens of microseconds and
-# the per-layer launch count decides; measured cross-over on MI355X is between the SA2
-# (262 144 positions: fused 2.7 ms vs 3.8 ms) and SA3 (65 536: 1.20 ms vs 1.04 ms) shapes.
+# Below this many (batch x npoint x nsample) positions the 1x1 convolutions go to the library GEMM
+# (a few thousand 32-position tiles do not fill the MFMA kernel; measured cross-over on MI355X is
+# between the SA2 (262 144 positions) and SA3 (65 536) shapes); BatchNorm / ReLU / pooling stay fused.
 MIN_POSITIONS = 100000
 
 
 def can_fuse(mlp, x, min_positions=None):
+    """min_positions is kept for callers that force the decision; any position count qualifies now."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and mlp.training):
-        return False
-    if x.shape[0] * x.shape[2] * x.shape[3] < (MIN_POSITIONS if min_positions is None else min_positions):
         return False
     return _layers(mlp) is not None
 
@@ -61,8 +60,14 @@ def _aff_rows(t):
 
 
 class _FusedMLPMax(torch.autograd.Function):
+    """library_gemm=False: every layer is sig3d_mlp_layer_fwd (MFMA GEMM with BatchNorm+ReLU on operand
+    load and statistics in the epilogue).  library_gemm=True (small levels): the 1x1 convolutions and
+    the input gradients are library GEMMs (torch.bmm), BatchNorm statistics / apply / pooling and the
+    whole BatchNorm+ReLU backward stay on the kernels of csrc/shared_mlp.hip -- no MIOpen BatchNorm, no
+    separate ReLU / threshold / max-reduce / scatter launches."""
+
     @staticmethod
-    def forward(ctx, x, layers, *flat):
+    def forward(ctx, x, layers, library_gemm, *flat):
         # flat = (W_1, gamma_1, beta_1, W_2, gamma_2, beta_2, ...) so that autograd tracks them
         dev = x.device
         x = x.contiguous()
@@ -76,11 +81,22 @@ class _FusedMLPMax(torch.autograd.Function):
                 w = flat[3 * i].reshape(conv.out_channels, conv.in_channels).contiguous()
                 gamma, beta = flat[3 * i + 1], flat[3 * i + 2]
                 cout, cin = w.shape
-                y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
                 st = torch.empty((2, cout), dtype=torch.float64, device=dev)
-                _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
-                          _lib.ptr(ps), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
-                          stream)
+                if library_gemm:
+                    if ps is not None:  # materialise relu(bn(y_prev)) for the library GEMM
+                        act = torch.empty_like(cur)
+                        _lib.call("sig3d_bn_relu_apply", b, cin, e, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                                  _lib.ptr(act), stream)
+                    else:
+                        act = cur
+                    y = torch.bmm(w.unsqueeze(0).expand(b, cout, cin), act.view(b, cin, e)).view(b, cout, p, s)
+                    _lib.call("sig3d_channel_stats", b, cout, e, _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
+                              stream)
+                else:
+                    y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
+                              _lib.ptr(ps), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
+                              stream)
                 aff = torch.empty((4, cout), dtype=torch.float32, device=dev)
                 _lib.call("sig3d_bn_finalize", cout, ctypes.c_double(float(b) * e),
                           ctypes.c_float(bn.eps), ctypes.c_float(bn.momentum), _lib.ptr(st[0]),
@@ -100,6 +116,7 @@ class _FusedMLPMax(torch.autograd.Function):
         ctx.save_for_backward(x, arg, *ys, *affs, *ws)
         ctx.nl = len(layers)
         ctx.dims = (b, p, s)
+        ctx.library_gemm = library_gemm
         return out
 
     @staticmethod
@@ -145,21 +162,27 @@ class _FusedMLPMax(torch.autograd.Function):
                           _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), stream)
                 grads[3 * k] = dW.view(cout, cin, 1, 1)
                 if k > 0 or ctx.needs_input_grad[0]:
-                    wt = ws[k].t().contiguous()  # (cin, cout): dA = W^T dY through the same GEMM
-                    dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
-                    scratch = torch.empty((2, cin), dtype=torch.float64, device=dev)
-                    _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
-                              _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(scratch[0]),
-                              _lib.ptr(scratch[1]), stream)
+                    if ctx.library_gemm:
+                        dA = torch.bmm(ws[k].t().unsqueeze(0).expand(b, cin, cout), dY.view(b, cout, e)).view(b, cin, p, s)
+                    else:
+                        wt = ws[k].t().contiguous()  # (cin, cout): dA = W^T dY through the same GEMM
+                        dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
+                        scratch = torch.empty((2, cin), dtype=torch.float64, device=dev)
+                        _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
+                                  _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(scratch[0]),
+                                  _lib.ptr(scratch[1]), stream)
                     if k == 0:
                         grad_x = dA
-        return (grad_x, None) + tuple(grads)
+        return (grad_x, None, None) + tuple(grads)
 
 
-def fused_mlp_max(mlp, x):
-    """max over nsample of SharedMLP(x): x (B,C,npoint,nsample) -> (B,C_out,npoint)."""
+def fused_mlp_max(mlp, x, library_gemm=None):
+    """max over nsample of SharedMLP(x): x (B,C,npoint,nsample) -> (B,C_out,npoint).
+    library_gemm=None: decided by the position count (MIN_POSITIONS)."""
     layers = _layers(mlp)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _FusedMLPMax.apply(x, layers, *flat)
+    if library_gemm is None:
+        library_gemm = x.shape[0] * x.shape[2] * x.shape[3] < MIN_POSITIONS
+    return _FusedMLPMax.apply(x, layers, bool(library_gemm), *flat)

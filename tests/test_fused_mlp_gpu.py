@@ -21,7 +21,8 @@ def _close(a, b, name, tol=1e-4):
                                          (2, [259, 128, 128, 256], 33, 16), (1, [9, 32], 5, 7),
                                          (2, [35, 64, 32], 17, 12),
                                          (1, [6, 32, 64], 300, 64)])  # rows of 19200 positions: full 8192-chunks + tail
-def test_fused_mlp_max_matches_torch(b, chans, p, s):
+@pytest.mark.parametrize("library_gemm", [False, True])
+def test_fused_mlp_max_matches_torch(b, chans, p, s, library_gemm):
     from situation3d_amd.pointnet2 import fused_mlp
     from situation3d_amd.pointnet2.pytorch_utils import SharedMLP
     torch.manual_seed(sum(chans) + p)
@@ -38,8 +39,9 @@ def test_fused_mlp_max_matches_torch(b, chans, p, s):
     x2 = x.clone().requires_grad_(True)
     g = torch.randn(b, chans[-1], p, device=DEV)
 
-    assert fused_mlp.can_fuse(mlp, x1, min_positions=0)
-    out = fused_mlp.fused_mlp_max(mlp, x1)
+    assert fused_mlp.can_fuse(mlp, x1)
+    # library_gemm=False: MFMA layer kernels; True: torch.bmm convolutions + the same BN / pool kernels
+    out = fused_mlp.fused_mlp_max(mlp, x1, library_gemm=library_gemm)
     (out * g).sum().backward()
     exp = torch.max(ref(x2), dim=3)[0]
     (exp * g).sum().backward()
