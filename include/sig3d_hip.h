@@ -118,10 +118,13 @@ int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_
  * then BatchNorm2d, then ReLU) as ONE kernel: y (b,cout,e) = w (cout,cin) . a, where
  * a = x (b,cin,e) when pscale == NULL, else a = relu(x * pscale[ci] + pshift[ci]) -- i.e. the
  * PREVIOUS layer's BatchNorm+ReLU applied on load to its raw conv output.  stat_sum / stat_sq
- * (cout doubles each; zeroed here) receive sum_e y and sum_e y^2 per output channel. */
+ * (cout doubles each) receive sum_e y and sum_e y^2 per output channel; both NULL: no statistics
+ * (input-gradient use).  `accumulate` (here and in sig3d_channel_stats / sig3d_bn_relu_bwd /
+ * sig3d_mlp_layer_dw): 0 = the accumulators (stat_sum/stat_sq, s1/s2, dW) are zeroed by the call;
+ * != 0 = the caller zeroed them (e.g. every layer of a stack with one fill) and the call only adds. */
 int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                         const float *pscale, const float *pshift, float *y, double *stat_sum,
-                        double *stat_sq, void *stream);
+                        double *stat_sq, int accumulate, void *stream);
 
 /* Turns the sums into the layer's training-mode BatchNorm affine: scale = gamma/sqrt(var+eps),
  * shift = beta - mean*scale (biased var), saves mean / invstd for the backward pass and updates
@@ -142,7 +145,7 @@ int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y, const floa
  * a few thousand positions do not fill the MFMA kernel): per-channel sum(y), sum(y^2) of y (b,c,e)
  * as doubles (zeroed here; feed sig3d_bn_finalize), and out = relu(y*scale + shift). */
 int sig3d_channel_stats(int b, int c, long e, const float *y, double *stat_sum, double *stat_sq,
-                        void *stream);
+                        int accumulate, void *stream);
 int sig3d_bn_relu_apply(int b, int c, long e, const float *y, const float *scale, const float *shift,
                         float *out, void *stream);
 
@@ -154,13 +157,13 @@ int sig3d_bn_relu_apply(int b, int c, long e, const float *y, const float *scale
 int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, const float *dOut,
                       const int *arg, const float *y, const float *scale, const float *shift,
                       const float *mean, const float *invstd, double *s1, double *s2, float *dY,
-                      void *stream);
+                      int accumulate, void *stream);
 
 /* Weight gradient of one layer: dW (cout,cin) = sum_{b,e} dY[b,co,e] * a[b,ci,e], with a = x or
  * relu(x*pscale + pshift) exactly as in sig3d_mlp_layer_fwd.  dW is zeroed here.  (The input
  * gradient dA = W^T dY is sig3d_mlp_layer_fwd with x = dY and w = W^T.) */
 int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
-                       const float *pscale, const float *pshift, float *dW, void *stream);
+                       const float *pscale, const float *pshift, float *dW, int accumulate, void *stream);
 
 /* ---- situational pose re-encode -------------------------------------------------------- */
 

@@ -30,13 +30,13 @@ SIGNATURES = {
     "sig3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused": [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused_grad": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "sig3d_mlp_layer_fwd": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer_fwd": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_bn_finalize": [_I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_bn_relu_maxpool": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "sig3d_channel_stats": [_I, _I, ctypes.c_long, _P, _P, _P, _P],
+    "sig3d_channel_stats": [_I, _I, ctypes.c_long, _P, _P, _P, _I, _P],
     "sig3d_bn_relu_apply": [_I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
-    "sig3d_bn_relu_bwd": [_I, _I, ctypes.c_long, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "sig3d_mlp_layer_dw": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P],
+    "sig3d_bn_relu_bwd": [_I, _I, ctypes.c_long, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "sig3d_mlp_layer_dw": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_situational_transform": [_I, _I, _P, _P, _P, _I, _P],
     "sig3d_situational_transform_grad": [_I, _I, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_pos_embed_add": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     }
   }
 
+  if (stat_sum == nullptr) return;  // input-gradient use: no statistics wanted (uniform branch)
   // per-channel partial sums: the two half-waves hold disjoint position sets of the same channel
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -757,18 +758,27 @@ static int dispatch_mlp_fwd(bool prologue, bool vec, int b, int cin, int cout, l
              : launch_mlp_fwd<NT, false, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
 }
 
+// accumulate == 0: statistic / gradient accumulators are zeroed by the call; != 0: the caller zeroed
+// them (e.g. all layers of a stack with ONE fill) and the call only adds.
+static int zero_pair(double *a, double *b2, int n, int accumulate, hipStream_t stream) {
+  if (accumulate || a == nullptr) return 0;
+  if (b2 == a + n) {  // the usual (2, n) allocation: one memset node
+    SIG3D_HIP_TRY(hipMemsetAsync(a, 0, sizeof(double) * 2 * n, stream));
+  } else {
+    SIG3D_HIP_TRY(hipMemsetAsync(a, 0, sizeof(double) * n, stream));
+    SIG3D_HIP_TRY(hipMemsetAsync(b2, 0, sizeof(double) * n, stream));
+  }
+  return 0;
+}
+
 extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                                    const float *pscale, const float *pshift, float *y,
-                                   double *stat_sum, double *stat_sq, void *stream_) {
+                                   double *stat_sum, double *stat_sq, int accumulate, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
-  if (stat_sq == stat_sum + cout) {  // the usual (2, cout) allocation: one memset node
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * 2 * cout, stream));
-  } else {
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * cout, stream));
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * cout, stream));
-  }
+  SIG3D_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "stat_sum/stat_sq must come together");
+  if (int rc = zero_pair(stat_sum, stat_sq, cout, accumulate, stream)) return rc;
   if (b == 0 || e == 0) return 0;
   SIG3D_REQUIRE((long)cin * e < (1L << 31) && (long)cout * e < (1L << 31),
                 "cin*e and cout*e must stay below 2^31 (32-bit addressing inside the kernel)");
@@ -836,15 +846,10 @@ extern "C" int sig3d_bn_relu_maxpool(int b, int c, int p, int s, const float *y,
 
 
 extern "C" int sig3d_channel_stats(int b, int c, long e, const float *y, double *stat_sum,
-                                   double *stat_sq, void *stream_) {
+                                   double *stat_sq, int accumulate, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && e < (1L << 31), "bad size");
-  if (stat_sq == stat_sum + c) {
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * 2 * c, stream));
-  } else {
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sum, 0, sizeof(double) * c, stream));
-    SIG3D_HIP_TRY(hipMemsetAsync(stat_sq, 0, sizeof(double) * c, stream));
-  }
+  if (int rc = zero_pair(stat_sum, stat_sq, c, accumulate, stream)) return rc;
   if (b == 0 || e == 0) return 0;
   dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
   hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(BNB_THREADS), 0, stream, c, e, y, stat_sum, stat_sq);
@@ -868,18 +873,13 @@ extern "C" int sig3d_bn_relu_apply(int b, int c, long e, const float *y, const f
 extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, const float *dOut,
                                  const int *arg, const float *y, const float *scale,
                                  const float *shift, const float *mean, const float *invstd,
-                                 double *s1, double *s2, float *dY, void *stream_) {
+                                 double *s1, double *s2, float *dY, int accumulate, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && s >= 1, "bad size");
   SIG3D_REQUIRE((dA != nullptr) != (dOut != nullptr && arg != nullptr),
                 "pass either a dense dA or the (dOut, arg) pair of the max-pool");
   SIG3D_REQUIRE(e < (1L << 31) && e % s == 0, "positions per row must be a multiple of s and < 2^31");
-  if (s2 == s1 + c) {
-    SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * 2 * c, stream));
-  } else {
-    SIG3D_HIP_TRY(hipMemsetAsync(s1, 0, sizeof(double) * c, stream));
-    SIG3D_HIP_TRY(hipMemsetAsync(s2, 0, sizeof(double) * c, stream));
-  }
+  if (int rc = zero_pair(s1, s2, c, accumulate, stream)) return rc;
   if (b == 0 || e == 0) return 0;
   const double count = (double)b * (double)e;
   dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
@@ -920,12 +920,12 @@ static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, cons
 }
 
 extern "C" int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
-                                  const float *pscale, const float *pshift, float *dW,
+                                  const float *pscale, const float *pshift, float *dW, int accumulate,
                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0, "bad size");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
-  SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
+  if (!accumulate) SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
   if (b == 0 || e == 0) return 0;
   const bool vec = (e % 32 == 0);  // every 16-position run is in range and 16-byte aligned
   if (pscale) return vec ? launch_mlp_dw<true, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)

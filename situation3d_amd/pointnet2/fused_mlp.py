@@ -76,12 +76,15 @@ class _FusedMLPMax(torch.autograd.Function):
         stream = _lib.stream_ptr(dev)
         ys, affs, ws = [], [], []
         cur, ps, pb = x, None, None
+        cmax = max(conv.out_channels for conv, _ in layers)
         with torch.cuda.device(dev):
+            # all statistic accumulators of the stack are zeroed by ONE fill (accumulate = 1 below)
+            st_all = torch.zeros((len(layers), 2, cmax), dtype=torch.float64, device=dev)
             for i, (conv, bn) in enumerate(layers):
                 w = flat[3 * i].reshape(conv.out_channels, conv.in_channels).contiguous()
                 gamma, beta = flat[3 * i + 1], flat[3 * i + 2]
                 cout, cin = w.shape
-                st = torch.empty((2, cout), dtype=torch.float64, device=dev)
+                st = st_all[i]
                 if library_gemm:
                     if ps is not None:  # materialise relu(bn(y_prev)) for the library GEMM
                         act = torch.empty_like(cur)
@@ -91,12 +94,12 @@ class _FusedMLPMax(torch.autograd.Function):
                         act = cur
                     y = torch.bmm(w.unsqueeze(0).expand(b, cout, cin), act.view(b, cin, e)).view(b, cout, p, s)
                     _lib.call("sig3d_channel_stats", b, cout, e, _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
-                              stream)
+                              1, stream)
                 else:
                     y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
                     _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
                               _lib.ptr(ps), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
-                              stream)
+                              1, stream)
                 aff = torch.empty((4, cout), dtype=torch.float32, device=dev)
                 _lib.call("sig3d_bn_finalize", cout, ctypes.c_double(float(b) * e),
                           ctypes.c_float(bn.eps), ctypes.c_float(bn.momentum), _lib.ptr(st[0]),
@@ -136,30 +139,36 @@ class _FusedMLPMax(torch.autograd.Function):
         grad_x = None
         with torch.cuda.device(dev):
             dA = None
+            # one fill each for every BatchNorm-gradient accumulator and every dW of the stack
+            cmax = max(w.shape[0] for w in ws)
+            sums_all = torch.zeros((nl, 2, cmax), dtype=torch.float64, device=dev)
+            dw_all = torch.zeros(sum(w.numel() for w in ws), dtype=torch.float32, device=dev)
+            dw_off = 0
             for k in range(nl - 1, -1, -1):
                 cout, cin = ws[k].shape
                 scale, shift, mean, invstd = _aff_rows(affs[k])
-                sums = torch.empty((2, cout), dtype=torch.float64, device=dev)
+                sums = sums_all[k]
                 dY = torch.empty_like(ys[k])
                 if k == nl - 1:
                     _lib.call("sig3d_bn_relu_bwd", b, cout, e, s, _lib.ptr(None), _lib.ptr(grad_out),
                               _lib.ptr(arg), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
-                              _lib.ptr(dY), stream)
+                              _lib.ptr(dY), 1, stream)
                 else:
                     _lib.call("sig3d_bn_relu_bwd", b, cout, e, s, _lib.ptr(dA), _lib.ptr(None),
                               _lib.ptr(None), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
-                              _lib.ptr(dY), stream)
-                sums32 = sums.to(torch.float32)                # one conversion launch for both rows
+                              _lib.ptr(dY), 1, stream)
+                sums32 = sums[:, :cout].to(torch.float32)      # one conversion launch for both rows
                 grads[3 * k + 1] = sums32[1]                   # d gamma
                 grads[3 * k + 2] = sums32[0]                   # d beta
                 prev = ys[k - 1] if k > 0 else x
                 pps = affs[k - 1][0] if k > 0 else None
                 ppb = affs[k - 1][1] if k > 0 else None
-                dW = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+                dW = dw_all[dw_off:dw_off + cout * cin].view(cout, cin)
+                dw_off += cout * cin
                 _lib.call("sig3d_mlp_layer_dw", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
-                          _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), stream)
+                          _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, stream)
                 grads[3 * k] = dW.view(cout, cin, 1, 1)
                 if k > 0 or ctx.needs_input_grad[0]:
                     if ctx.library_gemm:
@@ -167,10 +176,9 @@ class _FusedMLPMax(torch.autograd.Function):
                     else:
                         wt = ws[k].t().contiguous()  # (cin, cout): dA = W^T dY through the same GEMM
                         dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
-                        scratch = torch.empty((2, cin), dtype=torch.float64, device=dev)
                         _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
-                                  _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(scratch[0]),
-                                  _lib.ptr(scratch[1]), stream)
+                                  _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
+                                  _lib.ptr(None), 0, stream)   # no statistics for an input gradient
                     if k == 0:
                         grad_x = dA
         return (grad_x, None, None) + tuple(grads)

@@ -29,12 +29,12 @@ for name, b, chans, p, ns in [("SA1", 8, [6, 64, 64, 128], 2048, 64), ("SA2", 8,
         ps = torch.rand(cin, device=dev) + 0.5 if li else None
         pb = torch.randn(cin, device=dev) * 0.1 if li else None
         t = timeit(lambda: L.call("sig3d_mlp_layer_fwd", b, cin, cout, e, L.ptr(x), L.ptr(w), L.ptr(ps), L.ptr(pb),
-                                  L.ptr(y), L.ptr(st[0]), L.ptr(st[1]), L.stream_ptr()))
+                                  L.ptr(y), L.ptr(st[0]), L.ptr(st[1]), 0, L.stream_ptr()))
         byt = 4.0 * b * e * (cin + cout)
         print("%s L%d fwd  %3d->%3d : %7.1f us  %5.2f TB/s  (%.0f MB, %.1f GFLOP -> %.0f us at 157 TF)" % (
             name, li + 1, cin, cout, t, byt / t / 1e6, byt / 1e6, 2e-9 * b * e * cin * cout, 2e-3 * b * e * cin * cout / 157e3 * 1e3))
         dw = torch.empty(cout, cin, device=dev)
         t = timeit(lambda: L.call("sig3d_mlp_layer_dw", b, cin, cout, e, L.ptr(y), L.ptr(x), L.ptr(ps), L.ptr(pb),
-                                  L.ptr(dw), L.stream_ptr()))
+                                  L.ptr(dw), 0, L.stream_ptr()))
         print("%s L%d dW               : %7.1f us  %5.2f TB/s" % (name, li + 1, t, byt / t / 1e6))
         x = y

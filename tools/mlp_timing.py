@@ -12,7 +12,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-shared", "-DSIG3D_M
                        os.path.join(CSRC, "shared_mlp.hip"), os.path.join(CSRC, "capi.hip"), "-o", so] + FLAGS)
 lib = ctypes.CDLL(so)
 P, I = ctypes.c_void_p, ctypes.c_int
-lib.sig3d_mlp_layer_fwd.argtypes = [I, I, I, ctypes.c_long] + [P] * 8
+lib.sig3d_mlp_layer_fwd.argtypes = [I, I, I, ctypes.c_long] + [P] * 7 + [I, P]
 dev = "cuda:0"
 for name, b, cin, cout, e in [("SA1 L3", 8, 64, 128, 131072), ("SA2 L3", 8, 128, 256, 32768), ("SA2 L2", 8, 128, 128, 32768)]:
     x = torch.randn(b, cin, e, device=dev); w = torch.randn(cout, cin, device=dev)
@@ -22,7 +22,7 @@ for name, b, cin, cout, e in [("SA1 L3", 8, 64, 128, 131072), ("SA2 L3", 8, 128,
     marks = (ctypes.c_ulonglong * 64)(); n = ctypes.c_int(0)
     for it in range(3):
         lib.sig3d_debug_mlp_marks(marks, ctypes.byref(n))
-        lib.sig3d_mlp_layer_fwd(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]),
+        lib.sig3d_mlp_layer_fwd(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]), 0,
                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
     lib.sig3d_debug_mlp_marks(marks, ctypes.byref(n))
