@@ -62,6 +62,9 @@ def to_device(d, device):
     return out
 
 
+CPU_SCENES = 4   # scenes in the bounded cpu_baseline sample
+
+
 def group_algorithmic_bytes(b, n, m, ns, c):
     """group_points(C) = B*(4CN + 4*M*ns + 4C*M*ns); the fused kernel moves the xyz
     group (C=3) and the feature group (C=c) in one launch and reads idx once."""
@@ -69,13 +72,14 @@ def group_algorithmic_bytes(b, n, m, ns, c):
 
 
 def cpu_baseline(model, seed):
-    """The same step on the host cores through the ORACLE (kind "port"): one scene (B=1) of the
-    B=8 workload, forward + backward.  Checker code only -- never on the product path."""
+    """The same step on the host cores through the ORACLE (kind "port"): CPU_SCENES scenes of the
+    B=8 workload as one batch, forward + backward (~10 s).  Checker code only -- never on the
+    product path."""
     from oracle import pointnet2_ref, qformer_ref
     from situation3d_amd.pointnet2 import pointnet2_utils
     import copy
     cpu_model = copy.deepcopy(model).cpu().train()
-    batch = synthetic_batch(1, N_POINTS, seed, "cpu")
+    batch = synthetic_batch(CPU_SCENES, N_POINTS, seed, "cpu")
     saved_ext = pointnet2_utils._ext
     pointnet2_utils._ext = pointnet2_ref  # CPU restatement of the nine ops
     try:
@@ -96,8 +100,8 @@ def cpu_baseline(model, seed):
                    layer_norm_eps=c.layer_norm_eps, add_cross_attention=True,
                    cross_attention_freq=c.cross_attention_freq)
         q = batch["q_feat"]
-        att = torch.cat([torch.ones(1, N_QUERY, dtype=torch.long), q["attention_mask"]], 1)
-        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=cpu_model.query_tokens.expand(1, -1, -1),
+        att = torch.cat([torch.ones(CPU_SCENES, N_QUERY, dtype=torch.long), q["attention_mask"]], 1)
+        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=cpu_model.query_tokens.expand(CPU_SCENES, -1, -1),
                                         input_ids=q["input_ids"], attention_mask=att,
                                         encoder_hidden_states=tokens)
         pooled = hidden[:, :N_QUERY].mean(1)
@@ -109,10 +113,12 @@ def cpu_baseline(model, seed):
         dt = time.perf_counter() - t0
     finally:
         pointnet2_utils._ext = saved_ext
-    return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": pointnet2_ref.num_threads(),
+    threads = max(pointnet2_ref.num_threads(), torch.get_num_threads())
+    return {"value": round(CPU_SCENES / dt, 4), "unit": "samples/s", "cores": threads,
             "kind": "port",
-            "sample": "1 scene (B=1 of the B=8 step), 40k pts, fwd+bwd, oracle C ops (OpenMP) + "
-                      "torch CPU fp32 MLP/Q-Former, %d host cores, %.1f s" % (os.cpu_count(), dt)}
+            "sample": "%d scenes (B=%d of the B=8 step), 40k pts, fwd+bwd, oracle C ops (OpenMP, %d threads) + "
+                      "torch CPU fp32 MLP/Q-Former (%d threads), %.1f s of wall time"
+                      % (CPU_SCENES, CPU_SCENES, pointnet2_ref.num_threads(), torch.get_num_threads(), dt)}
 
 
 def main():
