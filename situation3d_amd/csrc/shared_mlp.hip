@@ -230,19 +230,34 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     ML_MARK(4);
   };
 
-  float b0[ML_KC], b1[ML_KC], b2[ML_KC];
-  if (total > 0) issue(b0, 0);
-  if (total > 1) issue(b1, 1);
-  for (int g = 0; g < total; g += 3) {
-    if (g + 2 < total) issue(b2, g + 2);
-    consume(b0, g);
-    if (g + 1 < total) {
-      if (g + 3 < total) issue(b0, g + 3);
-      consume(b1, g + 1);
+  if (NT >= 4) {
+    // NT = 4: a chunk is 64 MFMAs (~4.5 us with the pipe shared), one chunk of lookahead covers the
+    // load latency, and the 16 registers of a third buffer are what separates 2 from 3 waves per SIMD
+    float b0[ML_KC], b1[ML_KC];
+    if (total > 0) issue(b0, 0);
+    for (int g = 0; g < total; g += 2) {
+      if (g + 1 < total) issue(b1, g + 1);
+      consume(b0, g);
+      if (g + 1 < total) {
+        if (g + 2 < total) issue(b0, g + 2);
+        consume(b1, g + 1);
+      }
     }
-    if (g + 2 < total) {
-      if (g + 4 < total) issue(b1, g + 4);
-      consume(b2, g + 2);
+  } else {
+    float b0[ML_KC], b1[ML_KC], b2[ML_KC];
+    if (total > 0) issue(b0, 0);
+    if (total > 1) issue(b1, 1);
+    for (int g = 0; g < total; g += 3) {
+      if (g + 2 < total) issue(b2, g + 2);
+      consume(b0, g);
+      if (g + 1 < total) {
+        if (g + 3 < total) issue(b0, g + 3);
+        consume(b1, g + 1);
+      }
+      if (g + 2 < total) {
+        if (g + 4 < total) issue(b1, g + 4);
+        consume(b2, g + 2);
+      }
     }
   }
 
@@ -727,12 +742,12 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  // one full round of resident workgroups: occupancy per CU from LDS and registers (182 / 134 /
-  // 120 VGPRs for NT = 4 / 2 / 1 -> 2 / 3 / 4 waves per SIMD), 256 CUs
+  // one full round of resident workgroups: occupancy per CU from LDS and registers (168 / 134 /
+  // 120 VGPRs for NT = 4 / 2 / 1 -> 3 / 3 / 4 waves per SIMD), 256 CUs
   const long wave_tiles = (e + 31) / 32;
   const int cblocks = sig3d_ceil_div(cout, CT);
   int occ = (int)((160 * 1024) / lds);
-  const int occ_regs = NT == 1 ? 4 : (NT == 2 ? 3 : 2);
+  const int occ_regs = NT == 1 ? 4 : 3;
   if (occ > occ_regs) occ = occ_regs;
   if (occ < 1) occ = 1;
   long gy = (256L * occ + (long)b * cblocks - 1) / ((long)b * cblocks);
