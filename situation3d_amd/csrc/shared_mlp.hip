@@ -38,12 +38,13 @@ constexpr int ML_TRLD = 36;  // row stride of the epilogue transpose buffer (16-
 // (0,0,0) appends the 100 MHz real-time counter at every mark.
 #ifdef SIG3D_MLP_TIMING
 __device__ unsigned long long g_ml_marks[64];
+__device__ unsigned long long g_ml_cycles[64];   // shader-clock counter at the same marks
 __device__ int g_ml_nmarks;
 #define ML_MARK(id)                                                                              \
   do {                                                                                           \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {             \
       const int n_ = g_ml_nmarks;                                                                \
-      if (n_ < 64) { g_ml_marks[n_] = ((unsigned long long)(id) << 56) | __builtin_amdgcn_s_memrealtime(); g_ml_nmarks = n_ + 1; } \
+      if (n_ < 64) { g_ml_marks[n_] = ((unsigned long long)(id) << 56) | __builtin_amdgcn_s_memrealtime(); g_ml_cycles[n_] = __builtin_readcyclecounter(); g_ml_nmarks = n_ + 1; } \
     }                                                                                            \
   } while (0)
 #else
@@ -112,7 +113,6 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   }
   __syncthreads();
   ML_MARK(1);
-
   const float *xb = x + (size_t)bi * cin * E;
   float *yb = y + (size_t)bi * cout * E;
   float s1[NT], s2[NT];
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < ML_KC; ++i) {
       const int k = (c * ML_KC + i) * 2 + half;
+#ifdef ML_EXP_NO_LOAD
+      buf[i] = __builtin_bit_cast(float, (unsigned)k * 0x9E3779B9u + eo) * 1e-30f;
+#else
       buf[i] = xb[(unsigned)min(k, cin - 1) * (unsigned)E + eo];
+#endif
     }
   };
   auto consume = [&](const float (&buf)[ML_KC], int g) {
@@ -181,8 +185,12 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const float v0 = acc[nt][4 * g4], v1 = acc[nt][4 * g4 + 1], v2 = acc[nt][4 * g4 + 2], v3 = acc[nt][4 * g4 + 3];
           if (VEC && full) {
+#ifndef ML_EXP_NO_STATS
             s1[nt] += (v0 + v1) + (v2 + v3);
             s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+#else
+            s1[nt] += v0;
+#endif
           } else {
             const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -196,7 +204,11 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
         }
       }
     }
+#ifdef ML_EXP_NO_TRANSPOSE
+    if (false) {
+#else
     if (VEC && full) {
+#endif
       // Stores through a wave-private LDS transpose.  In the accumulator layout a lane owns ONE
       // channel row, so a direct store instruction scatters 64 separate 16-byte pieces over 64
       // rows and every 128-byte line of y is assembled from 8 partial writes (2.9 TB/s at SA1
@@ -208,8 +220,11 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 #pragma unroll
         for (int hrow = 0; hrow < 2; ++hrow) {  // 16 channel rows per pass
           if ((l31 >> 4) == hrow) {
+            // registers 4g..4g+3 are four consecutive positions 8g + 4*half + (0..3): 16-byte LDS writes
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_tr[(l31 & 15) * ML_TRLD + mrow(r, half)] = acc[nt][r];
+            for (int g4 = 0; g4 < 4; ++g4)
+              *reinterpret_cast<float4 *>(s_tr + (l31 & 15) * ML_TRLD + 8 * g4 + 4 * half) =
+                  make_float4(acc[nt][4 * g4], acc[nt][4 * g4 + 1], acc[nt][4 * g4 + 2], acc[nt][4 * g4 + 3]);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
@@ -219,7 +234,11 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
             const int row = trow + 8 * j;
             const int co = co0 + nt * 32 + hrow * 16 + row;
             const float4 v = *reinterpret_cast<const float4 *>(s_tr + row * ML_TRLD + tcol);
+#ifdef ML_EXP_NO_STORE
+            if (co < cout && v.x == 123.456f) *reinterpret_cast<float4 *>(yb + ((unsigned)co * (unsigned)E + (unsigned)e0 + tcol)) = v;
+#else
             if (co < cout) *reinterpret_cast<float4 *>(yb + ((unsigned)co * (unsigned)E + (unsigned)e0 + tcol)) = v;
+#endif
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
@@ -720,6 +739,10 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
 
 // ---- C ABI ----------------------------------------------------------------------------------
 #ifdef SIG3D_MLP_TIMING
+extern "C" int sig3d_debug_mlp_cycles(unsigned long long *host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ml_cycles), sizeof(unsigned long long) * 64);
+}
+
 extern "C" int sig3d_debug_mlp_marks(unsigned long long *host_out, int *n) {
   int zero = 0;
   hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ml_marks), sizeof(unsigned long long) * 64);

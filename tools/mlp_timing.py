@@ -25,7 +25,12 @@ for name, b, cin, cout, e in [("SA1 L3", 8, 64, 128, 131072), ("SA2 L3", 8, 128,
         lib.sig3d_mlp_layer_fwd(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]), 0,
                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
+    cyc = (ctypes.c_ulonglong * 64)()
+    lib.sig3d_debug_mlp_cycles(cyc)
     lib.sig3d_debug_mlp_marks(marks, ctypes.byref(n))
     t0 = marks[0] & ((1 << 56) - 1)
+    last = min(n.value, 64) - 1
+    dt_us = ((marks[last] & ((1 << 56) - 1)) - t0) / 100.0
+    print("   shader clock over the marked span: %.0f MHz (%d cycles in %.1f us)" % ((cyc[last] - cyc[0]) / dt_us, cyc[last] - cyc[0], dt_us))
     print("==", name, "marks:", n.value)
     print("  " + " ".join("%d@%.2f" % (marks[i] >> 56, ((marks[i] & ((1 << 56) - 1)) - t0) / 100.0) for i in range(min(n.value, 40))))
