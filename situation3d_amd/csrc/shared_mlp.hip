@@ -73,7 +73,7 @@ __host__ __device__ inline int ml_kpad(int cin) { return (cin + 2 * ML_KC - 1) /
 // The A operand (one activation value per lane per K-step, a coalesced 128-byte row segment per
 // half-wave) is software-pipelined in chunks of ML_KC steps: the loads of chunk c+1 are in flight
 // while the MFMAs of chunk c issue.
-template <int NT, bool PROLOGUE, bool VEC>
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
 __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int co0 = blockIdx.x * CT;
   const int bi = blockIdx.z;
+  const int nt_act = min(NT, (cout - co0 + 31) / 32);  // 32-channel tiles of this block that hold channels
   float *s_tr = s_red + ML_WAVES * 2 * CT + wave * (16 * ML_TRLD);  // [ML_WAVES][16][ML_TRLD], wave-private
 
   ML_MARK(0);
@@ -161,15 +162,39 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
     }
+    // Two bodies.  The common one is branch-free straight-line code (any per-step branch cuts the
+    // chunk into basic blocks and exposes the LDS operand latency of every step: +25 % measured).
+    // The ragged one -- last K chunk with padding steps (cin = 131 pads to 160, 259 to 288) or a
+    // channel block with empty 32-channel tiles (cout = 131: the second block holds 3 channels) --
+    // skips the padding MFMAs under uniform predicates.
+    // (RAGGED is a template parameter: compiled into the common kernel, the second body costs the
+    // NT = 4 variant its third wave per SIMD.)
+    const bool ragged = RAGGED && (nt_act < NT || (c + 1) * ML_KC * 2 > cin + 1);
+    if (!ragged) {
 #pragma unroll
-    for (int i = 0; i < ML_KC; ++i) {
-      const int k = (c * ML_KC + i) * 2 + half;
-      float a = buf[i];
-      if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
-      a = (k < cin) ? a : 0.f;
+      for (int i = 0; i < ML_KC; ++i) {
+        const int k = (c * ML_KC + i) * 2 + half;
+        float a = buf[i];
+        if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
+        a = (k < cin) ? a : 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ML_KC; ++i) {
+        if ((c * ML_KC + i) * 2 < cin) {
+          const int k = (c * ML_KC + i) * 2 + half;
+          float a = buf[i];
+          if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);
+          a = (k < cin) ? a : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (nt < nt_act)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s_w[(nt * 32 + l31) * ldw + k], acc[nt], 0, 0, 0);
+        }
+      }
     }
     ML_MARK(3);
     if (c != nchunks - 1) return;
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
       const int trow = lane >> 3, tcol = (lane & 7) * 4;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        if (RAGGED && nt >= nt_act) continue;
 #pragma unroll
         for (int hrow = 0; hrow < 2; ++hrow) {  // 16 channel rows per pass
           if ((l31 >> 4) == hrow) {
@@ -657,6 +683,9 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  // ragged blocks (cin = 6, 131, 259: the last 64-wide block holds 3-6 channels; cout = 64 exactly):
+  // 32-row tiles without any channel are skipped, loads and MFMAs alike (uniform per workgroup)
+  const int ni = (cout - co0 > 32) ? 2 : 1, nj = (cin - ci0 > 32) ? 2 : 1;
 
   const long n_steps = (E + 31) / 32;
   const long st_begin = ((long)blockIdx.x * DW_WAVES + wave) * steps_per_wave;
@@ -682,8 +711,8 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
   if (st_begin < st_end) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      load_frag(fa[0][t], arow[t], st_begin * 32, aok[t]);
-      load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
+      if (t < ni) load_frag(fa[0][t], arow[t], st_begin * 32, aok[t]);
+      if (t < nj) load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
     }
   }
   for (long st = st_begin; st < st_end; st += 2) {
@@ -694,8 +723,8 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
         if (cur + 1 < st_end) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            load_frag(fa[ph ^ 1][t], arow[t], (cur + 1) * 32, aok[t]);
-            load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
+            if (t < ni) load_frag(fa[ph ^ 1][t], arow[t], (cur + 1) * 32, aok[t]);
+            if (t < nj) load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
           }
         }
         const bool tail = !VEC && (cur * 32 + 32 > E);
@@ -714,7 +743,8 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+              if (i < ni && j < nj)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -752,7 +782,7 @@ extern "C" int sig3d_debug_mlp_marks(unsigned long long *host_out, int *n) {
 }
 #endif
 
-template <int NT, bool PROLOGUE, bool VEC>
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
 static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                           const float *pscale, const float *pshift, float *y, double *stat_sum,
                           double *stat_sq, hipStream_t stream) {
@@ -761,7 +791,7 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
   const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT + ML_WAVES * 16 * ML_TRLD);
   static bool attr_done = false;  // per template instance
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -779,21 +809,31 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
   if (gy < 1) gy = 1;
   const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
   dim3 grid(cblocks, (unsigned)gy, b);
-  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC>), grid, dim3(ML_WAVES * 64), lds, stream,
+  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED>), grid, dim3(ML_WAVES * 64), lds, stream,
                      cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
   return 0;
+}
+
+template <int NT, bool RAGGED>
+static int dispatch_mlp_fwd2(bool prologue, bool vec, int b, int cin, int cout, long e, const float *x,
+                             const float *w, const float *pscale, const float *pshift, float *y,
+                             double *stat_sum, double *stat_sq, hipStream_t stream) {
+  if (prologue)
+    return vec ? launch_mlp_fwd<NT, true, true, RAGGED>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+               : launch_mlp_fwd<NT, true, false, RAGGED>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  return vec ? launch_mlp_fwd<NT, false, true, RAGGED>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+             : launch_mlp_fwd<NT, false, false, RAGGED>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
 }
 
 template <int NT>
 static int dispatch_mlp_fwd(bool prologue, bool vec, int b, int cin, int cout, long e, const float *x,
                             const float *w, const float *pscale, const float *pshift, float *y,
                             double *stat_sum, double *stat_sq, hipStream_t stream) {
-  if (prologue)
-    return vec ? launch_mlp_fwd<NT, true, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
-               : launch_mlp_fwd<NT, true, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
-  return vec ? launch_mlp_fwd<NT, false, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
-             : launch_mlp_fwd<NT, false, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  // padding K-steps (cin not a multiple of 32) or empty 32-channel tiles in the last channel block
+  const bool ragged = (cin % (2 * ML_KC) != 0 && ml_kpad(cin) - cin >= 2) || (cout % (32 * NT) != 0 && cout % (32 * NT) <= 32 * (NT - 1));
+  return ragged ? dispatch_mlp_fwd2<NT, true>(prologue, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream)
+                : dispatch_mlp_fwd2<NT, false>(prologue, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
 }
 
 // accumulate == 0: statistic / gradient accumulators are zeroed by the call; != 0: the caller zeroed
