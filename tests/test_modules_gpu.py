@@ -168,6 +168,45 @@ def test_qformer_with_question_tokens_matches_reference(segmented):
             _close(params[k[len("t.grad."):]].grad, v, k)
 
 
+@pytest.mark.parametrize("b,tq,tt", [(3, 5, 9), (2, 32, 20), (1, 7, 1)])
+def test_qformer_padded_segment_layout_equals_plain_layout(b, tq, tt):
+    """The hot-path layout ([query rows, pad | text rows, pad], batched feed-forward GEMMs, token->row
+    mapping inside the attention kernels) against the plain (B, N, C) execution of the same modules:
+    outputs and every gradient, including text longer than the queries and odd sizes."""
+    from situation3d_amd.qformer import QFormer, QFormerConfig
+    torch.manual_seed(b * 100 + tq)
+    cfg = QFormerConfig(vocab_size=200, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=64, encoder_width=96,
+                        cross_attention_freq=2, query_length=tq, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    model = QFormer(cfg).to(DEV).train()
+    ids = torch.randint(1, 200, (b, tt), device=DEV)
+    att = torch.ones(b, tq + tt, dtype=torch.long, device=DEV)
+    att[0, -1] = 0                                   # one padded text token
+    enc = torch.randn(b, 11, 96, device=DEV)
+    G = torch.randn(b, tq + tt, 128, device=DEV)
+    results = []
+    for segmented in (False, True):
+        model.bert.segmented_layout = segmented
+        model.zero_grad(set_to_none=True)
+        q = (torch.randn(b, tq, 128, generator=torch.Generator().manual_seed(1)) * 0.1).to(DEV).requires_grad_(True)
+        e = enc.clone().requires_grad_(True)
+        out = model.bert(input_ids=ids, attention_mask=att, query_embeds=q, encoder_hidden_states=e,
+                         return_dict=True).last_hidden_state
+        (out * G).sum().backward()
+        results.append((out.detach(), q.grad, e.grad, {n: p.grad.clone() for n, p in model.bert.named_parameters()
+                                                       if p.grad is not None}))
+    (o0, q0, e0, g0), (o1, q1, e1, g1) = results
+    # same arithmetic up to GEMM blocking / summation order: 1e-4 (north star), observed ~1e-6
+    torch.testing.assert_close(o1, o0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(q1, q0, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(e1, e0, rtol=1e-3, atol=1e-4)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        scale = max(1.0, g0[n].abs().max().item())
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-3, atol=1e-4 * scale, msg=lambda m: n + ": " + m)
+
+
 def test_composed_model_step_and_entry_smoke():
     """forward(data_dict) contract keys + one optimiser step; then the driver's smoke()."""
     import __graft_entry__
