@@ -49,10 +49,17 @@ MIN_POSITIONS = 100000
 
 
 def can_fuse(mlp, x, min_positions=None):
-    """min_positions is kept for callers that force the decision; any position count qualifies now."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and mlp.training):
+    """min_positions is kept for callers that force the decision; any position count qualifies now.
+    Training mode: the autograd Function below.  Eval mode: the inference path (running statistics),
+    only when no gradient is wanted (torch.no_grad / frozen inputs and weights)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
         return False
-    return _layers(mlp) is not None
+    if _layers(mlp) is None:
+        return False
+    if mlp.training:
+        return True
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mlp.parameters()))
+    return not needs_grad
 
 
 def _aff_rows(t):
@@ -184,10 +191,40 @@ class _FusedMLPMax(torch.autograd.Function):
         return (grad_x, None, None) + tuple(grads)
 
 
+def _fused_mlp_max_eval(layers, x):
+    """Inference: BatchNorm2d.eval() is the affine map scale = gamma / sqrt(running_var + eps),
+    shift = beta - running_mean * scale, so a layer is one sig3d_mlp_layer_fwd (previous layer's
+    BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool."""
+    dev = x.device
+    x = x.contiguous()
+    b, _, p, s = x.shape
+    e = p * s
+    stream = _lib.stream_ptr(dev)
+    cur, ps, pb = x, None, None
+    with torch.no_grad(), torch.cuda.device(dev):
+        for conv, bn in layers:
+            w = conv.weight.reshape(conv.out_channels, conv.in_channels).contiguous()
+            cout, cin = w.shape
+            y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
+            _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w), _lib.ptr(ps),
+                      _lib.ptr(pb), _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0, stream)
+            scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+            shift = (bn.bias - bn.running_mean * scale).contiguous()
+            cur, ps, pb = y, scale, shift
+        c_last = cur.shape[1]
+        out = torch.empty((b, c_last, p), dtype=torch.float32, device=dev)
+        arg = torch.empty((b, c_last, p), dtype=torch.int32, device=dev)
+        _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                  _lib.ptr(out), _lib.ptr(arg), stream)
+    return out
+
+
 def fused_mlp_max(mlp, x, library_gemm=None):
     """max over nsample of SharedMLP(x): x (B,C,npoint,nsample) -> (B,C_out,npoint).
     library_gemm=None: decided by the position count (MIN_POSITIONS)."""
     layers = _layers(mlp)
+    if not mlp.training:
+        return _fused_mlp_max_eval(layers, x)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]

@@ -54,7 +54,7 @@ def test_fused_mlp_max_matches_torch(b, chans, p, s, library_gemm):
         _close(b1.float(), b2.float(), n1, tol=1e-5)
 
 
-def test_fused_path_is_taken_by_sa_module_and_falls_back_in_eval():
+def test_fused_path_is_taken_by_sa_module_in_train_and_inference():
     from situation3d_amd.pointnet2 import fused_mlp, pointnet2_modules
     from util import feats, scene
     mod = pointnet2_modules.PointnetSAModuleVotes(npoint=64, radius=0.8, nsample=16, mlp=[5, 32, 64],
@@ -69,8 +69,12 @@ def test_fused_path_is_taken_by_sa_module_and_falls_back_in_eval():
         _, a, _ = mod(xyz, f)
         assert calls == [1]
         mod.eval()
-        _, bb, _ = mod(xyz, f)  # eval mode uses running stats through the unfused torch path
+        _, bb, _ = mod(xyz, f)  # eval mode WITH autograd: the unfused torch path (running stats)
         assert calls == [1]
+        with torch.no_grad():
+            _, cc, _ = mod(xyz, f)  # eval mode, no gradient wanted: the fused inference path
+        assert calls == [1, 1]
+        torch.testing.assert_close(cc, bb, rtol=1e-4, atol=1e-4)
     finally:
         fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS = orig, orig_min
     assert a.shape == bb.shape == (2, 64, 64)
