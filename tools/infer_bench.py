@@ -1,0 +1,37 @@
+"""Forward-only throughput (BASELINE config 2: B=4, 40k points, eval mode, no autograd), eager and as a
+captured hipGraph.  python tools/infer_bench.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+from situation3d_amd import gemm_tuning
+from situation3d_amd.model import SIG3DQFormer
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+gemm_tuning.enable(tune_missing=True)
+torch.manual_seed(0)
+B = 4
+model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS).to(dev).eval()
+batch = bench.synthetic_batch(B, bench.N_POINTS, 7, dev)
+work = torch.cuda.Stream(dev)
+with torch.cuda.stream(work), torch.no_grad():
+    for _ in range(3):
+        out = model(dict(batch))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        out = model(dict(batch))
+    torch.cuda.synchronize()
+    eager = (time.perf_counter() - t0) / 10
+    g = torch.cuda.CUDAGraph()
+    with gemm_tuning.no_tuning(), torch.cuda.graph(g, stream=work):
+        out = model(dict(batch))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    graphed = (time.perf_counter() - t0) / 20
+print("forward only, B=%d x %d pts: eager %.2f ms (%.0f samples/s), hipGraph %.2f ms (%.0f samples/s)"
+      % (B, bench.N_POINTS, eager * 1e3, B / eager, graphed * 1e3, B / graphed))
