@@ -285,7 +285,11 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
                         const float *q,
                         const float *k, const float *v, const float *mask, float *out,
                         float *lse, float p_drop, unsigned call_id, const unsigned *rng_counter,
-                        void *stream);
+                        int key_splits, float *workspace, void *stream);
+/* key_splits > 1 (few queries, many keys -- the 3D-LLM shapes of 5000..80000 scene tokens): the key
+ * range is cut into key_splits pieces so that the launch covers the chip, and a second kernel folds
+ * the pieces; workspace = b*h*roundup32(nq)*key_splits*66 floats.  key_splits <= 1: one pass, workspace
+ * may be NULL. */
 /* p_drop > 0: attention-probability dropout (Qformer.py:219).  The keep bit of element
  * (b, head, query, key) is hash(*rng_counter, call_id, index), identical in forward and backward;
  * advance the device counter once per forward pass (sig3d_counter_increment).  p_drop == 0 is the

@@ -51,7 +51,7 @@ SIGNATURES = {
     "sig3d_adamw_table": [_I, _P, _P, _F, _F, _F, _F, _F, _P],
     "sig3d_gather_table": [_I, _P, _P],
     "sig3d_attention_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F,
-                            ctypes.c_uint, _P, _P],
+                            ctypes.c_uint, _P, _I, _P, _P],
     "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _F, ctypes.c_uint, _P, _P],
 }

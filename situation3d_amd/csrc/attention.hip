@@ -136,14 +136,18 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     int ldv, float scale, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
     const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
-    float *__restrict__ out, float *__restrict__ lse) {
+    float *__restrict__ out, float *__restrict__ lse, int key_splits, float *__restrict__ part) {
   __shared__ float s_o[AT_WAVES][AT_D][32];
   __shared__ float s_m[AT_WAVES][32];
   __shared__ float s_l[AT_WAVES][32];
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q0 = blockIdx.x * 32, hi = blockIdx.y, bi = blockIdx.z;
+  // blockIdx.x = query tile * key_splits + key split: with few queries and many keys (3D-LLM: 32 x
+  // 5000..80000) the key range is cut into key_splits pieces so that the grid covers the chip; the
+  // pieces leave (max, sum, un-normalised O) partials that attention_combine_kernel folds.
+  const int q0 = (blockIdx.x / key_splits) * 32, split = blockIdx.x % key_splits;
+  const int hi = blockIdx.y, bi = blockIdx.z;
   if (blockIdx.x == 0 && bi == 0) zero_pad_rows(out, (unsigned)(h * AT_D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
   // token-major operands: storage row r of head hi starts at base + r*ld + hi*64, where ld is the
   // row stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
@@ -163,7 +167,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o0 = {0}, o1 = {0};
   const int ntiles = (nk + 31) / 32;
-  for (int t = wave; t < ntiles; t += AT_WAVES) {
+  const int tps = (ntiles + key_splits - 1) / key_splits;
+  const int t_begin = split * tps, t_end = min(ntiles, t_begin + tps);
+  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
     const int key0 = t * 32;
     // every global operand of this key tile is requested up front -- K rows, the 16 additive mask
     // values and the 32 V^T operands of the PV product -- and the scheduler is fenced so that it
@@ -242,6 +248,22 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
       wgt[w] = __expf(s_m[w][qq] - mt);  // waves without a tile: exp(-inf) = 0
       lt += s_l[w][qq] * wgt[w];
     }
+    if (key_splits > 1) {
+      // partial of this key split: part[row][split] = {m, l, O[64] relative to m}, row = (b*h + head)*nq_pad + q
+      if (q0 + qq < nq) {
+        const int nq_pad = (nq + 31) / 32 * 32;
+        float *pp = part + (((size_t)(bi * h + hi) * nq_pad + q0 + qq) * key_splits + split) * (AT_D + 2);
+        if (dg == 0) { pp[0] = mt; pp[1] = lt; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float acc = 0.f;
+#pragma unroll
+          for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * 8 + i][qq] * wgt[w];
+          pp[2 + dg * 8 + i] = acc;
+        }
+      }
+      return;
+    }
     const float inv = 1.f / lt;
     if (q0 + qq < nq) {
       float res[8];
@@ -259,6 +281,31 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
       if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
     }
   }
+}
+
+// fold the key-split partials of one (batch, head, query) row: one wave per row, lane = feature
+__global__ __launch_bounds__(256) void attention_combine_kernel(int h, int nq, int q_seg, int q_base2,
+                                                                int key_splits, int nb,
+                                                                const float *__restrict__ part,
+                                                                float *__restrict__ out,
+                                                                float *__restrict__ lse) {
+  const int lane = lane_id();
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b*h + head)*nq + q
+  if (row >= (long)nb * h * nq) return;
+  const int qq = (int)(row % nq), bh = (int)(row / nq), hi = bh % h, bi = bh / h;
+  const int nq_pad = (nq + 31) / 32 * 32;
+  const float *pp = part + ((size_t)bh * nq_pad + qq) * key_splits * (AT_D + 2);
+  float mt = -INFINITY;
+  for (int s2 = 0; s2 < key_splits; ++s2) mt = fmaxf(mt, pp[(size_t)s2 * (AT_D + 2)]);
+  float lt = 0.f, acc = 0.f;
+  for (int s2 = 0; s2 < key_splits; ++s2) {
+    const float *ps = pp + (size_t)s2 * (AT_D + 2);
+    const float wgt = __expf(ps[0] - mt);   // splits without keys: exp(-inf) = 0
+    lt += ps[1] * wgt;
+    acc += ps[2 + lane] * wgt;
+  }
+  out[tok_row(qq, bi, nq, q_seg, q_base2) * (unsigned)(h * AT_D) + hi * AT_D + lane] = acc / lt;
+  if (lse && lane == 0) lse[row] = mt + __logf(lt);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -541,7 +588,8 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
                                    int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
                                    float scale, const float *q, const float *k, const float *v,
                                    const float *mask, float *out, float *lse, float p_drop,
-                                   unsigned call_id, const unsigned *rng_counter, void *stream_) {
+                                   unsigned call_id, const unsigned *rng_counter, int key_splits,
+                                   float *workspace, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
@@ -556,12 +604,23 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE((long)(b * nq + q_base2 + q_rows) * ldq < (1L << 31) && (long)(b * nk + k_base2 + k_rows) * ldk < (1L << 31) &&
                     (long)(b * nk + k_base2 + k_rows) * ldv < (1L << 31),
                 "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
-  dim3 grid((nq + 31) / 32, h, b);
+  if (key_splits < 1) key_splits = 1;
+  const int ntiles_fwd = (nk + 31) / 32;
+  if (key_splits > ntiles_fwd) key_splits = ntiles_fwd;
+  SIG3D_REQUIRE(key_splits == 1 || workspace != nullptr,
+                "key_splits > 1 needs a workspace of b*h*roundup32(nq)*key_splits*66 floats");
+  dim3 grid(((nq + 31) / 32) * key_splits, h, b);
   (void)k_rows;
   hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
                      q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
-                     p_drop, call_id, rng_counter, q, k, v, mask, out, lse);
+                     p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
+  if (key_splits > 1) {
+    const long rows = (long)b * h * nq;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
+                       q_seg, q_base2, key_splits, b, workspace, out, lse);
+    SIG3D_LAUNCH_CHECK("attention_combine_kernel");
+  }
   return 0;
 }
 

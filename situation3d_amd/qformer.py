@@ -217,11 +217,12 @@ class _AttentionFn(torch.autograd.Function):
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
+        _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev)
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, nq, nk, 0, 0, 0, 0, hd, hd, hd, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
                       _lib.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
-                      _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
+                      _lib.ptr(_rng_counter(dev)), _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         ctx.save_for_backward(q, k, v, mask, out, lse)
         ctx.cfg = (num_heads, scale, p_drop, call_id)
         return out
@@ -241,6 +242,19 @@ class _AttentionFn(torch.autograd.Function):
                       _lib.ptr(dv), ctypes.c_float(p_drop), ctypes.c_uint(call_id),
                       _lib.ptr(_rng_counter(q.device)), _lib.stream_ptr(q.device))
         return dq, dk, dv, None, None, None, None, None
+
+
+def _fwd_key_splits(b, heads, nq, nk, device):
+    """(key_splits, workspace) for sig3d_attention_fwd: split the key range when (batch x heads x query
+    tiles) alone cannot fill 256 CUs and there are enough 32-key tiles to share out (3D-LLM shapes)."""
+    qtiles = (nq + 31) // 32
+    ntiles = (nk + 31) // 32
+    wgs = b * heads * qtiles
+    splits = min(max(1, 1024 // max(wgs, 1)), ntiles // 16, 64)
+    if splits <= 1:
+        return 1, None
+    work = torch.empty(b * heads * qtiles * 32 * splits * 66, dtype=torch.float32, device=device)
+    return splits, work
 
 
 def _off(t, floats):
@@ -316,11 +330,12 @@ class _ProjAttentionFn(torch.autograd.Function):
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
+        _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev)
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, kseg, b * seg, b * kseg, 0, 0,
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(out), _lib.ptr(lse),
                       ctypes.c_float(p_drop), ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)),
-                      _lib.stream_ptr(dev))
+                      _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         ctx.save_for_backward(hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse)
         ctx.cfg = (num_heads, scale, p_drop, call_id, hd, nk, b, nq, seg, kseg)
         # key / value for the reference's "present_key_value" are views of the projections
@@ -418,11 +433,12 @@ class _AttentionBlockFn(torch.autograd.Function):
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
+        _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev)
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], rows, klay[2],
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
-                      _lib.stream_ptr(dev))
+                      _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         y = att.mm(wo.t())
         out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out)
         ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)

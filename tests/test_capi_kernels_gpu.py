@@ -108,7 +108,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     ld = h * 64  # dense token-major operands
     L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
-           L.ptr(None), L.stream_ptr())
+           L.ptr(None), 1, L.ptr(None), L.stream_ptr())
 
     q64 = q.double().requires_grad_(True)
     k64 = k.double().requires_grad_(True)
@@ -162,7 +162,7 @@ def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad):
         dq, dk, dv = torch.full_like(q, nan), torch.full_like(k, nan), torch.full_like(v, nan)
         L.call("sig3d_attention_fwd", b, h, n, n, 64, qs, ks, base2, base2, rows, rows, ld, ld, ld, scale,
                L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0),
-               ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
+               ctypes.c_uint(0), L.ptr(None), 1, L.ptr(None), L.stream_ptr())
         L.call("sig3d_attention_bwd", b, h, n, n, 64, qs, ks, base2, base2, rows, rows, ld, ld, ld, scale,
                L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), L.ptr(go), L.ptr(dq), L.ptr(dk),
                L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
@@ -177,3 +177,25 @@ def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad):
     for name, a, c in zip(("out", "dq", "dk", "dv"), (plain[0],) + plain[2:], (segd[0],) + segd[2:]):
         # token rows identical bit for bit; rows without a token are exact zeros
         assert torch.equal(_to_segments(a.view(b, n, ld), seg, base2, rows, fill=0.0), c.view(rows, ld)), name
+
+
+@pytest.mark.parametrize("b,h,nq,nk,splits", [(2, 3, 32, 5000, 7), (1, 2, 40, 1000, 32), (1, 1, 5, 77, 3)])
+def test_attention_fwd_key_splits_match_single_pass(b, h, nq, nk, splits):
+    """key_splits only re-associates the streaming softmax over key ranges: same result as one pass
+    within rounding (1e-5), lse included; more splits than 32-key tiles are clamped."""
+    L = _lib()
+    g = torch.Generator().manual_seed(nk)
+    ld = h * 64
+    q, k, v = (torch.randn(b, n, ld, generator=g).to(DEV) for n in (nq, nk, nk))
+    mask = ((torch.rand(b, nk, generator=g) < 0.1).float() * -10000.0).to(DEV)
+    mask[:, 0] = 0.0
+    outs = []
+    for ks in (1, splits):
+        out, lse = torch.empty_like(q), torch.empty(b, h, nq, device=DEV)
+        work = torch.full((b * h * ((nq + 31) // 32) * 32 * ks * 66,), float("nan"), device=DEV)
+        L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(0.125),
+               L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0),
+               ctypes.c_uint(0), L.ptr(None), ks, L.ptr(work), L.stream_ptr())
+        outs.append((out, lse))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-5)

@@ -16,8 +16,8 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-shared", "-DSIG3D_A
                        os.path.join(CSRC, "attention.hip"), os.path.join(CSRC, "capi.hip"), "-o", so] + FLAGS)
 lib = ctypes.CDLL(so)
 P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-lib.sig3d_attention_fwd.argtypes = [I] * 10 + [F] + [P] * 6 + [F, ctypes.c_uint, P, P]
-lib.sig3d_attention_bwd.argtypes = [I] * 10 + [F] + [P] * 10 + [F, ctypes.c_uint, P, P]
+lib.sig3d_attention_fwd.argtypes = [I] * 14 + [F] + [P] * 6 + [F, ctypes.c_uint, P, I, P, P]
+lib.sig3d_attention_bwd.argtypes = [I] * 14 + [F] + [P] * 10 + [F, ctypes.c_uint, P, P]
 NAMES = ["start", "D+zero done", "K/V loaded", "q operands issued", "S done", "dP+ds done", "dV/dK done",
          "dQ mfma done", "dq lds-atomics done", "tiles done", "barrier", "dq written"]
 dev = "cuda:0"
@@ -29,9 +29,9 @@ for (b, h, nq, nk, label) in [(8, 12, 52, 52, "self 52x52"), (8, 12, 32, 256, "c
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
-        lib.sig3d_attention_fwd(b, h, nq, nk, 64, nq, nk, hd, hd, hd, 0.125, ptr(q), ptr(k), ptr(v), None,
-                                ptr(out), ptr(lse), 0.1, 7, None, st)
-        lib.sig3d_attention_bwd(b, h, nq, nk, 64, nq, nk, hd, hd, hd, 0.125, ptr(q), ptr(k), ptr(v), None,
+        lib.sig3d_attention_fwd(b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, hd, hd, hd, 0.125, ptr(q), ptr(k), ptr(v), None,
+                                ptr(out), ptr(lse), 0.1, 7, None, 1, None, st)
+        lib.sig3d_attention_bwd(b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, hd, hd, hd, 0.125, ptr(q), ptr(k), ptr(v), None,
                                 ptr(out), ptr(lse), ptr(go), ptr(dq), ptr(dk), ptr(dv), 0.1, 7, None, st)
     torch.cuda.synchronize()
     marks = (ctypes.c_ulonglong * (2 * 4 * 16))()
