@@ -190,7 +190,8 @@ def main():
         # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
         # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
         # issued once more eagerly right after the timed region and bracketed there.
-        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_furthest_point_sampling"])
+        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_ball_query_grid",
+                            "sig3d_furthest_point_sampling"])
         if reducer is not None:
             reducer.hooks_enabled = True
         for i in range(KSTEPS):
@@ -212,7 +213,7 @@ def main():
         grp = kernel_ms("sig3d_query_group_fused")
         grp_bytes = sum(group_algorithmic_bytes(BATCH, *lvl) for lvl in SA_LEVELS) * KSTEPS
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
-        bq = kernel_ms("sig3d_ball_query")
+        bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid")
         fps = kernel_ms("sig3d_furthest_point_sampling")
         # HBM traffic of the roofline kernel cannot be read from inside this process: it comes from
         # the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE)

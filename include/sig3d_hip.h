@@ -63,6 +63,16 @@ int sig3d_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, floa
 int sig3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                      const float *xyz, int *idx, void *stream);
 
+/* Same result, bit for bit, through a hashed uniform grid (cells of 1.01*radius; one wave per centre
+ * walks the 27 neighbour buckets, hits are put back into index order by rank counting; centres with
+ * more than 256 hits fall back to the ordered scan): ~45 distance tests per centre instead of n at the
+ * SA1 shape.  workspace: b*(3*H+1)*4 bytes rounded up to 16, plus b*n*16 bytes, H = smallest power of
+ * two >= max(1024, 2n), at most 2^20.  n < 1024 is forwarded to sig3d_ball_query.  Assumes
+ * |coordinate| / radius < ~1e5 (cell indexing in f32). */
+int sig3d_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                          const float *xyz, int *idx, void *workspace, long workspace_bytes,
+                          void *stream);
+
 /* replaces group_points_kernel_wrapper(b,c,n,npoints,nsample,points,idx,out)
  *   group_points.cpp:4-6, group_points_gpu.cu:8-39.
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */

@@ -23,6 +23,7 @@ SIGNATURES = {
     "sig3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "sig3d_ball_query_grid": [_I, _I, _I, _F, _I, _P, _P, _P, _P, ctypes.c_long, _P],
     "sig3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],

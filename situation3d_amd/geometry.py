@@ -17,6 +17,7 @@ import ctypes
 import torch
 
 from . import _lib
+from .pointnet2 import _ext
 
 
 class GeometryPlan:
@@ -26,6 +27,7 @@ class GeometryPlan:
         self.levels = list(levels)
         self.batch, self.n_points = batch, n_points
         self.inds, self.new_xyz, self.ball_idx, self._temp = [], [], [], []
+        self._bq_work = None  # scratch of the grid ball query (allocated once: static under hipGraph)
         n = n_points
         for npoint, radius, nsample in self.levels:
             self.inds.append(torch.zeros(batch, npoint, dtype=torch.int32, device=device))
@@ -49,8 +51,16 @@ class GeometryPlan:
                           _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
                 _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
                           _lib.ptr(self.new_xyz[lvl]), s)
-                _lib.call("sig3d_ball_query", b, n, npoint, ctypes.c_float(radius), nsample,
-                          _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
+                if n >= _ext.GRID_MIN_POINTS:
+                    if self._bq_work is None or self._bq_work.numel() < _ext.ball_query_workspace_bytes(b, n):
+                        self._bq_work = torch.empty(_ext.ball_query_workspace_bytes(b, n), dtype=torch.uint8,
+                                                    device=dev)
+                    _lib.call("sig3d_ball_query_grid", b, n, npoint, ctypes.c_float(radius), nsample,
+                              _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]),
+                              _lib.ptr(self._bq_work), self._bq_work.numel(), s)
+                else:
+                    _lib.call("sig3d_ball_query", b, n, npoint, ctypes.c_float(radius), nsample,
+                              _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
                 cur, n = self.new_xyz[lvl], npoint
         return self
 

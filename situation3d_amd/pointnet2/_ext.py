@@ -121,9 +121,27 @@ def ball_query(new_xyz, xyz, radius, nsample):
     n = xyz.shape[1]
     nsample = int(nsample)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=dev)
+    if n >= GRID_MIN_POINTS and radius > 0:
+        # large scenes: hashed uniform grid, same output bit for bit (csrc/ball_query.hip)
+        work = torch.empty(ball_query_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
+        _run("sig3d_ball_query_grid", dev, b, n, m, ctypes.c_float(radius), nsample, _lib.ptr(new_xyz),
+             _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(work), work.numel())
+        return idx
     _run("sig3d_ball_query", dev, b, n, m, ctypes.c_float(radius), nsample, _lib.ptr(new_xyz),
          _lib.ptr(xyz), _lib.ptr(idx))
     return idx
+
+
+GRID_MIN_POINTS = 8192   # below: the ordered brute-force scan is faster than building the grid
+
+
+def ball_query_workspace_bytes(b, n):
+    """Scratch of sig3d_ball_query_grid (include/sig3d_hip.h)."""
+    h = 2048
+    while h < 2 * n and h < (1 << 20):
+        h <<= 1
+    ints = b * (3 * h + 1 + h // 2048) * 4
+    return (ints + 15) // 16 * 16 + b * n * 16
 
 
 def group_points(points, idx):

@@ -68,6 +68,28 @@ def test_ball_query(hip_ext, oracle, n, m, r, ns):
     assert (got[:, -1] == 0).all()
 
 
+@pytest.mark.parametrize("n,m,r,ns,dup,zero_tail", [(40000, 2048, 0.2, 64, 0, 0), (40000, 2048, 0.2, 64, 5000, 3000),
+                                                    (9000, 300, 0.4, 32, 1000, 0), (20000, 256, 1.5, 16, 0, 500),
+                                                    (8192, 64, 0.05, 8, 0, 0)])
+def test_ball_query_grid_path_bit_exact(hip_ext, oracle, n, m, r, ns, dup, zero_tail):
+    """n >= 8192 takes the hashed-grid kernels: index order, padding, all-zero rows and dense
+    neighbourhoods (duplicates, a zero-padded tail with thousands of coincident points -> the
+    ordered-scan fallback) must equal the reference's serial scan bit for bit."""
+    from situation3d_amd.pointnet2 import _ext
+    assert n >= _ext.GRID_MIN_POINTS
+    xyz = scene(2, n, seed=n + ns, dup=dup)
+    if zero_tail:
+        xyz[:, -zero_tail:] = 0.0
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(2))[:m]
+    new_xyz = xyz[:, sel].contiguous()
+    new_xyz[:, 0] = 0.0            # a centre inside the zero-padded cluster (if any)
+    new_xyz[:, -1] = 100.0         # a centre with no neighbour: row must stay all-zero
+    new_xyz[:, 1] = -3.7           # negative cell coordinates
+    ref = oracle.ball_query(new_xyz, xyz, r, ns)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("c,n,p,s", [(3, 4096, 512, 64), (6, 9, 2, 3), (131, 2048, 256, 32),
                                      (5, 100, 7, 5), (1, 50, 1, 1)])
 def test_group_points_and_grad(hip_ext, oracle, c, n, p, s):
