@@ -144,6 +144,22 @@ class GradBucketReducer:
                 if not self._avg:
                     b["flat"].div_(self.world)
 
+    def launch_all(self):
+        """Launch every bucket's all-reduce asynchronously (no join): pair with wait(bucket)."""
+        for b in self.buckets:
+            b["launched"] = False
+            b["handle"] = None
+            self._launch(b)
+
+    def wait(self, b):
+        """Make the current stream wait for ONE bucket's collective (and apply the mean for backends
+        without ReduceOp.AVG)."""
+        if b["handle"] is not None:
+            b["handle"].wait()
+            b["handle"] = None
+            if not self._avg:
+                b["flat"].div_(self.world)
+
     def num_collectives(self):
         return len(self.buckets)
 

@@ -99,6 +99,8 @@ class GraphedTrainStep:
             return loss
 
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
+        # data parallel + flat storage: AdamW runs bucket by bucket behind that bucket's all-reduce
+        self._bucketed_update = bool(reducer is not None and fused_opt and getattr(reducer, "flat_mode", False))
 
         def update():
             if not fused_opt and max_grad_value is not None and max_grad_value > 0:
@@ -159,6 +161,11 @@ class GraphedTrainStep:
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         if self.reducer is not None:
-            self.reducer.reduce_all()
-            self.graph_opt.replay()
+            if self._bucketed_update:
+                # all-reduce per bucket, AdamW per bucket right behind it (eager launches, ~12 per step)
+                self.optimizer.mark_gathered()   # the replayed graph filled the flat gradient buffers
+                self.optimizer.step_after(self.reducer)
+            else:
+                self.reducer.reduce_all()
+                self.graph_opt.replay()
         return self.static_loss

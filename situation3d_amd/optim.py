@@ -128,6 +128,51 @@ class FlatAdamW(torch.optim.Optimizer):
         for p, _, _ in self._params:
             p.grad = None
 
+    def mark_gathered(self):
+        """A replayed hipGraph ran gather_grads(): the flat gradient buffers are current."""
+        self._gathered = True
+
+    @torch.no_grad()
+    def step_after(self, reducer):
+        """Data-parallel update overlapped with the gradient exchange: every bucket's all-reduce is
+        launched at once (ddp.GradBucketReducer over flat_grad_buffers(), after gather_grads()), then
+        the AdamW kernel runs bucket by bucket as soon as that bucket's collective has completed --
+        the 1 ms HBM-bound update hides under the remaining collectives instead of following them."""
+        assert self._gathered, "call gather_grads() first"
+        dev = self._dev
+        stream = _lib.stream_ptr(dev)
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        starts = {}
+        for gi, f in enumerate(self._groups):
+            if f is not None:
+                starts[f["g"].data_ptr()] = gi
+        reducer.launch_all()
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_step_increment", _lib.ptr(self._step), stream)
+            for bucket in reducer.buckets:
+                reducer.wait(bucket)   # the current stream waits for this bucket's collective only
+                flat = bucket["flat"]
+                gi = None
+                for f_i, f in enumerate(self._groups):   # which group's flat buffer is this a slice of?
+                    if f is None:
+                        continue
+                    lo = f["g"].data_ptr()
+                    if lo <= flat.data_ptr() < lo + 4 * f["total"]:
+                        gi, off = f_i, (flat.data_ptr() - lo) // 4
+                        break
+                assert gi is not None, "bucket is not a slice of this optimizer's flat gradients"
+                f, group = self._groups[gi], self.param_groups[gi]
+                n = flat.numel()
+                _lib.call("sig3d_adamw_flat", n, ctypes.c_void_p(f["p"].data_ptr() + 4 * off),
+                          ctypes.c_void_p(f["g"].data_ptr() + 4 * off),
+                          ctypes.c_void_p(f["m"].data_ptr() + 4 * off),
+                          ctypes.c_void_p(f["v"].data_ptr() + 4 * off), _lib.ptr(self._step),
+                          ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
+                          ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
+                          ctypes.c_float(self.clip_value), 0, stream)
+        self._gathered = False
+
     def zero_grad(self, set_to_none=True):
         for p, _, _ in self._params:
             p.grad = None

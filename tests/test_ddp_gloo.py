@@ -113,3 +113,43 @@ def test_bucket_reducer_single_process_is_identity():
             assert p.grad.abs().max() == 0
         else:
             assert torch.equal(p.grad, q.grad)
+
+
+def _flat_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from situation3d_amd.ddp import GradBucketReducer, init_distributed
+    init_distributed(backend="gloo")
+    # two flat gradient buffers (decay / no-decay groups of optim.FlatAdamW), sliced into small buckets
+    g = torch.Generator().manual_seed(10 + rank)
+    flats = [torch.randn(5000, generator=g), torch.randn(300, generator=g)]
+    reducer = GradBucketReducer.from_flat(flats, bucket_bytes=4096)
+    assert reducer.flat_mode and reducer.num_collectives() == 6
+    # the protocol of FlatAdamW.step_after: launch everything, then consume bucket by bucket
+    reducer.launch_all()
+    consumed = []
+    for b in reducer.buckets:
+        reducer.wait(b)
+        consumed.append(b["flat"].clone())   # "update" reads the reduced slice right away
+    torch.save({"flats": [f.clone() for f in flats], "consumed": consumed}, os.path.join(out_dir, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_launch_all_then_wait_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_flat_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "f0.pt"), torch.load(tmp_path / "f1.pt")
+    exp = []
+    for i, n in enumerate((5000, 300)):
+        parts = []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(10 + rank)
+            both = [torch.randn(5000, generator=g), torch.randn(300, generator=g)]
+            parts.append(both[i])
+        exp.append(sum(parts) / world)
+    for got0, got1, e in zip(r0["flats"], r1["flats"], exp):
+        assert torch.equal(got0, got1)
+        torch.testing.assert_close(got0, e, rtol=1e-6, atol=1e-6)
+    # every bucket was already reduced at the moment it was consumed
+    torch.testing.assert_close(torch.cat(r0["consumed"]), torch.cat(exp), rtol=1e-6, atol=1e-6)

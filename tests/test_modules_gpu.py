@@ -284,3 +284,50 @@ def test_graphed_step_matches_eager(prefetch):
     torch.cuda.synchronize()
     # float atomics in the scatter-add gradients make runs differ in the last bits only
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
+
+
+def test_graphed_data_parallel_step_with_bucketed_update_matches_eager():
+    """The N > 1 step structure at world size 1: graph (forward + backward + gradient gather) ->
+    per-bucket all-reduce -> AdamW bucket by bucket (optim.FlatAdamW.step_after) must follow the
+    same loss trajectory as the plain eager FlatAdamW step."""
+    from situation3d_amd.ddp import GradBucketReducer
+    from situation3d_amd.graph_step import GraphedTrainStep
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.trainer import build_optimizer, train_step
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0)
+
+    def make():
+        torch.manual_seed(5)
+        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
+
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for i in range(3):
+        b, n = 2, 5000
+        xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+        batches.append({
+            "point_clouds": torch.cat([xyz, torch.rand(b, n, 3, generator=g)], -1).to(DEV),
+            "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * b).to(DEV),
+            "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
+                       "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
+            "answer_cat_scores": torch.zeros(b, 16, device=DEV),
+        })
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        m1, o1 = make()
+        for _ in range(3):
+            train_step(m1, o1, dict(batches[0]))
+        eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(5)]
+        m2, o2 = make()
+        reducer = GradBucketReducer.from_flat(o2.flat_grad_buffers(), bucket_bytes=1 << 20)
+        assert reducer.num_collectives() > 2
+        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=True, reducer=reducer)
+        assert gs._bucketed_update
+        graph = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(5)]
+    torch.cuda.synchronize()
+    torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
