@@ -54,7 +54,7 @@ class GraphedTrainStep:
     (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
-                 prefetch_geometry=False, geometry_levels=None, reducer=None):
+                 prefetch_geometry=False, geometry_levels=None, reducer=None, split_backward=True):
         """`reducer` (ddp.GradBucketReducer, data parallel): the step becomes graph A (forward +
         backward, gradients accumulated into the reducer's flat buckets) -> eager bucketed RCCL
         all-reduce -> graph B (value clip + AdamW).  No collective is ever captured."""
@@ -98,9 +98,48 @@ class GraphedTrainStep:
                 optimizer.gather_grads()  # scattered grads -> the flat buffers the reducer owns
             return loss
 
+        def fwd_bwd_head():
+            """Split mode, part 1: forward, then backward of everything DOWNSTREAM of the point encoder
+            (down to the token features), gradients gathered into the flat buffers."""
+            batch = dict(self.static_batch)
+            batch["_split_backward"] = True
+            if self.prefetch:
+                batch["geometry_plan"] = self.plan_cur
+            out = model(batch)
+            self._boundary = out.pop("_boundary")
+            out.pop("_split_backward", None)
+            loss, out = get_loss(out)
+            self.static_out = out
+            loss.backward(inputs=self._head_params + [self._boundary[1]])
+            optimizer.gather_grads(slot=0, zero=True)
+            return loss
+
+        def bwd_encoder():
+            """Split mode, part 2: the encoder's backward from the boundary gradient, own gather."""
+            tok_feat, leaf = self._boundary
+            tok_feat.backward(leaf.grad)
+            optimizer.gather_grads(slot=1, zero=False)
+            self._boundary = None
+
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
         # data parallel + flat storage: AdamW runs bucket by bucket behind that bucket's all-reduce
         self._bucketed_update = bool(reducer is not None and fused_opt and getattr(reducer, "flat_mode", False))
+        # ... and the backward pass is cut at the point encoder's output: the all-reduce of everything
+        # downstream (Q-Former, heads: 99 % of the gradient bytes) runs while the encoder's backward
+        # (a third of the step) is still computing.  Two graphs + two bucket sets; no collective captured.
+        self._split = False
+        if self._bucketed_update and split_backward and hasattr(model, "encoder"):
+            enc = [p for p in model.encoder.parameters() if p.requires_grad]
+            parts = optimizer.flat_grad_split(enc)
+            if parts is not None and parts[0] and parts[1]:
+                from .ddp import GradBucketReducer
+                enc_ids = {id(p) for p in enc}
+                self._head_params = [p for p in params if id(p) not in enc_ids]
+                self._red_enc = GradBucketReducer.from_flat(parts[0], process_group=reducer.group)
+                self._red_head = GradBucketReducer.from_flat(parts[1], process_group=reducer.group)
+                self.graph_enc = torch.cuda.CUDAGraph()
+                optimizer._tables(1)   # second gather's staging buffers: pinned allocation is illegal in capture
+                self._split = True
 
         def update():
             if not fused_opt and max_grad_value is not None and max_grad_value > 0:
@@ -131,12 +170,18 @@ class GraphedTrainStep:
                     self.plan_next.compute(self.static_next_xyz)
             if reducer is not None:
                 reducer.zero_grad()
-            self.static_loss = fwd_bwd()
+            self.static_loss = fwd_bwd_head() if self._split else fwd_bwd()
             if reducer is None:
                 update()
             if self.prefetch:
                 stream.wait_stream(self.side)                    # join
-                self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
+                if not self._split:
+                    self.plan_cur.copy_from(self.plan_next)      # hand over for the next replay
+        if self._split:
+            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool()):
+                bwd_encoder()
+                if self.prefetch:  # the encoder's backward still reads plan_cur: hand over after it
+                    self.plan_cur.copy_from(self.plan_next)
         if reducer is not None:
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
                                                            pool=self.graph.pool()):
@@ -161,7 +206,16 @@ class GraphedTrainStep:
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         if self.reducer is not None:
-            if self._bucketed_update:
+            if self._split:
+                self._red_head.launch_all()      # Q-Former / head gradients: on the wire ...
+                self.graph_enc.replay()          # ... while the encoder's backward runs
+                self._red_enc.launch_all()
+                self.optimizer.mark_gathered()
+                self.optimizer.begin_bucketed_step()
+                self.optimizer.update_buckets(self._red_head)
+                self.optimizer.update_buckets(self._red_enc)
+                self.optimizer.end_bucketed_step()
+            elif self._bucketed_update:
                 # all-reduce per bucket, AdamW per bucket right behind it (eager launches, ~12 per step)
                 self.optimizer.mark_gathered()   # the replayed graph filled the flat gradient buffers
                 self.optimizer.step_after(self.reducer)

@@ -86,6 +86,12 @@ class SIG3DQFormer(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
         tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("geometry_plan"))
         tok_feat = tok_feat.transpose(1, 2).contiguous()            # (B,T,256)
+        if data_dict.get("_split_backward"):
+            # data-parallel step (graph_step.py): the backward pass is cut here so that the gradient
+            # all-reduce of everything downstream (99 % of the parameters) overlaps the encoder's backward
+            leaf = tok_feat.detach().requires_grad_(True)
+            data_dict["_boundary"] = (tok_feat, leaf)
+            tok_feat = leaf
         data_dict["scene_positions"] = tok_xyz
         data_dict["att_feat_pre"] = tok_feat
 

@@ -77,10 +77,20 @@ class FlatAdamW(torch.optim.Optimizer):
         self._host = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory()
         self._host_np = self._host.numpy().view(_REC)
         self._table = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev)
+        self._slots = [(self._host, self._host_np, self._table)]
         self._gathered = False
 
     # ---- chunk table ------------------------------------------------------------------------
-    def _upload(self, dst_field_from_flat_g=False):
+    def _tables(self, slot):
+        """(pinned host staging, its numpy view, device table) of call site `slot`.  Every call site that
+        can sit in a captured hipGraph needs its OWN staging buffer: a captured upload is a memcpy node
+        that re-reads the staging memory at every replay."""
+        while len(self._slots) <= slot:
+            host = torch.empty(len(self._static) * _REC.itemsize, dtype=torch.uint8).pin_memory()
+            self._slots.append((host, host.numpy().view(_REC), torch.empty_like(self._table)))
+        return self._slots[slot]
+
+    def _upload(self, dst_field_from_flat_g=False, slot=0):
         """Fill the per-step columns of the table (gradient pointers) and push it to the device."""
         gptr = np.zeros(len(self._params), dtype=np.uint64)
         live = np.zeros(len(self._params), dtype=bool)
@@ -93,7 +103,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.grad = g
             gptr[i] = g.data_ptr()
             live[i] = True
-        t = self._host_np
+        host, t, table = self._tables(slot)
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]
         t["n"] = np.where(live[self._owners], self._static["n"], 0)  # params without grad: skipped
@@ -104,7 +114,8 @@ class FlatAdamW(torch.optim.Optimizer):
             t["m"] = base[self._owners] + self._static["g"]
         # eager: blocking copy (the pinned staging buffer is rewritten next step); inside a hipGraph
         # capture the copy becomes a memcpy node reading the (then static) staging buffer
-        self._table.copy_(self._host, non_blocking=torch.cuda.is_current_stream_capturing())
+        table.copy_(host, non_blocking=torch.cuda.is_current_stream_capturing())
+        return table
 
     # ---- public ----------------------------------------------------------------------------------
     def flat_grad_buffers(self):
@@ -113,16 +124,19 @@ class FlatAdamW(torch.optim.Optimizer):
                 g["g"] = torch.zeros(g["total"], dtype=torch.float32, device=self._dev)
         return [g["g"] for g in self._groups if g is not None]
 
-    def gather_grads(self):
+    def gather_grads(self, slot=0, zero=True):
         """Scattered .grad tensors -> flat gradient buffers (one launch); the next step() then reads
-        the flat (e.g. all-reduced) gradients."""
+        the flat (e.g. all-reduced) gradients.  Parameters whose .grad is None are skipped, so a
+        backward pass run in two parts gathers in two calls: the first with zero=True (whole buffers
+        cleared), the second with zero=False and its own `slot` (see _tables)."""
         self.flat_grad_buffers()
-        for g in self._groups:
-            if g is not None:
-                g["g"].zero_()  # parameters without a gradient contribute zeros to the all-reduce
-        self._upload(dst_field_from_flat_g=True)
+        if zero:
+            for g in self._groups:
+                if g is not None:
+                    g["g"].zero_()  # parameters without a gradient contribute zeros to the all-reduce
+        table = self._upload(dst_field_from_flat_g=True, slot=slot)
         with torch.cuda.device(self._dev):
-            _lib.call("sig3d_gather_table", len(self._static), _lib.ptr(self._table),
+            _lib.call("sig3d_gather_table", len(self._static), _lib.ptr(table),
                       _lib.stream_ptr(self._dev))
         self._gathered = True
         for p, _, _ in self._params:
@@ -132,24 +146,62 @@ class FlatAdamW(torch.optim.Optimizer):
         """A replayed hipGraph ran gather_grads(): the flat gradient buffers are current."""
         self._gathered = True
 
+    def flat_grad_split(self, part_params):
+        """Slices of the flat gradient buffers covering exactly `part_params` and exactly the rest, as
+        ([part slices], [rest slices]) -- or None when `part_params` do not form ONE contiguous run in
+        a group's storage order (they do for a submodule such as the point encoder)."""
+        self.flat_grad_buffers()
+        ids = {id(p) for p in part_params}
+        part, rest = [], []
+        for gi, f in enumerate(self._groups):
+            if f is None:
+                continue
+            mine = [(p, off) for p, g2, off in self._params if g2 == gi]
+            flags = [id(p) in ids for p, _ in mine]
+            if not any(flags):
+                rest.append(f["g"])
+                continue
+            k0 = flags.index(True)
+            k1 = len(flags) - flags[::-1].index(True)
+            if not all(flags[k0:k1]):
+                return None
+            lo = mine[k0][1]
+            hi = mine[k1][1] if k1 < len(mine) else f["total"]
+            part.append(f["g"][lo:hi])
+            if lo > 0:
+                rest.append(f["g"][:lo])
+            if hi < f["total"]:
+                rest.append(f["g"][hi:])
+        return part, rest
+
     @torch.no_grad()
     def step_after(self, reducer):
         """Data-parallel update overlapped with the gradient exchange: every bucket's all-reduce is
         launched at once (ddp.GradBucketReducer over flat_grad_buffers(), after gather_grads()), then
         the AdamW kernel runs bucket by bucket as soon as that bucket's collective has completed --
         the 1 ms HBM-bound update hides under the remaining collectives instead of following them."""
+        reducer.launch_all()
+        self.begin_bucketed_step()
+        self.update_buckets(reducer)
+        self.end_bucketed_step()
+
+    def begin_bucketed_step(self):
         assert self._gathered, "call gather_grads() first"
+        with torch.cuda.device(self._dev):
+            _lib.call("sig3d_step_increment", _lib.ptr(self._step), _lib.stream_ptr(self._dev))
+
+    def end_bucketed_step(self):
+        self._gathered = False
+
+    @torch.no_grad()
+    def update_buckets(self, reducer):
+        """AdamW on every bucket of `reducer` (slices of flat_grad_buffers()), each right behind its own
+        all-reduce; the collectives must have been launched (reducer.launch_all())."""
         dev = self._dev
         stream = _lib.stream_ptr(dev)
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
-        starts = {}
-        for gi, f in enumerate(self._groups):
-            if f is not None:
-                starts[f["g"].data_ptr()] = gi
-        reducer.launch_all()
         with torch.cuda.device(dev):
-            _lib.call("sig3d_step_increment", _lib.ptr(self._step), stream)
             for bucket in reducer.buckets:
                 reducer.wait(bucket)   # the current stream waits for this bucket's collective only
                 flat = bucket["flat"]
@@ -171,7 +223,6 @@ class FlatAdamW(torch.optim.Optimizer):
                           ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
                           ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
                           ctypes.c_float(self.clip_value), 0, stream)
-        self._gathered = False
 
     def zero_grad(self, set_to_none=True):
         for p, _, _ in self._params:

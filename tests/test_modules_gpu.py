@@ -286,10 +286,13 @@ def test_graphed_step_matches_eager(prefetch):
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
 
 
-def test_graphed_data_parallel_step_with_bucketed_update_matches_eager():
+@pytest.mark.parametrize("split", [False, True])
+def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split):
     """The N > 1 step structure at world size 1: graph (forward + backward + gradient gather) ->
     per-bucket all-reduce -> AdamW bucket by bucket (optim.FlatAdamW.step_after) must follow the
-    same loss trajectory as the plain eager FlatAdamW step."""
+    same loss trajectory as the plain eager FlatAdamW step.  split=True: the backward pass is cut at
+    the point encoder's output (two graphs, two bucket sets) so that the Q-Former gradients are on
+    the wire while the encoder's backward runs."""
     from situation3d_amd.ddp import GradBucketReducer
     from situation3d_amd.graph_step import GraphedTrainStep
     from situation3d_amd.model import SIG3DQFormer
@@ -326,8 +329,9 @@ def test_graphed_data_parallel_step_with_bucketed_update_matches_eager():
         m2, o2 = make()
         reducer = GradBucketReducer.from_flat(o2.flat_grad_buffers(), bucket_bytes=1 << 20)
         assert reducer.num_collectives() > 2
-        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=True, reducer=reducer)
-        assert gs._bucketed_update
+        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=True, reducer=reducer,
+                              split_backward=split)
+        assert gs._bucketed_update and gs._split == split
         graph = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(5)]
     torch.cuda.synchronize()
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
