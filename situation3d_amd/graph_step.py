@@ -163,7 +163,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if reducer is None:
             optimizer.zero_grad(set_to_none=True)
-        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream):
+        # with a live process group its watchdog thread issues HIP calls of its own (event queries);
+        # they are harmless to this capture, so only police the capturing thread
+        import torch.distributed as dist
+        cap_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
             if self.prefetch:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
@@ -178,13 +182,14 @@ class GraphedTrainStep:
                 if not self._split:
                     self.plan_cur.copy_from(self.plan_next)      # hand over for the next replay
         if self._split:
-            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool()):
+            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(), capture_error_mode=cap_mode):
                 bwd_encoder()
                 if self.prefetch:  # the encoder's backward still reads plan_cur: hand over after it
                     self.plan_cur.copy_from(self.plan_next)
         if reducer is not None:
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
-                                                           pool=self.graph.pool()):
+                                                           pool=self.graph.pool(),
+                                                           capture_error_mode=cap_mode):
                 update()
         torch.cuda.synchronize()
 
