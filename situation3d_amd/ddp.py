@@ -171,10 +171,16 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal on a one-GPU box: SIG3D_DIST_BACKEND=gloo SIG3D_SHARE_GPU=1 runs every rank on GPU 0
+    # with host-side collectives -- slow, but it drives the exact multi-rank code path (graphs around
+    # collectives, buckets, bucketed AdamW) that RCCL drives on the 8-GPU node.
+    backend = os.environ.get("SIG3D_DIST_BACKEND", backend)
+    if os.environ.get("SIG3D_SHARE_GPU") and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
