@@ -1,0 +1,28 @@
+"""query_group_fused at the four SA shapes of the bench (per-level time and achieved HBM rate).
+SIG3D_GROUP_LDS=0 forces the direct-gather kernel for the small levels."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from situation3d_amd import _lib as L
+import bench
+dev = torch.device("cuda", 0)
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+b = 8
+tot_t = tot_b = 0
+for (n, m, ns, c) in bench.SA_LEVELS:
+    xyz = torch.rand(b, n, 3, device=dev); new_xyz = xyz[:, :m].contiguous()
+    feat = torch.randn(b, c, n, device=dev)
+    idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev)
+    out = torch.empty(b, 3 + c, m, ns, device=dev)
+    t = timeit(lambda: L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, 1, ctypes.c_float(0.5), L.ptr(xyz),
+                              L.ptr(new_xyz), L.ptr(feat), L.ptr(idx), L.ptr(out), L.stream_ptr()))
+    byt = bench.group_algorithmic_bytes(b, n, m, ns, c)
+    tot_t += t; tot_b += byt
+    print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB)" % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6))
+print("total %.1f us, %.2f TB/s = %.3f of 8 TB/s" % (tot_t, tot_b / tot_t / 1e6, tot_b / tot_t / 8e6))
