@@ -234,7 +234,7 @@ def main():
                                    "(32 queries + 20 question tokens, 12 layers)",
                        "global_batch": world * BATCH, "points_per_scene": N_POINTS,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "sig3d_query_group_fused (query_group_fused_kernel, query_group_lds_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),

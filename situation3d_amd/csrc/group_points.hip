@@ -9,8 +9,6 @@
 // consecutive samples (16-byte idx load, 16-byte stores), and walks a slab of channels with
 // its four neighbour indices held in registers, so idx is read once per slab instead of once
 // per channel.  The gathered rows (n floats per channel) are L2-resident.
-#include <cstdlib>
-
 #include "sig3d_common.h"
 
 namespace {
@@ -215,75 +213,6 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
   }
 }
 
-// Fused QueryAndGroup tail for SMALL source clouds (n <= 4096: every level but the first): the
-// workgroup stages its `cslab` feature rows (cslab * n floats <= 64 KiB) in LDS with coalesced
-// 16-byte loads and gathers from there -- "LDS-staged neighbour tiles" -- instead of issuing
-// 4-byte random reads against L2 for every output element; idx is read once per 4 samples and
-// the output leaves as 16-byte stores.  blockIdx.y == 0 is the xyz slab (centre subtraction),
-// blockIdx.y >= 1 a feature slab; blockIdx.x splits the (npoint * nsample) range.
-__global__ __launch_bounds__(GP_THREADS) void query_group_lds_kernel(
-    int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius, int cslab,
-    long e_per_block, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float s_rows[];
-  const int bi = blockIdx.z;
-  const long total = (long)m * nsample;
-  const int c_total = (use_xyz ? 3 : 0) + c;
-  const long e_begin = (long)blockIdx.x * e_per_block, e_end = min(total, e_begin + e_per_block);
-  int slab = blockIdx.y;
-  if (use_xyz) {
-    if (slab == 0) {
-      const float *pts = xyz + (size_t)bi * n * 3;
-      for (int i = threadIdx.x; i < n * 3; i += GP_THREADS) s_rows[i] = pts[i];
-      __syncthreads();
-      for (long e = e_begin + (long)threadIdx.x * 4; e < e_end; e += GP_THREADS * 4) {
-        const int4 t = *reinterpret_cast<const int4 *>(idx + (size_t)bi * total + e);
-        const int ii[4] = {t.x, t.y, t.z, t.w};
-        const float *ctr = new_xyz + ((size_t)bi * m + (int)(e / nsample)) * 3;  // 4 samples share a centre
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float ca = ctr[a];
-          float v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float d = __fsub_rn(s_rows[3 * ii[q] + a], ca);   // grouped_xyz -= new_xyz  (:349)
-            if (normalize_xyz) d = __fdiv_rn(d, radius);      // grouped_xyz /= radius   (:351)
-            v[q] = d;
-          }
-          *reinterpret_cast<float4 *>(out + ((size_t)bi * c_total + a) * total + e) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      return;
-    }
-    slab -= 1;
-  }
-  const int l0 = slab * cslab;
-  const int nl = min(cslab, c - l0);
-  const int c_off = use_xyz ? 3 : 0;
-  {  // stage nl rows of n floats (n % 4 == 0 checked by the launcher)
-    const float4 *src = reinterpret_cast<const float4 *>(features + ((size_t)bi * c + l0) * n);
-    float4 *dst = reinterpret_cast<float4 *>(s_rows);
-    const int n4 = nl * (n / 4);
-    for (int i = threadIdx.x; i < n4; i += GP_THREADS) dst[i] = src[i];
-  }
-  __syncthreads();
-  for (long e = e_begin + (long)threadIdx.x * 4; e < e_end; e += GP_THREADS * 4) {
-    const int4 t = *reinterpret_cast<const int4 *>(idx + (size_t)bi * total + e);
-    float *o = out + ((size_t)bi * c_total + c_off + l0) * total + e;
-    for (int l = 0; l < nl; l += 4) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float *row = s_rows + (size_t)min(l + u, nl - 1) * n;
-        v[u] = make_float4(row[t.x], row[t.y], row[t.z], row[t.w]);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (l + u < nl) *reinterpret_cast<float4 *>(o + (size_t)(l + u) * total) = v[u];
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int sig3d_group_points(int b, int c, int n, int npoints, int nsample,
@@ -376,28 +305,6 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused: n must be >= 1 when idx is non-empty");
   const bool vec = (nsample % 4 == 0);
-  static const int lds_mode = [] { const char *v = getenv("SIG3D_GROUP_LDS"); return v ? atoi(v) : 1; }();
-  if (lds_mode && vec && c >= 8 && n % 4 == 0 && n <= 4096) {
-    // small source cloud: rows staged in LDS (query_group_lds_kernel)
-    int cslab = GG_LDS_FLOATS / n;
-    if (cslab > c) cslab = c;
-    cslab = cslab / 4 * 4;
-    const int slabs = (use_xyz ? 1 : 0) + sig3d_ceil_div(c, cslab);
-    const long per_sweep = (long)GP_THREADS * 4;
-    long max_splits = total / per_sweep;
-    if (max_splits < 1) max_splits = 1;
-    long splits = (768 + (long)slabs * b - 1) / ((long)slabs * b);
-    if (splits > max_splits) splits = max_splits;
-    long e_per_block = (total + splits - 1) / splits;
-    e_per_block = (e_per_block + per_sweep - 1) / per_sweep * per_sweep;
-    splits = (total + e_per_block - 1) / e_per_block;
-    const size_t lds = sizeof(float) * (size_t)max(cslab * n, 3 * n);
-    hipLaunchKernelGGL(query_group_lds_kernel, dim3((unsigned)splits, slabs, b), dim3(GP_THREADS), lds, stream, n,
-                       m, c, nsample, use_xyz, normalize_xyz, radius, cslab, e_per_block, xyz, new_xyz, features,
-                       idx, out);
-    SIG3D_LAUNCH_CHECK("query_group_lds_kernel");
-    return 0;
-  }
   dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS),
             (use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB), b);
   if (vec)
