@@ -148,8 +148,10 @@ class _FusedMLPMax(torch.autograd.Function):
             dA = None
             # one fill each for every BatchNorm-gradient accumulator and every dW of the stack
             cmax = max(w.shape[0] for w in ws)
-            sums_all = torch.zeros((nl, 2, cmax), dtype=torch.float64, device=dev)
-            dw_all = torch.zeros(sum(w.numel() for w in ws), dtype=torch.float32, device=dev)
+            n_dw = sum(w.numel() for w in ws)
+            zeros = torch.zeros(nl * 2 * cmax * 8 + n_dw * 4, dtype=torch.uint8, device=dev)
+            sums_all = zeros[:nl * 2 * cmax * 8].view(torch.float64).view(nl, 2, cmax)
+            dw_all = zeros[nl * 2 * cmax * 8:].view(torch.float32)
             dw_off = 0
             for k in range(nl - 1, -1, -1):
                 cout, cin = ws[k].shape
@@ -166,9 +168,6 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(None), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
                               _lib.ptr(dY), 1, stream)
-                sums32 = sums[:, :cout].to(torch.float32)      # one conversion launch for both rows
-                grads[3 * k + 1] = sums32[1]                   # d gamma
-                grads[3 * k + 2] = sums32[0]                   # d beta
                 prev = ys[k - 1] if k > 0 else x
                 pps = affs[k - 1][0] if k > 0 else None
                 ppb = affs[k - 1][1] if k > 0 else None
@@ -188,6 +187,11 @@ class _FusedMLPMax(torch.autograd.Function):
                                   _lib.ptr(None), 0, stream)   # no statistics for an input gradient
                     if k == 0:
                         grad_x = dA
+            sums32 = sums_all.to(torch.float32)                # one conversion launch for the whole stack
+            for k in range(nl):
+                cout = ws[k].shape[0]
+                grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma
+                grads[3 * k + 2] = sums32[k, 0, :cout]         # d beta
         return (grad_x, None, None) + tuple(grads)
 
 
