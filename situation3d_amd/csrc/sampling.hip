@@ -20,6 +20,8 @@
 // as (bitrev << 22) | (k >> L).  Points with x^2+y^2+z^2 <= 1e-3 (double compare, :100-101)
 // never take part: their running distance is pinned to -1, which also makes the all-skipped
 // case return index 0 as the reference does (best = -1, besti = 0).
+#include <cstdlib>
+
 #include "sig3d_common.h"
 
 namespace {
@@ -148,7 +150,7 @@ int launch_fps(int b, int n, int m, int L, const float *dataset, float *temp, in
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
-constexpr int FPS_SLOT_U64 = 64;  // per scene: 2 parities x up to 8 workgroups x {val,key}, padded
+constexpr int FPS_SLOT_U64 = 64;  // per scene: 2 parities x W <= 16 workgroups x {val,key}
 
 template <int NT, int PPT, int W>
 __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L,
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
       const unsigned ok = s_key[par][lane & (NW - 1)];
       const int lv = row_allreduce_max_i32(ov);
       const unsigned lk = row_allreduce_min_u32(ov == lv ? ok : 0xFFFFFFFFu);
-      gu64 *slot = slots + (size_t)par * (2 * 8);
+      gu64 *slot = slots + (size_t)par * (2 * W);
       if (lane == 0) {
         __hip_atomic_store(slot + 2 * w + 0, ((u64)(unsigned)j << 32) | (unsigned)lv,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -342,12 +344,18 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
   if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream);
-  if (n <= 16384) return launch_fps<1024, 16>(b, n, m, L, dataset, temp, idxs, stream);
-  if (n <= 24576) return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
+  static const bool old_split = getenv("SIG3D_FPS_OLD_SPLIT") != nullptr;  // tools/fps_bench.py A/B
+  if (old_split) {
+    if (n <= 16384) return launch_fps<1024, 16>(b, n, m, L, dataset, temp, idxs, stream);
+    if (n <= 24576) return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
+  }
   if (n <= 196608) {
     // cooperative kernel; at most 64 co-resident workgroups per launch (so that several
     // concurrent launches -- other streams, other processes -- can never starve each other)
-    const int W = n <= 98304 ? 4 : 8;
+    // 8 workgroups of 512 threads per scene: measured 1.76 us/round at n = 40 000 against 2.18 for
+    // 4 x 1024 (half the points per SIMD between two exchanges, 8-wave barriers) and 2.07 for
+    // 16 x 512 (more peers to wait for per hop); 8 scenes = 64 workgroups per launch
+    const int W = (old_split && n <= 98304) ? 4 : 8;
     const int chunk = 64 / W;
     for (int s0 = 0; s0 < b; s0 += chunk) {
       const int bc = (b - s0) < chunk ? (b - s0) : chunk;
@@ -355,9 +363,16 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
       float *tp = temp + (size_t)s0 * n;
       int *ix = idxs + (size_t)s0 * m;
       int rc;
-      if (n <= 40960) rc = launch_fps_coop<1024, 10, 4>(bc, n, m, L, ds, tp, ix, stream);
-      else if (n <= 65536) rc = launch_fps_coop<1024, 16, 4>(bc, n, m, L, ds, tp, ix, stream);
-      else if (n <= 98304) rc = launch_fps_coop<1024, 24, 4>(bc, n, m, L, ds, tp, ix, stream);
+      if (old_split) {
+        if (n <= 40960) rc = launch_fps_coop<1024, 10, 4>(bc, n, m, L, ds, tp, ix, stream);
+        else if (n <= 65536) rc = launch_fps_coop<1024, 16, 4>(bc, n, m, L, ds, tp, ix, stream);
+        else if (n <= 98304) rc = launch_fps_coop<1024, 24, 4>(bc, n, m, L, ds, tp, ix, stream);
+        else rc = launch_fps_coop<1024, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
+      } else if (n <= 16384) rc = launch_fps_coop<512, 4, 8>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 24576) rc = launch_fps_coop<512, 6, 8>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 40960) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 98304) rc = launch_fps_coop<512, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
       else rc = launch_fps_coop<1024, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
       if (rc) return rc;
     }

@@ -1,0 +1,20 @@
+"""FPS at the SA1 shape (B=8 x 40000 -> 2048) and the small levels; SIG3D_FPS_VARIANT picks experimental
+(threads, points/thread, workgroups/scene) splits of the cooperative kernel."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from situation3d_amd.pointnet2 import _ext
+import bench
+dev = torch.device("cuda", 0)
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+for b, n, m in [(8, 40000, 2048), (4, 40000, 2048), (8, 60000, 2048), (8, 90000, 2048), (8, 10000, 2048), (8, 16384, 2048), (8, 24000, 2048), (8, 8192, 2048), (8, 2048, 1024)]:
+    xyz = bench.synthetic_batch(b, n, 5, dev)["point_clouds"][..., :3].contiguous()
+    ref = _ext.furthest_point_sampling(xyz, m)
+    t = timeit(lambda: _ext.furthest_point_sampling(xyz, m))
+    print("B=%d N=%5d M=%4d: %8.1f us  (%.2f us/round)  checksum %d" % (b, n, m, t, t / (m - 1), int(ref.long().sum())))
