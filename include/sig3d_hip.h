@@ -73,6 +73,33 @@ int sig3d_ball_query_grid(int b, int n, int m, float radius, int nsample, const 
                           const float *xyz, int *idx, void *workspace, long workspace_bytes,
                           void *stream);
 
+/* ---- scene voxelisation / de-duplication (the DataLoader-side numpy path) ----
+ * replaces, for a whole ragged batch at once,
+ *   lib/sepdataset.py:286-300 (augmentation rotations p <- p.R^T, p <- p - p.min(0)),
+ *   lib/openscene/voxelizer_dev.py:35-48 (Voxelizer.voxelize: floor([p,1] @ diag(1/voxel)^T), gathers),
+ *   lib/openscene/voxelization_utils.py:9-24,108-140 (fnv_hash_vec, sparse_quantize's np.unique).
+ * offsets (b+1) i32 DEVICE array: scene s owns points [offsets[s], offsets[s+1]) of the flat arrays;
+ * max_n >= the largest scene, total = offsets[b] (both host values, no device sync).
+ * coords (total,3) f32 (coords_f64 == 0) or f64; rot (b,n_rot,9) f64 row-major matrices applied in
+ * order (n_rot <= 8, NULL when 0); shift_min: subtract the per-scene minimum (in float32 when the
+ * scene is still float32, as numpy would); cell = floor(v * quant[a]) (divide == 0, the voxeliser's
+ * matmul) or floor(v / quant[a]) (divide == 1, sparse_quantize), all in float64.
+ * -> inds (total) i32: per scene, scene-local index of the FIRST point of every distinct cell in
+ *    ascending FNV-key order (np.unique's return_index), first num_unique[s] entries valid;
+ *    inverse (total) i32: rank of every point's cell (return_inverse); num_unique (b) i32;
+ *    mins (b,3) f64: per-scene minimum of the (rotated) coordinates (always written);
+ *    optional (NULL to skip) vox (total,3) i32 cells of the kept points, feats_out (total,c_feat) f32
+ *    = feats[inds], labels_out (total) i32 = labels[inds].
+ * Bit-identical to the numpy path (stable 8-pass LSD radix sort of the 64-bit keys). */
+long sig3d_voxelize_workspace_bytes(int b, long total, int max_n);
+int sig3d_voxelize(int b, int max_n, const int *offsets, const void *coords, int coords_f64, int n_rot,
+                   const double *rot, int shift_min, int divide, const double *quant, int c_feat,
+                   const float *feats, const int *labels, int *inds, int *inverse, int *num_unique,
+                   int *vox, float *feats_out, int *labels_out, double *mins, void *workspace,
+                   long workspace_bytes, long total, void *stream);
+/* voxelization_utils.py:9-24 alone: arr (n,d) i64 cells -> out (n) u64 keys */
+int sig3d_fnv_hash_vec(long n, int d, const long *arr, unsigned long long *out, void *stream);
+
 /* replaces group_points_kernel_wrapper(b,c,n,npoints,nsample,points,idx,out)
  *   group_points.cpp:4-6, group_points_gpu.cu:8-39.
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */

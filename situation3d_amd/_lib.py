@@ -24,6 +24,9 @@ SIGNATURES = {
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "sig3d_ball_query_grid": [_I, _I, _I, _F, _I, _P, _P, _P, _P, ctypes.c_long, _P],
+    "sig3d_voxelize": [_I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                       ctypes.c_long, ctypes.c_long, _P],
+    "sig3d_fnv_hash_vec": [ctypes.c_long, _I, _P, _P, _P],
     "sig3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
@@ -56,7 +59,7 @@ SIGNATURES = {
     "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _F, ctypes.c_uint, _P, _P],
 }
-INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error")
+INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes")
 
 _lib = None
 
@@ -82,6 +85,8 @@ def load():
         fn.restype = ctypes.c_int
     lib.sig3d_version.restype = ctypes.c_char_p
     lib.sig3d_last_error.restype = ctypes.c_char_p
+    lib.sig3d_voxelize_workspace_bytes.argtypes = [_I, ctypes.c_long, _I]
+    lib.sig3d_voxelize_workspace_bytes.restype = ctypes.c_long
     _lib = lib
     return lib
 
