@@ -81,7 +81,8 @@ int sig3d_ball_query_grid(int b, int n, int m, float radius, int nsample, const 
  * offsets (b+1) i32 DEVICE array: scene s owns points [offsets[s], offsets[s+1]) of the flat arrays;
  * max_n >= the largest scene, total = offsets[b] (both host values, no device sync).
  * coords (total,3) f32 (coords_f64 == 0) or f64; rot (b,n_rot,9) f64 row-major matrices applied in
- * order (n_rot <= 8, NULL when 0); shift_min: subtract the per-scene minimum (in float32 when the
+ * order (n_rot <= 8, NULL when 0); flips (b) i32 device array or NULL, bit a set = negate axis a first
+ * (the mirror augmentation, sepdataset.py:243-262); shift_min: subtract the per-scene minimum (in float32 when the
  * scene is still float32, as numpy would); cell = floor(v * quant[a]) (divide == 0, the voxeliser's
  * matmul) or floor(v / quant[a]) (divide == 1, sparse_quantize), all in float64.
  * -> inds (total) i32: per scene, scene-local index of the FIRST point of every distinct cell in
@@ -93,7 +94,7 @@ int sig3d_ball_query_grid(int b, int n, int m, float radius, int nsample, const 
  * Bit-identical to the numpy path (stable 8-pass LSD radix sort of the 64-bit keys). */
 long sig3d_voxelize_workspace_bytes(int b, long total, int max_n);
 int sig3d_voxelize(int b, int max_n, const int *offsets, const void *coords, int coords_f64, int n_rot,
-                   const double *rot, int shift_min, int divide, const double *quant, int c_feat,
+                   const double *rot, const int *flips, int shift_min, int divide, const double *quant, int c_feat,
                    const float *feats, const int *labels, int *inds, int *inverse, int *num_unique,
                    int *vox, float *feats_out, int *labels_out, double *mins, void *workspace,
                    long workspace_bytes, long total, void *stream);

@@ -118,11 +118,15 @@ class Voxelizer:
         return aug, feats, labels, np.array(inverse)
 
 
-def prepare_scene(points, rotations=(), voxel_size=0.02):
-    """sepdataset.py:286-302 for one scene: p <- p.R^T for every rotation in order (float64 np.dot),
-    p <- p - p.min(0), Voxelizer(voxel_size).voxelize(...).  Returns (cells float64 (U,3), inds, inverse,
-    min_coords)."""
+def prepare_scene(points, rotations=(), voxel_size=0.02, flips=0):
+    """sepdataset.py:243-302 for one scene: mirror flips (bit 0: x, bit 1: y), p <- p.R^T for every
+    rotation in order (float64 np.dot), p <- p - p.min(0), Voxelizer(voxel_size).voxelize(...).
+    Returns (cells float64 (U,3), inds, inverse, min_coords)."""
     p = np.array(points)
+    if flips & 1:
+        p[:, 0] = -1 * p[:, 0]
+    if flips & 2:
+        p[:, 1] = -1 * p[:, 1]
     for r in rotations:
         p = np.dot(p[:, 0:3], np.transpose(np.asarray(r, dtype=np.float64)))
     mins = p.min(0)
@@ -152,3 +156,42 @@ def align_pose(position, bs_center, axis_align_matrix):
     aug = np.dot(aug, np.asarray(axis_align_matrix, dtype=np.float64).transpose())
     rot = np.dot(np.asarray(axis_align_matrix, dtype=np.float64)[0:3, 0:3], quat_to_matrix(position[3:]))
     return aug[:, 0:3].reshape(-1), rot
+
+
+def matrix_to_quat(m):
+    """Unit quaternion xyzw of a rotation matrix (Shepperd's branch on the largest of trace / diagonal);
+    defined up to sign, compare with +-."""
+    m = np.asarray(m, dtype=np.float64)
+    t = np.trace(m)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = [(m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s]
+    else:
+        i = int(np.argmax(np.diag(m)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+        q = [0.0, 0.0, 0.0, (m[k, j] - m[j, k]) / s]
+        q[i] = 0.25 * s
+        q[j] = (m[j, i] + m[i, j]) / s
+        q[k] = (m[k, i] + m[i, k]) / s
+    return np.array(q)
+
+
+def augment_pose(coord, rot, flips, rotations):
+    """The pose half of sepdataset.py:243-295 on (position, rotation MATRIX): flips negate a coordinate
+    and conjugate the matrix as written there (x flip: m[0,0], m[1,1] negated -- :249-250; y flip: rows
+    and columns 0/1 swapped -- :258-259); every rotation r: coord <- coord.r^T, m <- r.m."""
+    coord = np.array(coord, dtype=np.float64)
+    m = np.array(rot, dtype=np.float64)
+    if flips & 1:
+        coord[0] = -coord[0]
+        m[0, 0] *= -1
+        m[1, 1] *= -1
+    if flips & 2:
+        coord[1] = -coord[1]
+        m = m[[1, 0, 2], :][:, [1, 0, 2]]
+    for r in rotations:
+        r = np.asarray(r, dtype=np.float64)
+        coord = np.dot(coord.reshape(1, -1), r.T).reshape(-1)
+        m = np.dot(r, m)
+    return coord, m

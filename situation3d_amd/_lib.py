@@ -24,7 +24,7 @@ SIGNATURES = {
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "sig3d_ball_query_grid": [_I, _I, _I, _F, _I, _P, _P, _P, _P, ctypes.c_long, _P],
-    "sig3d_voxelize": [_I, _I, _P, _P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "sig3d_voxelize": [_I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                        ctypes.c_long, ctypes.c_long, _P],
     "sig3d_fnv_hash_vec": [ctypes.c_long, _I, _P, _P, _P],
     "sig3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],

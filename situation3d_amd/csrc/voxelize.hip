@@ -31,6 +31,7 @@ struct VoxParams {
   const void *coords;      // flat (total,3), f32 or f64
   const double *rot;       // (b, n_rot, 9) row-major 3x3, applied in order as p <- R p, or NULL
   const int *offsets;      // (b+1) first point of every scene
+  const int *flips;        // (b) bit a set: negate axis a before anything else (mirror augmentation), or NULL
   int is_f64, n_rot, shift_min, divide;
   double q0, q1, q2;       // per-axis scale (divide == 0) or cell size (divide == 1)
 };
@@ -53,6 +54,10 @@ __device__ __forceinline__ VoxPoint vox_load(const VoxParams &p, int scene, long
     const float *c = (const float *)p.coords + 3 * gi;
     v.x = (double)c[0]; v.y = (double)c[1]; v.z = (double)c[2];
     v.f32 = true;
+  }
+  if (p.flips) {  // sepdataset.py:246,255: exact sign change, the scene keeps its dtype
+    const int f = p.flips[scene];
+    v.x = (f & 1) ? -v.x : v.x; v.y = (f & 2) ? -v.y : v.y; v.z = (f & 4) ? -v.z : v.z;
   }
   for (int k = 0; k < p.n_rot; ++k) {
     const double *r = p.rot + ((long)scene * p.n_rot + k) * 9;
@@ -175,40 +180,38 @@ __global__ __launch_bounds__(VX_THREADS) void vox_hist_kernel(const int *__restr
   counts[((long)scene * 256 + tid) * tiles + tile] = s_hist[tid];
 }
 
-// exclusive scan of one scene's (digit-major, tile-minor) counts, in place
-__global__ __launch_bounds__(1024) void vox_scan_kernel(int entries, int *__restrict__ counts) {
-  __shared__ int s_wave[16];
-  const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int *c = counts + (long)scene * entries;
-  const int per = (entries + 1023) / 1024;
-  const int lo = min(tid * per, entries), hi = min(lo + per, entries);
-  int tot = 0;
-  for (int i = lo; i < hi; ++i) tot += c[i];
-  int incl = tot;
+// one wave per (scene, digit): exclusive scan over the tiles of that digit's row, in place, and the
+// row total; the scatter kernel turns the 256 totals into digit bases itself
+__global__ __launch_bounds__(64) void vox_rowscan_kernel(int tiles, int *__restrict__ counts,
+                                                         int *__restrict__ digit_tot) {
+  const int row = blockIdx.x, lane = threadIdx.x;  // row = scene * 256 + digit
+  int *c = counts + (long)row * tiles;
+  int carry = 0;
+  for (int t0 = 0; t0 < tiles; t0 += 64) {
+    const int t = t0 + lane;
+    const int v = t < tiles ? c[t] : 0;
+    int incl = v;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (t < tiles) c[t] = carry + incl - v;
+    carry += __shfl(incl, 63);
   }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  int run = incl - tot;
-  for (int w = 0; w < wave; ++w) run += s_wave[w];
-  for (int i = lo; i < hi; ++i) {
-    const int v = c[i];
-    c[i] = run;
-    run += v;
-  }
+  if (lane == 0) digit_tot[row] = carry;
 }
 
 __global__ __launch_bounds__(VX_THREADS) void vox_scatter_kernel(const int *__restrict__ offsets, int tiles,
                                                                  int shift, const u64 *__restrict__ keys_in,
                                                                  const int *__restrict__ vals_in,
                                                                  const int *__restrict__ starts,
+                                                                 const int *__restrict__ digit_tot,
                                                                  u64 *__restrict__ keys_out,
                                                                  int *__restrict__ vals_out) {
   __shared__ int s_cnt[VX_WAVES][256];
   __shared__ int s_base[VX_WAVES][256];
+  __shared__ int s_dig[VX_WAVES];
   const int scene = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seg = offsets[scene], n = offsets[scene + 1] - seg;
@@ -244,9 +247,19 @@ __global__ __launch_bounds__(VX_THREADS) void vox_scatter_kernel(const int *__re
     __builtin_amdgcn_wave_barrier();
     rank[r] = pre + before;
   }
+  // digit base = totals of all smaller digits (block scan of the 256 row totals)
+  const int dtot = digit_tot[scene * 256 + tid];
+  int dincl = dtot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(dincl, off);
+    if (lane >= off) dincl += o;
+  }
+  if (lane == 63) s_dig[wave] = dincl;
   __syncthreads();
   {
-    int run = starts[((long)scene * 256 + tid) * tiles + tile];
+    int run = starts[((long)scene * 256 + tid) * tiles + tile] + dincl - dtot;
+    for (int w = 0; w < wave; ++w) run += s_dig[w];
     for (int w = 0; w < VX_WAVES; ++w) {
       s_base[w][tid] = run;
       run += s_cnt[w][tid];
@@ -276,8 +289,9 @@ __global__ __launch_bounds__(VX_THREADS) void vox_heads_kernel(const int *__rest
   const int scene = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int seg = offsets[scene], n = offsets[scene + 1] - seg;
   int c = 0;
+#pragma unroll
   for (int j = 0; j < VX_ITEMS; ++j) {
-    const int e = tile * VX_TILE + tid * VX_ITEMS + j;
+    const int e = tile * VX_TILE + j * VX_THREADS + tid;
     if (e < n && vx_head(keys, seg, e)) ++c;
   }
 #pragma unroll
@@ -316,50 +330,89 @@ __global__ __launch_bounds__(VX_THREADS) void vox_emit_kernel(
     const int *__restrict__ vals, const int *__restrict__ tile_off, int c_feat, const float *__restrict__ feats,
     const int *__restrict__ labels, int *__restrict__ inds, int *__restrict__ inverse, int *__restrict__ vox,
     float *__restrict__ feats_out, int *__restrict__ labels_out) {
-  __shared__ int s_w[VX_WAVES];
-  const int scene = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_cnt[VX_ITEMS][VX_WAVES];
+  const int scene = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int seg = p.offsets[scene], n = p.offsets[scene + 1] - seg;
   if (tile * VX_TILE >= n) return;
+  // element order: round-major, then thread (coalesced); all key / index loads first
+  u64 k[VX_ITEMS], kp[VX_ITEMS];
+  int src[VX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < VX_ITEMS; ++r) {
+    const int e = tile * VX_TILE + r * VX_THREADS + tid;
+    const long g = (long)seg + (e < n ? e : 0);
+    k[r] = keys[g];
+    kp[r] = keys[g > seg ? g - 1 : g];
+    src[r] = vals[g];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const u64 lt = (1ull << lane) - 1ull;
   bool head[VX_ITEMS];
-  int tot = 0;
+  int before[VX_ITEMS];
 #pragma unroll
-  for (int j = 0; j < VX_ITEMS; ++j) {
-    const int e = tile * VX_TILE + tid * VX_ITEMS + j;
-    head[j] = e < n && vx_head(keys, seg, e);
-    tot += head[j];
+  for (int r = 0; r < VX_ITEMS; ++r) {
+    const int e = tile * VX_TILE + r * VX_THREADS + tid;
+    head[r] = e < n && (e == 0 || k[r] != kp[r]);
+    const u64 bal = __ballot(head[r]);
+    before[r] = __popcll(bal & lt);
+    if (lane == 0) s_cnt[r][wave] = __popcll(bal);
   }
-  int incl = tot;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) s_w[wave] = incl;
   __syncthreads();
-  int run = tile_off[(long)scene * tiles + tile] + incl - tot;
-  for (int w = 0; w < wave; ++w) run += s_w[w];
   const double m0 = p.shift_min ? mins[scene * 3 + 0] : 0.0, m1 = p.shift_min ? mins[scene * 3 + 1] : 0.0,
                m2 = p.shift_min ? mins[scene * 3 + 2] : 0.0;
+  int rank[VX_ITEMS];
+  {
+    int run = tile_off[(long)scene * tiles + tile];
 #pragma unroll
-  for (int j = 0; j < VX_ITEMS; ++j) {
-    const int e = tile * VX_TILE + tid * VX_ITEMS + j;
-    if (e >= n) break;
-    run += head[j];
-    const int rank = run - 1;  // heads up to and including e, minus one
-    const int src = vals[(long)seg + e];
-    inverse[(long)seg + src] = rank;
-    if (head[j]) {
-      const long o = (long)seg + rank;
-      inds[o] = src;
-      if (vox) {
-        const VoxPoint v = vox_load(p, scene, (long)seg + src);
-        vox[3 * o + 0] = (int)(long)vox_cell(v.x, m0, v.f32, p, p.q0);
-        vox[3 * o + 1] = (int)(long)vox_cell(v.y, m1, v.f32, p, p.q1);
-        vox[3 * o + 2] = (int)(long)vox_cell(v.z, m2, v.f32, p, p.q2);
+    for (int r = 0; r < VX_ITEMS; ++r) {
+      int mine = run;
+#pragma unroll
+      for (int w = 0; w < VX_WAVES; ++w) {
+        const int c = s_cnt[r][w];
+        mine += w < wave ? c : 0;
+        run += c;
       }
-      if (feats_out)
-        for (int c = 0; c < c_feat; ++c) feats_out[o * c_feat + c] = feats[((long)seg + src) * c_feat + c];
-      if (labels_out) labels_out[o] = labels[(long)seg + src];
+      rank[r] = mine + before[r] + (head[r] ? 1 : 0) - 1;  // heads up to and including e, minus one
+    }
+  }
+  // gathers of the kept points: loads of all rounds before any store
+  VoxPoint pt[VX_ITEMS];
+  int lab[VX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < VX_ITEMS; ++r) {
+    const long gs = (long)seg + (head[r] ? src[r] : 0);
+    if (vox) pt[r] = vox_load(p, scene, gs);
+    lab[r] = labels_out ? labels[gs] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < VX_ITEMS; ++r) {
+    const int e = tile * VX_TILE + r * VX_THREADS + tid;
+    if (e < n) inverse[(long)seg + src[r]] = rank[r];
+    if (head[r]) {
+      const long o = (long)seg + rank[r];
+      inds[o] = src[r];
+      if (vox) {
+        vox[3 * o + 0] = (int)(long)vox_cell(pt[r].x, m0, pt[r].f32, p, p.q0);
+        vox[3 * o + 1] = (int)(long)vox_cell(pt[r].y, m1, pt[r].f32, p, p.q1);
+        vox[3 * o + 2] = (int)(long)vox_cell(pt[r].z, m2, pt[r].f32, p, p.q2);
+      }
+      if (labels_out) labels_out[o] = lab[r];
+    }
+  }
+  if (feats_out) {
+#pragma unroll
+    for (int r = 0; r < VX_ITEMS; ++r) {
+      if (head[r]) {
+        const float *fs = feats + ((long)seg + src[r]) * c_feat;
+        float *fd = feats_out + ((long)seg + rank[r]) * c_feat;
+        if (c_feat == 3) {
+          const float a = fs[0], b2 = fs[1], c2 = fs[2];
+          fd[0] = a; fd[1] = b2; fd[2] = c2;
+        } else {
+          for (int c = 0; c < c_feat; ++c) fd[c] = fs[c];
+        }
+      }
     }
   }
 }
@@ -367,7 +420,7 @@ __global__ __launch_bounds__(VX_THREADS) void vox_emit_kernel(
 struct VoxWorkspace {
   u64 *keys[2];
   int *vals[2];
-  int *counts, *tile_heads;
+  int *counts, *digit_tot, *tile_heads;
   double *min_part;
   size_t bytes;
 };
@@ -385,6 +438,7 @@ VoxWorkspace vox_layout(void *base, long b, long total, int tiles) {
   w.vals[0] = (int *)take(sizeof(int) * total);
   w.vals[1] = (int *)take(sizeof(int) * total);
   w.counts = (int *)take(sizeof(int) * b * 256 * tiles);
+  w.digit_tot = (int *)take(sizeof(int) * b * 256);
   w.tile_heads = (int *)take(sizeof(int) * b * tiles);
   w.min_part = (double *)take(sizeof(double) * b * tiles * 3);
   w.bytes = (size_t)(p - (char *)base);
@@ -408,8 +462,8 @@ extern "C" int sig3d_fnv_hash_vec(long n, int d, const long *arr, unsigned long 
 }
 
 extern "C" int sig3d_voxelize(int b, int max_n, const int *offsets, const void *coords, int coords_f64,
-                              int n_rot, const double *rot, int shift_min, int divide, const double *quant,
-                              int c_feat, const float *feats, const int *labels, int *inds, int *inverse,
+                              int n_rot, const double *rot, const int *flips, int shift_min, int divide,
+                              const double *quant, int c_feat, const float *feats, const int *labels, int *inds, int *inverse,
                               int *num_unique, int *vox, float *feats_out, int *labels_out, double *mins,
                               void *workspace, long workspace_bytes, long total, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -428,7 +482,7 @@ extern "C" int sig3d_voxelize(int b, int max_n, const int *offsets, const void *
   SIG3D_REQUIRE(workspace && (size_t)workspace_bytes >= w.bytes, "workspace too small (sig3d_voxelize_workspace_bytes)");
 
   VoxParams p;
-  p.coords = coords; p.rot = rot; p.offsets = offsets;
+  p.coords = coords; p.rot = rot; p.offsets = offsets; p.flips = flips;
   p.is_f64 = coords_f64; p.n_rot = n_rot; p.shift_min = shift_min; p.divide = divide;
   p.q0 = quant[0]; p.q1 = quant[1]; p.q2 = quant[2];
   const dim3 tgrid(tiles, b), blk(VX_THREADS);
@@ -440,9 +494,9 @@ extern "C" int sig3d_voxelize(int b, int max_n, const int *offsets, const void *
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 8 * pass;
     hipLaunchKernelGGL(vox_hist_kernel, tgrid, blk, 0, stream, offsets, tiles, shift, w.keys[cur], w.counts);
-    hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, stream, 256 * tiles, w.counts);
+    hipLaunchKernelGGL(vox_rowscan_kernel, dim3(b * 256), dim3(64), 0, stream, tiles, w.counts, w.digit_tot);
     hipLaunchKernelGGL(vox_scatter_kernel, tgrid, blk, 0, stream, offsets, tiles, shift, w.keys[cur], w.vals[cur],
-                       w.counts, w.keys[cur ^ 1], w.vals[cur ^ 1]);
+                       w.counts, w.digit_tot, w.keys[cur ^ 1], w.vals[cur ^ 1]);
     cur ^= 1;
   }
   hipLaunchKernelGGL(vox_heads_kernel, tgrid, blk, 0, stream, offsets, tiles, w.keys[cur], w.tile_heads);

@@ -68,10 +68,11 @@ def _workspace(nbytes, device):
     return buf
 
 
-def voxelize_batch(coords, offsets, feats=None, labels=None, rotations=None, voxel_size=None,
+def voxelize_batch(coords, offsets, feats=None, labels=None, rotations=None, flips=None, voxel_size=None,
                    quantization_size=None, shift_min=True, want_cells=True):
     """coords (total,3) f32/f64 flat batch; offsets: python list / CPU int tensor of B+1 scene starts.
     rotations: optional (B,K,3,3) f64 applied in order as p <- p.R^T (sepdataset.py:267,279,291).
+    flips: optional B ints, bit a set = axis a negated first (mirror augmentation, sepdataset.py:246,255).
     voxel_size: cells = floor(p * (1/voxel_size)) (voxelizer_dev.py:29-43); or quantization_size
     (scalar or 3 values): cells = floor(p / q) (voxelization_utils.py:108).
     Everything is enqueued on the current stream; nothing synchronises with the host."""
@@ -98,6 +99,10 @@ def voxelize_batch(coords, offsets, feats=None, labels=None, rotations=None, vox
     if rotations is not None:
         rot = torch.as_tensor(rotations, dtype=torch.float64).reshape(b, -1, 9).to(dev).contiguous()
         n_rot = rot.shape[1]
+    flips_dev = None
+    if flips is not None:
+        flips_dev = torch.as_tensor(flips, dtype=torch.int32).to(dev)
+        assert flips_dev.numel() == b
     c_feat = 0
     feats_out = labels_out = labels32 = None
     if feats is not None:
@@ -117,7 +122,8 @@ def voxelize_batch(coords, offsets, feats=None, labels=None, rotations=None, vox
     nbytes = _lib.load().sig3d_voxelize_workspace_bytes(b, total, max_n)
     work = _workspace(nbytes, dev)
     _lib.call("sig3d_voxelize", b, max_n, _lib.ptr(off_dev), _lib.ptr(coords),
-              1 if coords.dtype == torch.float64 else 0, n_rot, _lib.ptr(rot), 1 if shift_min else 0, divide,
+              1 if coords.dtype == torch.float64 else 0, n_rot, _lib.ptr(rot), _lib.ptr(flips_dev),
+              1 if shift_min else 0, divide,
               ctypes.cast(quant_c, ctypes.c_void_p), c_feat, _lib.ptr(feats), _lib.ptr(labels32), _lib.ptr(inds),
               _lib.ptr(inverse), _lib.ptr(num_unique), _lib.ptr(cells), _lib.ptr(feats_out), _lib.ptr(labels_out),
               _lib.ptr(mins), _lib.ptr(work), nbytes, total, _lib.stream_ptr(dev))

@@ -154,3 +154,40 @@ def test_round_trip_properties_at_full_size():
         assert torch.equal(first, ind)
         keys = V.fnv_hash_vec(cells).cpu().numpy().view(np.uint64)
         assert (keys[1:] > keys[:-1]).all()
+
+
+def test_prepare_batch_with_augmentation_vs_oracle():
+    """Flips + three rotations + min shift + voxelise for a ragged batch, and the device-side pose shift."""
+    from situation3d_amd import scene_prep as sp
+    rng = np.random.default_rng(21)
+    sizes = [30000, 12345, 40000]
+    scenes = [(rng.random((n, 3)) * np.array([8.0, 8.0, 3.0]) - np.array([4.0, 4.0, 0.0])).astype(np.float32)
+              for n in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    augs = [sp.SceneAugmentation(1, [("x", 0.03), ("y", -0.05), ("z", 0.07)]),
+            sp.SceneAugmentation(2, [("x", -0.01), ("y", 0.02), ("z", -0.08)]),
+            sp.SceneAugmentation(3, [("x", 0.08), ("y", 0.0), ("z", 0.01)])]
+    sits = [(rng.normal(size=3), np.array([0.0, 0.0, np.sin(0.3), np.cos(0.3)])) for _ in sizes]
+    flat = np.concatenate(scenes)
+    feats = rng.random((len(flat), 3)).astype(np.float32)
+    labels = rng.integers(0, 20, len(flat))
+    vb, aux = sp.prepare_batch(_t(flat), off, _t(feats), _t(labels), sits, augs, voxel_size=0.02)
+    assert aux.shape == (3, 7) and aux.dtype == torch.float32
+    for s, pts in enumerate(scenes):
+        mats = [sp.axis_rotation(ax, t) for ax, t in augs[s].rotations]
+        cells, inds, inverse, mins = _ref().prepare_scene(pts, mats, 0.02, flips=augs[s].flips)
+        c, f, lab, inv, ind = vb.scene(s)
+        assert np.array_equal(vb.mins[s].cpu().numpy(), mins), s
+        assert np.array_equal(ind.cpu().numpy(), inds) and np.array_equal(inv.cpu().numpy(), inverse), s
+        assert np.array_equal(c.cpu().numpy(), cells), s
+        assert np.array_equal(f.cpu().numpy(), feats[off[s]:off[s + 1]][inds]), s
+        assert np.array_equal(lab.cpu().numpy(), labels[off[s]:off[s + 1]][inds]), s
+        coord, quat = sp.augment_situation(*sits[s], augs[s])
+        want = np.concatenate([coord - mins, quat]).astype(np.float32)
+        assert np.allclose(aux[s].cpu().numpy(), want, atol=1e-6), s   # f32 output of an f64 subtraction
+    # eval split: no augmentation, float32 min shift
+    vb, aux = sp.prepare_batch(_t(flat), off, None, None, sits, None, voxel_size=0.02)
+    for s, pts in enumerate(scenes):
+        cells, inds, inverse, mins = _ref().prepare_scene(pts, (), 0.02)
+        c, _, _, inv, ind = vb.scene(s)
+        assert np.array_equal(ind.cpu().numpy(), inds) and np.array_equal(c.cpu().numpy(), cells), s

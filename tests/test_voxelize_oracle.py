@@ -68,3 +68,39 @@ def test_align_pose_known_answers():
     from scipy.spatial.transform import Rotation
     q = np.array([0.1, -0.3, 0.2, 0.9])
     assert np.allclose(ref.quat_to_matrix(q), Rotation.from_quat(q).as_matrix(), atol=1e-15)
+
+
+def test_scene_prep_pose_matches_oracle_and_draw_order():
+    """Host half of situation3d_amd.scene_prep (pose alignment + augmentation) against the matrix-form
+    restatement; quaternions compared up to sign, 1e-12."""
+    from situation3d_amd import scene_prep as sp
+    rng = np.random.default_rng(3)
+    a = np.eye(4)
+    a[:3, :3] = sp.axis_rotation("z", 0.7)
+    a[:3, 3] = [0.3, -1.2, 0.05]
+    for trial in range(20):
+        th = rng.uniform(-np.pi, np.pi)   # SQA3D situations are rotations about the up axis
+        q = np.array([0.0, 0.0, np.sin(th / 2), np.cos(th / 2)])
+        position = list(rng.normal(size=3)) + list(q)
+        centre = rng.normal(size=3)
+        coord, quat = sp.align_situation(position, centre, a)
+        ocoord, orot = ref.align_pose(position, centre, a)
+        assert np.allclose(coord, ocoord, atol=1e-12)
+        oq = ref.matrix_to_quat(orot)
+        assert min(np.abs(quat - oq).max(), np.abs(quat + oq).max()) < 1e-12
+        aug = sp.SceneAugmentation(flips=trial % 4, rotations=[("x", 0.02), ("y", -0.04), ("z", 0.06)][:trial % 4])
+        c2, q2 = sp.augment_situation(coord, quat, aug)
+        oc2, om2 = ref.augment_pose(ocoord, orot, aug.flips, [sp.axis_rotation(ax, t) for ax, t in aug.rotations])
+        assert np.allclose(c2, oc2, atol=1e-12)
+        # (the reference's x flip keeps the matrix a rotation only for rotations about z, which is what the
+        # aligned SQA3D poses are at that point)
+        oq2 = ref.matrix_to_quat(om2)
+        assert min(np.abs(q2 - oq2).max(), np.abs(q2 + oq2).max()) < 1e-12
+    # draw order: mirror YZ, mirror XZ, rot x, rot y, rot z (sepdataset.py:243-286)
+    np.random.seed(7)
+    draws = [np.random.random() for _ in range(5)]
+    np.random.seed(7)
+    aug = sp.SceneAugmentation.sample()
+    assert aug.flips == (1 if draws[0] > 0.5 else 0) | (2 if draws[1] > 0.5 else 0)
+    assert [ax for ax, _ in aug.rotations] == ["x", "y", "z"]
+    assert np.allclose([t for _, t in aug.rotations], [d * np.pi / 18 - np.pi / 36 for d in draws[2:]])
