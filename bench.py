@@ -248,10 +248,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, 1234)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        line = json.dumps(out)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (flushed at exit when stdout is a file): push it
+        # out first so that the JSON line is the LAST line of rank 0's stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

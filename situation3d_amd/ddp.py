@@ -17,8 +17,17 @@ no data parallelism at all (lib/solver.py).  What this does instead, sized for x
   * no find_unused_parameters graph walk: parameters that received no gradient keep their
     zero-filled slot and are reduced with their bucket at finish().
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _single_rank_rehearsal():
+    """SIG3D_SINGLE_RANK_PG=1: a one-GPU box initialises a real RCCL process group of size 1 and the
+    reducers issue their collectives anyway -- the all-reduce kernels, their stream ordering and the
+    graphs-around-collectives structure run exactly as on the 8-GPU node, only the wire is missing."""
+    return bool(os.environ.get("SIG3D_SINGLE_RANK_PG")) and dist.is_initialized()
 
 
 class GradBucketReducer:
@@ -93,7 +102,7 @@ class GradBucketReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        if self.world == 1:
+        if self.world == 1 and not _single_rank_rehearsal():
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         b["handle"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
@@ -167,7 +176,6 @@ class GradBucketReducer:
 def init_distributed(backend=None):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run
     contract) and bind this process to its GPU.  Returns (rank, local_rank, world_size)."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,4 +193,7 @@ def init_distributed(backend=None):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
+        if os.environ.get("SIG3D_SINGLE_RANK_PG") and not dist.is_initialized():
+            dist.init_process_group(backend=backend or "nccl", rank=0, world_size=1,
+                                    init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29517"))
     return rank, local, world

@@ -1,0 +1,42 @@
+"""bench.py end to end on the GPU box: the contract line of the default mode, and the data-parallel code
+path driven by a REAL RCCL process group of size 1 (SIG3D_SINGLE_RANK_PG=1: all-reduce kernels, graphs
+cut around collectives, bucketed AdamW -- everything the 8-GPU run executes except the wire)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_args, extra_env):
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline"] + extra_args, env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return json.loads(lines[-1])   # the JSON line is the LAST line of stdout
+
+
+def test_default_line_carries_the_contract():
+    out = _run([], {})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_data_parallel_path_over_real_rccl_group_of_one():
+    out = _run(["--force-reducer"], {"SIG3D_SINGLE_RANK_PG": "1", "MASTER_PORT": "29533"})
+    assert out["value"] > 0 and out["n_gpus"] == 1
+    ref = _run([], {})
+    # same seeds, same batches, mean over one rank == identity: the loss after 6 steps must agree
+    assert abs(out["final_loss"] - ref["final_loss"]) <= 2e-3 * abs(ref["final_loss"])
