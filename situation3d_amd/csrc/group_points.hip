@@ -9,6 +9,8 @@
 // consecutive samples (16-byte idx load, 16-byte stores), and walks a slab of channels with
 // its four neighbour indices held in registers, so idx is read once per slab instead of once
 // per channel.  The gathered rows (n floats per channel) are L2-resident.
+#include <cstdlib>
+
 #include "sig3d_common.h"
 
 namespace {
@@ -148,7 +150,15 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_lds_kernel(
 // Fused QueryAndGroup tail (pointnet2_utils.py:348-359): channels [0,3) = (xyz[idx] - centre)
 // [/ radius], channels [3, 3+c) = features[idx]; one pass, grouped tensor written once.
 // blockIdx.y == 0 handles the xyz slab (when use_xyz), the others feature slabs.
-template <bool VEC4>
+typedef float gp_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void gp_store4(float *o, float a, float b, float c, float d) {
+  gp_f32x4 v = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<gp_f32x4 *>(o));
+  else *reinterpret_cast<gp_f32x4 *>(o) = v;
+}
+
+template <bool VEC4, bool NT>
 __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
     int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
           v[q] = t;
         }
         float *o = out + ((size_t)bi * c_total + a) * total + e;
-        if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        if (VEC4) gp_store4<NT>(o, v[0], v[1], v[2], v[3]);
         else *o = v[0];
       }
       return;
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
   for (int t = 0; t < GP_CSLAB; ++t) {
     if (l0 + t < c) {
       float *o = out + ((size_t)bi * c_total + c_off + l0 + t) * total + e;
-      if (VEC4) *reinterpret_cast<float4 *>(o) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+      if (VEC4) gp_store4<NT>(o, v[t][0], v[t][1], v[t][2], v[t][3]);
       else *o = v[t][0];
     }
   }
@@ -307,11 +317,16 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
   const bool vec = (nsample % 4 == 0);
   dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS),
             (use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB), b);
-  if (vec)
-    hipLaunchKernelGGL((query_group_fused_kernel<true>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+  // streaming (nontemporal) stores of the grouped tensor: +4 % on this kernel inside the bench, step unchanged
+  static const bool nt = !(getenv("SIG3D_GROUP_NT") && getenv("SIG3D_GROUP_NT")[0] == '0');
+  if (vec && nt)
+    hipLaunchKernelGGL((query_group_fused_kernel<true, true>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+                       nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
+  else if (vec)
+    hipLaunchKernelGGL((query_group_fused_kernel<true, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   else
-    hipLaunchKernelGGL((query_group_fused_kernel<false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+    hipLaunchKernelGGL((query_group_fused_kernel<false, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   SIG3D_LAUNCH_CHECK("query_group_fused_kernel");
   return 0;
