@@ -190,7 +190,8 @@ def main():
         # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
         # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
         # issued once more eagerly right after the timed region and bracketed there.
-        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_ball_query", "sig3d_ball_query_grid",
+        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_transpose_cn",
+                            "sig3d_ball_query", "sig3d_ball_query_grid",
                             "sig3d_furthest_point_sampling"])
         if reducer is not None:
             reducer.hooks_enabled = True
@@ -210,7 +211,10 @@ def main():
             r = recs[name]
             return [s.elapsed_time(e) for s, e, _ in r]
 
-        grp = kernel_ms("sig3d_query_group_fused")
+        # the grouping launches of a step: the narrow SA1 level through query_group_fused_kernel, the wide
+        # levels through its point-major twin (plus the small transposes that feed it, reported apart)
+        grp = kernel_ms("sig3d_query_group_fused") + kernel_ms("sig3d_query_group_fused_pm")
+        tr = kernel_ms("sig3d_transpose_cn")
         grp_bytes = sum(group_algorithmic_bytes(BATCH, *lvl) for lvl in SA_LEVELS) * KSTEPS
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid")
@@ -234,12 +238,13 @@ def main():
                                    "(32 queries + 20 question tokens, 12 layers)",
                        "global_batch": world * BATCH, "points_per_scene": N_POINTS,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel",
+            "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel + query_group_fused_pm_kernel",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),
                          "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
             "kernels_ms_per_step": {"query_group_fused": round(sum(grp) / KSTEPS, 4),
+                                    "point_major_transposes": round(sum(tr) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
                                     "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},
             "launch_mode": "hipGraph replay" if use_graph else "eager",

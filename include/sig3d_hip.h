@@ -144,6 +144,15 @@ int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, int use_xyz
                             const float *new_xyz, const float *features, const int *idx,
                             float *out, void *stream);
 
+/* Same result, bit for bit, from POINT-MAJOR features: features_pm (b,n,ld) holds the c channels of
+ * point k at features_pm[(b*n + k)*ld .. +c) (c % 4 == 0, ld % 4 == 0, 16-byte aligned), so a neighbour is
+ * one contiguous row instead of c strided 4-byte gathers; tiles of 64 grouped elements x 128 channels are
+ * turned through LDS.  sig3d_transpose_cn makes the point-major copy of a (b,c,n) tensor. */
+int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, int nsample, int use_xyz,
+                               int normalize_xyz, float radius, const float *xyz, const float *new_xyz,
+                               const float *features_pm, const int *idx, float *out, void *stream);
+int sig3d_transpose_cn(int b, int c, int n, const float *in, float *out, void *stream);
+
 /* Backward of the feature half of sig3d_query_group_fused: grad_out (b,c_total,m,nsample)
  * with channel offset c_off -> grad_features (b,c,n) (zeroed here). */
 int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_total,

@@ -223,6 +223,99 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
   }
 }
 
+// ---- point-major variant of the fused grouping -------------------------------------------------
+// The (b,c,n) layout makes every grouped element a 4-byte gather per channel.  With the features
+// ALSO available point-major (b,n,ld) a neighbour's channels are one contiguous row: a workgroup takes
+// 64 grouped elements x 128 channels, half-waves read whole 512-byte rows (16 B per lane), the tile is
+// turned through LDS (16-byte slots XOR-swizzled by the row so that both the row-wise writes and the
+// column-wise reads are conflict-free) and leaves as 256-byte runs of one channel.
+constexpr int GPM_P = 64;    // grouped elements per tile
+constexpr int GPM_C = 128;   // channels per tile
+
+__global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
+    int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
+    const int *__restrict__ idx, float *__restrict__ out) {
+  __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
+  const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = m * nsample;
+  const int e0 = blockIdx.x * GPM_P;
+  const int c_total = (use_xyz ? 3 : 0) + c;
+  const int *ip = idx + (size_t)bi * total;
+  const float *fb = feat_pm + (size_t)bi * n * ld;
+  // rows: wave w, round r, half h -> tile row p = r*8 + w*2 + h; the half-wave's 32 lanes cover 128 channels
+  const int half = lane >> 5, j = lane & 31;
+  const bool col_ok = c0 + 4 * j < c;
+  gp_f32x4 v[GPM_P / 8];
+  int pi[GPM_P / 8];
+#pragma unroll
+  for (int r = 0; r < GPM_P / 8; ++r) {
+    const int e = e0 + r * 8 + wave * 2 + half;
+    pi[r] = ip[e < total ? e : total - 1];
+  }
+#pragma unroll
+  for (int r = 0; r < GPM_P / 8; ++r)
+    v[r] = *reinterpret_cast<const gp_f32x4 *>(fb + (size_t)pi[r] * ld + (col_ok ? c0 + 4 * j : 0));
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < GPM_P / 8; ++r) {
+    const int p = r * 8 + wave * 2 + half;
+    s_tile[p * (GPM_C / 4) + (j ^ (p & 7))] = v[r];
+  }
+  // the xyz slab rides along with the first channel tile: lane p of wave 0 handles element e0 + p
+  if (use_xyz && blockIdx.y == 0 && wave == 0) {
+    const int e = e0 + lane;
+    if (e < total) {
+      const int a = ip[e], jc = e / nsample;
+      const float *pt = xyz + ((size_t)bi * n + a) * 3;
+      const float *ctr = new_xyz + ((size_t)bi * m + jc) * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float t = __fsub_rn(pt[k], ctr[k]);
+        if (normalize_xyz) t = __fdiv_rn(t, radius);
+        __builtin_nontemporal_store(t, out + ((size_t)bi * c_total + k) * total + e);
+      }
+    }
+  }
+  __syncthreads();
+  // columns: lane = element p, wave w walks 16-byte slots w*8 .. w*8+7 (4 channels each)
+  const int p = lane, e = e0 + p;
+  const int c_off = use_xyz ? 3 : 0;
+  gp_f32x4 w4[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) w4[q] = s_tile[p * (GPM_C / 4) + ((wave * 8 + q) ^ (p & 7))];
+  if (e < total) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cc = c0 + 4 * (wave * 8 + q);
+      float *o = out + ((size_t)bi * c_total + c_off + cc) * total + e;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (cc + k < c) __builtin_nontemporal_store(w4[q][k], o + (size_t)k * total);
+    }
+  }
+}
+
+// (b,c,n) -> (b,n,c): 32x32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float *__restrict__ in,
+                                                           float *__restrict__ out) {
+  __shared__ float s_t[32][33];
+  const int bi = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = c0 + ty + 8 * k, nn = n0 + tx;
+    s_t[ty + 8 * k][tx] = (cc < c && nn < n) ? in[((size_t)bi * c + cc) * n + nn] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int nn = n0 + ty + 8 * k, cc = c0 + tx;
+    if (cc < c && nn < n) out[((size_t)bi * n + nn) * c + cc] = s_t[tx][ty + 8 * k];
+  }
+}
+
 }  // namespace
 
 extern "C" int sig3d_group_points(int b, int c, int n, int npoints, int nsample,
@@ -329,6 +422,34 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
     hipLaunchKernelGGL((query_group_fused_kernel<false, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   SIG3D_LAUNCH_CHECK("query_group_fused_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_transpose_cn(int b, int c, int n, const float *in, float *out, void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0, "negative size");
+  if (b == 0 || c == 0 || n == 0) return 0;
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3(sig3d_ceil_div(n, 32), sig3d_ceil_div(c, 32), b), dim3(256), 0,
+                     (hipStream_t)stream_, c, n, in, out);
+  SIG3D_LAUNCH_CHECK("transpose_cn_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, int nsample, int use_xyz,
+                                          int normalize_xyz, float radius, const float *xyz,
+                                          const float *new_xyz, const float *features_pm, const int *idx,
+                                          float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 4 && n >= 0 && m >= 0 && nsample >= 0, "bad size (c >= 4)");
+  SIG3D_REQUIRE(c % 4 == 0 && ld % 4 == 0 && ld >= c, "point-major rows: c and ld multiples of 4, ld >= c");
+  SIG3D_REQUIRE(((uintptr_t)features_pm & 15) == 0, "features_pm must be 16-byte aligned");
+  const long total = (long)m * nsample;
+  SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
+  if (b == 0 || total == 0) return 0;
+  SIG3D_REQUIRE(n >= 1, "query_group_fused_pm: n must be >= 1 when idx is non-empty");
+  dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
+  hipLaunchKernelGGL(query_group_fused_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample, use_xyz,
+                     normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out);
+  SIG3D_LAUNCH_CHECK("query_group_fused_pm_kernel");
   return 0;
 }
 

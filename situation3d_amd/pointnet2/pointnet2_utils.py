@@ -8,6 +8,7 @@ new_xyz needs a gradient; the result is bit-identical to the unfused composition
 for the differentiable-xyz case.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -140,6 +141,9 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+POINT_MAJOR_MIN_CHANNELS = int(os.environ.get("SIG3D_GROUP_PM_MIN_C", "32"))
+
+
 class _QueryGroupFused(Function):
     """One-kernel version of pointnet2_utils.py:348-359 (xyz / new_xyz treated as constants)."""
 
@@ -152,10 +156,20 @@ class _QueryGroupFused(Function):
         c_total = (3 if use_xyz else 0) + c
         out = torch.empty((b, c_total, m, nsample), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.call("sig3d_query_group_fused", b, n, m, c, nsample, int(use_xyz),
-                      int(normalize_xyz), ctypes.c_float(radius), _lib.ptr(xyz),
-                      _lib.ptr(new_xyz), _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out),
-                      _lib.stream_ptr(dev))
+            if c >= POINT_MAJOR_MIN_CHANNELS and c % 4 == 0:
+                # wide levels: one coalesced row per neighbour from a point-major copy of the features
+                # (8 MB at the bench shapes) instead of c strided 4-byte gathers
+                feat_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                _lib.call("sig3d_transpose_cn", b, c, n, _lib.ptr(features), _lib.ptr(feat_pm),
+                          _lib.stream_ptr(dev))
+                _lib.call("sig3d_query_group_fused_pm", b, n, m, c, c, nsample, int(use_xyz),
+                          int(normalize_xyz), ctypes.c_float(radius), _lib.ptr(xyz), _lib.ptr(new_xyz),
+                          _lib.ptr(feat_pm), _lib.ptr(idx), _lib.ptr(out), _lib.stream_ptr(dev))
+            else:
+                _lib.call("sig3d_query_group_fused", b, n, m, c, nsample, int(use_xyz),
+                          int(normalize_xyz), ctypes.c_float(radius), _lib.ptr(xyz),
+                          _lib.ptr(new_xyz), _lib.ptr(features), _lib.ptr(idx), _lib.ptr(out),
+                          _lib.stream_ptr(dev))
         ctx.save_for_backward(idx)
         ctx.dims = (b, n, m, c, nsample, c_total, 3 if use_xyz else 0)
         return out

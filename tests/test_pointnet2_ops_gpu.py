@@ -152,3 +152,30 @@ def test_reference_error_behaviour(hip_ext):
         hip_ext.gather_points(feats(1, 3, 16).to(DEV), torch.zeros(1, 4, dtype=torch.int64, device=DEV))
     with pytest.raises(RuntimeError, match="float tensor"):
         hip_ext.three_nn(xyz.double().to(DEV), xyz.to(DEV))
+
+
+@pytest.mark.parametrize("b,n,m,ns,c,use_xyz,norm", [(2, 2048, 1024, 32, 128, 1, 1), (2, 1024, 512, 16, 256, 1, 0),
+                                                     (1, 300, 37, 5, 36, 1, 1), (2, 512, 100, 16, 260, 0, 0),
+                                                     (1, 64, 3, 7, 4, 1, 1)])
+def test_query_group_fused_point_major_is_bit_identical(b, n, m, ns, c, use_xyz, norm):
+    """sig3d_query_group_fused_pm (+ sig3d_transpose_cn) against sig3d_query_group_fused: gathers and the
+    individually rounded centre subtraction / division are exact, so every bit must agree -- ragged tiles
+    (m*ns % 64 != 0), channel counts that are not multiples of 128, no-xyz mode."""
+    import ctypes
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(b * 1000 + n + c)
+    xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+    new_xyz = xyz[:, :m].contiguous()
+    feat = torch.randn(b, c, n, generator=g).to(DEV)
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+    ct = (3 if use_xyz else 0) + c
+    ref = torch.full((b, ct, m, ns), float("nan"), device=DEV)
+    out = torch.full((b, ct, m, ns), float("nan"), device=DEV)
+    L.call("sig3d_query_group_fused", b, n, m, c, ns, use_xyz, norm, ctypes.c_float(0.37), L.ptr(xyz), L.ptr(new_xyz),
+           L.ptr(feat), L.ptr(idx), L.ptr(ref), L.stream_ptr())
+    pm = torch.empty(b, n, c, device=DEV)
+    L.call("sig3d_transpose_cn", b, c, n, L.ptr(feat), L.ptr(pm), L.stream_ptr())
+    assert torch.equal(pm, feat.transpose(1, 2).contiguous())
+    L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, use_xyz, norm, ctypes.c_float(0.37), L.ptr(xyz),
+           L.ptr(new_xyz), L.ptr(pm), L.ptr(idx), L.ptr(out), L.stream_ptr())
+    assert not torch.isnan(ref).any() and torch.equal(out, ref)

@@ -23,6 +23,27 @@ for (n, m, ns, c) in bench.SA_LEVELS:
     t = timeit(lambda: L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, 1, ctypes.c_float(0.5), L.ptr(xyz),
                               L.ptr(new_xyz), L.ptr(feat), L.ptr(idx), L.ptr(out), L.stream_ptr()))
     byt = bench.group_algorithmic_bytes(b, n, m, ns, c)
+    extra = ""
+    if c % 4 == 0:
+        pm = torch.empty(b, n, c, device=dev)
+        tt = timeit(lambda: L.call("sig3d_transpose_cn", b, c, n, L.ptr(feat), L.ptr(pm), L.stream_ptr()))
+        out2 = torch.empty_like(out)
+        tp = timeit(lambda: L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, 1, 1, ctypes.c_float(0.5), L.ptr(xyz),
+                                   L.ptr(new_xyz), L.ptr(pm), L.ptr(idx), L.ptr(out2), L.stream_ptr()))
+        assert torch.equal(out, out2)
+        extra = "   point-major: %5.1f us %5.2f TB/s (+ transpose %4.1f us)" % (tp, byt / tp / 1e6, tt)
+        t = tp
     tot_t += t; tot_b += byt
-    print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB)" % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6))
+    print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB)%s" % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6, extra))
 print("total %.1f us, %.2f TB/s = %.3f of 8 TB/s" % (tot_t, tot_b / tot_t / 1e6, tot_b / tot_t / 8e6))
+
+# practical ceilings at the same output sizes: a pure streaming write (fill) and a copy
+print("streaming ceilings at the grouped-tensor sizes (torch fill_ / copy_):")
+for (n, m, ns, c) in bench.SA_LEVELS:
+    out = torch.empty(b, 3 + c, m, ns, device=dev)
+    src = torch.empty_like(out)
+    tf = timeit(lambda: out.fill_(1.0))
+    tc = timeit(lambda: out.copy_(src))
+    byt = out.numel() * 4
+    print("  %6.1f MB: fill %5.1f us = %.2f TB/s written; copy %5.1f us = %.2f TB/s moved (R+W)"
+          % (byt / 1e6, tf, byt / tf / 1e6, tc, 2 * byt / tc / 1e6))
