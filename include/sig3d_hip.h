@@ -153,6 +153,14 @@ int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, int nsample, 
                                const float *features_pm, const int *idx, float *out, void *stream);
 int sig3d_transpose_cn(int b, int c, int n, const float *in, float *out, void *stream);
 
+/* Backward of the feature half into a POINT-MAJOR gradient: grad_out (b,c_total,m,nsample), window
+ * [c_off, c_off+c) -> grad_features_pm (b,n,ld) (zeroed here); sig3d_transpose_cn(b, n, c, ...) turns it
+ * back into (b,c,n) when ld == c.  Float atomics: sums agree with sig3d_query_group_fused_grad up to
+ * rounding order. */
+int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                    int c_off, const float *grad_out, const int *idx,
+                                    float *grad_features_pm, void *stream);
+
 /* Backward of the feature half of sig3d_query_group_fused: grad_out (b,c_total,m,nsample)
  * with channel offset c_off -> grad_features (b,c,n) (zeroed here). */
 int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_total,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "sig3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused": [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused_pm": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
+    "sig3d_query_group_fused_grad_pm": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_transpose_cn": [_I, _I, _I, _P, _P, _P],
     "sig3d_query_group_fused_grad": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -316,6 +316,80 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
   }
 }
 
+// ---- point-major scatter-add (backward of the fused grouping, wide levels) --------------------------
+// grad_out (b,c_total,m,ns) is read in 256-byte runs per channel, turned through the same swizzled LDS
+// tile, and every grouped element then adds ONE contiguous row of the point-major gradient (b,n,ld).
+// A half-wave walks 8 consecutive elements and merges runs of equal indices in registers first: ball
+// query pads a short neighbour list with its first hit, so most of a list is one repeated index.
+__global__ __launch_bounds__(GP_THREADS) void group_points_grad_pm_kernel(
+    int n, int c, int ld, int total, int c_total, int c_off, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_pm) {
+  __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
+  const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e0 = blockIdx.x * GPM_P;
+  {
+    const int p = lane, e = e0 + p;
+    const bool ok = e < total;
+    const float *g = grad_out + ((size_t)bi * c_total + c_off) * total + (ok ? e : total - 1);
+    float v[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cc = c0 + 4 * (wave * 8 + q) + k;
+        v[q][k] = g[(size_t)(cc < c ? cc : c - 1) * total];
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cc = c0 + 4 * (wave * 8 + q);
+      gp_f32x4 t = {(ok && cc + 0 < c) ? v[q][0] : 0.f, (ok && cc + 1 < c) ? v[q][1] : 0.f,
+                    (ok && cc + 2 < c) ? v[q][2] : 0.f, (ok && cc + 3 < c) ? v[q][3] : 0.f};
+      s_tile[p * (GPM_C / 4) + ((wave * 8 + q) ^ (p & 7))] = t;
+    }
+  }
+  __syncthreads();
+  const int hw = wave * 2 + (lane >> 5), j = lane & 31;
+  const int *ip = idx + (size_t)bi * total;
+  int a[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int e = e0 + hw * 8 + t;
+    a[t] = e < total ? ip[e] : -1;
+  }
+  const float *sf = reinterpret_cast<const float *>(s_tile);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = -1;
+  auto flush = [&]() {
+    if (cur < 0) return;
+    float *dst = grad_pm + ((size_t)bi * n + cur) * ld + c0 + j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c0 + j + 32 * k < c) unsafeAtomicAdd(dst + 32 * k, acc[k]);
+  };
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int p = hw * 8 + t;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // lane j holds channels j, j+32, j+64, j+96: 128-byte atomics runs
+      const int cc = j + 32 * k;
+      v[k] = sf[(p * (GPM_C / 4) + ((cc >> 2) ^ (p & 7))) * 4 + (cc & 3)];
+    }
+    if (a[t] != cur) {
+      flush();
+      cur = a[t];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += v[k];
+    }
+  }
+  flush();
+}
+
 }  // namespace
 
 extern "C" int sig3d_group_points(int b, int c, int n, int npoints, int nsample,
@@ -450,6 +524,24 @@ extern "C" int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, in
   hipLaunchKernelGGL(query_group_fused_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample, use_xyz,
                      normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out);
   SIG3D_LAUNCH_CHECK("query_group_fused_pm_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                               int c_off, const float *grad_out, const int *idx,
+                                               float *grad_features_pm, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 0 && nsample >= 0 && ld >= c, "bad size");
+  SIG3D_REQUIRE(c_off >= 0 && c_off + c <= c_total, "channel window out of range");
+  const long total = (long)m * nsample;
+  SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
+  if (b == 0 || n == 0) return 0;
+  SIG3D_HIP_TRY(hipMemsetAsync(grad_features_pm, 0, sizeof(float) * (size_t)b * n * ld, stream));
+  if (total == 0) return 0;
+  dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
+  hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, c, ld, (int)total, c_total,
+                     c_off, grad_out, idx, grad_features_pm);
+  SIG3D_LAUNCH_CHECK("group_points_grad_pm_kernel");
   return 0;
 }
 

@@ -179,3 +179,35 @@ def test_query_group_fused_point_major_is_bit_identical(b, n, m, ns, c, use_xyz,
     L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, use_xyz, norm, ctypes.c_float(0.37), L.ptr(xyz),
            L.ptr(new_xyz), L.ptr(pm), L.ptr(idx), L.ptr(out), L.stream_ptr())
     assert not torch.isnan(ref).any() and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("b,n,m,ns,c,c_off", [(2, 2048, 1024, 32, 128, 3), (2, 1024, 512, 16, 256, 3),
+                                              (1, 300, 37, 5, 36, 0), (2, 512, 100, 16, 260, 3), (1, 64, 3, 7, 4, 3)])
+@pytest.mark.parametrize("padded", [False, True])
+def test_query_group_fused_grad_point_major_vs_channel_major(b, n, m, ns, c, c_off, padded):
+    """Scatter-add into the point-major gradient (+ transpose back) against the channel-major kernel and
+    against an exact float64 index_add; float atomics: 1e-5 relative to the largest magnitude.  `padded`
+    lists repeat their first index like ball query's padding (the run-merging path)."""
+    import ctypes
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(b * 1000 + n + c + int(padded))
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32)
+    if padded:
+        keep = torch.randint(1, ns + 1, (b, m, 1), generator=g)
+        idx = torch.where(torch.arange(ns).view(1, 1, ns) < keep, idx, idx[:, :, :1])
+    idx = idx.to(DEV)
+    ct = c_off + c
+    go = torch.randn(b, ct, m, ns, generator=g).to(DEV)
+    ref = torch.empty(b, c, n, device=DEV)
+    L.call("sig3d_query_group_fused_grad", b, n, m, c, ns, ct, c_off, L.ptr(go), L.ptr(idx), L.ptr(ref), L.stream_ptr())
+    pm = torch.full((b, n, c), float("nan"), device=DEV)
+    L.call("sig3d_query_group_fused_grad_pm", b, n, m, c, c, ns, ct, c_off, L.ptr(go), L.ptr(idx), L.ptr(pm),
+           L.stream_ptr())
+    back = torch.empty(b, c, n, device=DEV)
+    L.call("sig3d_transpose_cn", b, n, c, L.ptr(pm), L.ptr(back), L.stream_ptr())
+    exact = torch.zeros(b, c, n, dtype=torch.float64, device=DEV)
+    exact.scatter_add_(2, idx.long().view(b, 1, m * ns).expand(b, c, m * ns),
+                       go[:, c_off:].reshape(b, c, m * ns).double())
+    scale = exact.abs().max().item()
+    assert (back.double() - exact).abs().max().item() <= 1e-5 * scale
+    assert (ref.double() - exact).abs().max().item() <= 1e-5 * scale

@@ -37,6 +37,21 @@ for (n, m, ns, c) in bench.SA_LEVELS:
     print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB)%s" % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6, extra))
 print("total %.1f us, %.2f TB/s = %.3f of 8 TB/s" % (tot_t, tot_b / tot_t / 1e6, tot_b / tot_t / 8e6))
 
+# backward: channel-major LDS scatter-add vs the point-major kernel, with ball-query-like padded lists
+print("backward (scatter-add), lists padded with their first index like ball query:")
+for (n, m, ns, c) in bench.SA_LEVELS[1:]:
+    g = torch.Generator().manual_seed(n)
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32)
+    keep = torch.randint(1, max(2, ns // 4), (b, m, 1), generator=g)
+    idx = torch.where(torch.arange(ns).view(1, 1, ns) < keep, idx, idx[:, :, :1]).to(dev)
+    go = torch.randn(b, 3 + c, m, ns, device=dev)
+    ref = torch.empty(b, c, n, device=dev); pm = torch.empty(b, n, c, device=dev); back = torch.empty(b, c, n, device=dev)
+    t0 = timeit(lambda: L.call("sig3d_query_group_fused_grad", b, n, m, c, ns, 3 + c, 3, L.ptr(go), L.ptr(idx), L.ptr(ref), L.stream_ptr()))
+    t1 = timeit(lambda: L.call("sig3d_query_group_fused_grad_pm", b, n, m, c, c, ns, 3 + c, 3, L.ptr(go), L.ptr(idx), L.ptr(pm), L.stream_ptr()))
+    t2 = timeit(lambda: L.call("sig3d_transpose_cn", b, n, c, L.ptr(pm), L.ptr(back), L.stream_ptr()))
+    print("  N=%5d M=%4d ns=%2d C=%3d: channel-major %6.1f us, point-major %6.1f us + transpose %4.1f us  (max diff %.2e)"
+          % (n, m, ns, c, t0, t1, t2, (ref - back).abs().max().item()))
+
 # practical ceilings at the same output sizes: a pure streaming write (fill) and a copy
 print("streaming ceilings at the grouped-tensor sizes (torch fill_ / copy_):")
 for (n, m, ns, c) in bench.SA_LEVELS:
