@@ -484,13 +484,9 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
   const bool vec = (nsample % 4 == 0);
   dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS),
             (use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB), b);
-  // streaming (nontemporal) stores of the grouped tensor: +4 % on this kernel inside the bench, step unchanged
-  static const bool nt = !(getenv("SIG3D_GROUP_NT") && getenv("SIG3D_GROUP_NT")[0] == '0');
-  if (vec && nt)
+  // the vector path streams the grouped tensor out with nontemporal stores (+4 % on this kernel)
+  if (vec)
     hipLaunchKernelGGL((query_group_fused_kernel<true, true>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
-                       nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
-  else if (vec)
-    hipLaunchKernelGGL((query_group_fused_kernel<true, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   else
     hipLaunchKernelGGL((query_group_fused_kernel<false, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,

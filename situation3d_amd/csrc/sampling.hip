@@ -344,31 +344,21 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
   if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream);
   if (n <= 8192) return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream);
-  static const bool old_split = getenv("SIG3D_FPS_OLD_SPLIT") != nullptr;  // tools/fps_bench.py A/B
-  if (old_split) {
-    if (n <= 16384) return launch_fps<1024, 16>(b, n, m, L, dataset, temp, idxs, stream);
-    if (n <= 24576) return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);
-  }
   if (n <= 196608) {
     // cooperative kernel; at most 64 co-resident workgroups per launch (so that several
     // concurrent launches -- other streams, other processes -- can never starve each other)
     // 8 workgroups of 512 threads per scene: measured 1.76 us/round at n = 40 000 against 2.18 for
     // 4 x 1024 (half the points per SIMD between two exchanges, 8-wave barriers) and 2.07 for
     // 16 x 512 (more peers to wait for per hop); 8 scenes = 64 workgroups per launch
-    const int W = (old_split && n <= 98304) ? 4 : 8;
-    const int chunk = 64 / W;
+    // (4 x 1024: 2.18 us/round, 2 x 1024: 2.97 -- tools/fps_bench.py)
+    const int chunk = 8;
     for (int s0 = 0; s0 < b; s0 += chunk) {
       const int bc = (b - s0) < chunk ? (b - s0) : chunk;
       const float *ds = dataset + (size_t)s0 * n * 3;
       float *tp = temp + (size_t)s0 * n;
       int *ix = idxs + (size_t)s0 * m;
       int rc;
-      if (old_split) {
-        if (n <= 40960) rc = launch_fps_coop<1024, 10, 4>(bc, n, m, L, ds, tp, ix, stream);
-        else if (n <= 65536) rc = launch_fps_coop<1024, 16, 4>(bc, n, m, L, ds, tp, ix, stream);
-        else if (n <= 98304) rc = launch_fps_coop<1024, 24, 4>(bc, n, m, L, ds, tp, ix, stream);
-        else rc = launch_fps_coop<1024, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
-      } else if (n <= 16384) rc = launch_fps_coop<512, 4, 8>(bc, n, m, L, ds, tp, ix, stream);
+      if (n <= 16384) rc = launch_fps_coop<512, 4, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 24576) rc = launch_fps_coop<512, 6, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 40960) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);

@@ -148,11 +148,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < ML_KC; ++i) {
       const int k = (c * ML_KC + i) * 2 + half;
-#ifdef ML_EXP_NO_LOAD
-      buf[i] = __builtin_bit_cast(float, (unsigned)k * 0x9E3779B9u + eo) * 1e-30f;
-#else
       buf[i] = xb[(unsigned)min(k, cin - 1) * (unsigned)E + eo];
-#endif
     }
   };
   auto consume = [&](const float (&buf)[ML_KC], int g) {
@@ -210,12 +206,8 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const float v0 = acc[nt][4 * g4], v1 = acc[nt][4 * g4 + 1], v2 = acc[nt][4 * g4 + 2], v3 = acc[nt][4 * g4 + 3];
           if (VEC && full) {
-#ifndef ML_EXP_NO_STATS
             s1[nt] += (v0 + v1) + (v2 + v3);
             s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
-#else
-            s1[nt] += v0;
-#endif
           } else {
             const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
@@ -229,11 +221,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
         }
       }
     }
-#ifdef ML_EXP_NO_TRANSPOSE
-    if (false) {
-#else
     if (VEC && full) {
-#endif
       // Stores through a wave-private LDS transpose.  In the accumulator layout a lane owns ONE
       // channel row, so a direct store instruction scatters 64 separate 16-byte pieces over 64
       // rows and every 128-byte line of y is assembled from 8 partial writes (2.9 TB/s at SA1
@@ -260,11 +248,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
             const int row = trow + 8 * j;
             const int co = co0 + nt * 32 + hrow * 16 + row;
             const float4 v = *reinterpret_cast<const float4 *>(s_tr + row * ML_TRLD + tcol);
-#ifdef ML_EXP_NO_STORE
-            if (co < cout && v.x == 123.456f) *reinterpret_cast<float4 *>(yb + ((unsigned)co * (unsigned)E + (unsigned)e0 + tcol)) = v;
-#else
             if (co < cout) *reinterpret_cast<float4 *>(yb + ((unsigned)co * (unsigned)E + (unsigned)e0 + tcol)) = v;
-#endif
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();

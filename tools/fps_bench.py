@@ -1,5 +1,5 @@
-"""FPS at the SA1 shape (B=8 x 40000 -> 2048) and the small levels; SIG3D_FPS_VARIANT picks experimental
-(threads, points/thread, workgroups/scene) splits of the cooperative kernel."""
+"""Furthest point sampling time per round over scene sizes (B=8 x 40000 -> 2048 is the SA1 shape): the
+single-workgroup register-resident kernel (n <= 8192) and the cooperative 8 x 512 kernel above it."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
