@@ -14,13 +14,21 @@ def timeit(fn, iters=20, warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 b = 8
+from situation3d_amd.pointnet2 import _ext
+pc = bench.synthetic_batch(b, bench.N_POINTS, 7, dev)["point_clouds"]
+cur_xyz = pc[..., :3].contiguous()
+RADII = [0.2, 0.4, 0.8, 1.2]
 tot_t = tot_b = 0
-for (n, m, ns, c) in bench.SA_LEVELS:
-    xyz = torch.rand(b, n, 3, device=dev); new_xyz = xyz[:, :m].contiguous()
+print("real geometry (FPS centres, ball-query lists) of the bench scenes; random feature values")
+for (n, m, ns, c), radius in zip(bench.SA_LEVELS, RADII):
+    xyz = cur_xyz
+    inds = _ext.furthest_point_sampling(xyz, m)
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = _ext.ball_query(new_xyz, xyz, radius, ns)
+    cur_xyz = new_xyz
     feat = torch.randn(b, c, n, device=dev)
-    idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev)
     out = torch.empty(b, 3 + c, m, ns, device=dev)
-    t = timeit(lambda: L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, 1, ctypes.c_float(0.5), L.ptr(xyz),
+    t = timeit(lambda: L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, 1, ctypes.c_float(radius), L.ptr(xyz),
                               L.ptr(new_xyz), L.ptr(feat), L.ptr(idx), L.ptr(out), L.stream_ptr()))
     byt = bench.group_algorithmic_bytes(b, n, m, ns, c)
     extra = ""
@@ -28,13 +36,15 @@ for (n, m, ns, c) in bench.SA_LEVELS:
         pm = torch.empty(b, n, c, device=dev)
         tt = timeit(lambda: L.call("sig3d_transpose_cn", b, c, n, L.ptr(feat), L.ptr(pm), L.stream_ptr()))
         out2 = torch.empty_like(out)
-        tp = timeit(lambda: L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, 1, 1, ctypes.c_float(0.5), L.ptr(xyz),
+        tp = timeit(lambda: L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, 1, 1, ctypes.c_float(radius), L.ptr(xyz),
                                    L.ptr(new_xyz), L.ptr(pm), L.ptr(idx), L.ptr(out2), L.stream_ptr()))
         assert torch.equal(out, out2)
-        extra = "   point-major: %5.1f us %5.2f TB/s (+ transpose %4.1f us)" % (tp, byt / tp / 1e6, tt)
+        extra = "   channel-major kernel %5.1f us; + transpose %4.1f us" % (t, tt)
         t = tp
+    tf = timeit(lambda: out.fill_(1.0))
     tot_t += t; tot_b += byt
-    print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB)%s" % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6, extra))
+    print("N=%5d M=%4d ns=%2d C=%3d: %6.1f us  %5.2f TB/s (%.1f MB; fill_ of the output alone: %4.1f us)%s"
+          % (n, m, ns, c, t, byt / t / 1e6, byt / 1e6, tf, extra))
 print("total %.1f us, %.2f TB/s = %.3f of 8 TB/s" % (tot_t, tot_b / tot_t / 1e6, tot_b / tot_t / 8e6))
 
 # backward: channel-major LDS scatter-add vs the point-major kernel, with ball-query-like padded lists
