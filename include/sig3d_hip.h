@@ -317,7 +317,9 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  * q (b,nq,h*d), k (b,nk,h*d), v (b,nk,h*d) contiguous and TOKEN-MAJOR, i.e. exactly what the
  * query/key/value nn.Linear layers produce (Qformer.py:164-176) -- the transpose_for_scores
  * permute (:140-147) is folded into the kernel's addressing; mask additive (b,nk) or NULL
- * (the reference's (B,1,1,Nk) extended mask, Qformer.py:700-732); d must be 64.
+ * (the reference's (B,1,1,Nk) extended mask, Qformer.py:700-732); d is 64 (Q-Former, 768/12) or 96
+ * (the MCAN blocks of the native SIG3D head, mcan_sqa_module.py:113-126: 768/8).  The backward pass runs
+ * in chunks of 128 (d = 64) / 64 (d = 96) query rows, dK / dV then meet through float atomics.
  * out (b,nq,h*d) -- already in the permuted "context_layer" layout of Qformer.py:225-227.
  * lse (b,h,nq) receives log-sum-exp rows for the backward pass (may be NULL).
  * ldq / ldk / ldv: row strides in floats of q, k, v (h*d for dense tensors; 3*h*d when q, k, v are
@@ -343,7 +345,7 @@ int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
                         int key_splits, float *workspace, void *stream);
 /* key_splits > 1 (few queries, many keys -- the 3D-LLM shapes of 5000..80000 scene tokens): the key
  * range is cut into key_splits pieces so that the launch covers the chip, and a second kernel folds
- * the pieces; workspace = b*h*roundup32(nq)*key_splits*66 floats.  key_splits <= 1: one pass, workspace
+ * the pieces; workspace = b*h*roundup32(nq)*key_splits*(d+2) floats.  key_splits <= 1: one pass, workspace
  * may be NULL. */
 /* p_drop > 0: attention-probability dropout (Qformer.py:219).  The keep bit of element
  * (b, head, query, key) is hash(*rng_counter, call_id, index), identical in forward and backward;

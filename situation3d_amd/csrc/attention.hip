@@ -24,9 +24,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int AT_D = 64;       // head size (Qformer.py:112: 768 / 12)
+// head size D is a template parameter: 64 (Qformer.py:112: 768 / 12) and 96 (the MCAN blocks of the
+// native SIG3D head, mcan_sqa_module.py:113-126: 768 / 8).  A lane owns half a row (D/2 features), the
+// D features of the PV / dK / dV / dQ products are D/32 MFMA blocks of 32.
 constexpr int AT_WAVES = 4;    // waves per workgroup, each streams every 4th key tile
-constexpr int AT_NQ_MAX = 128; // backward keeps per-row statistics / dQ of one head in LDS
+constexpr int AT_NQ_MAX = 128; // backward keeps per-row statistics / dQ of one query chunk in LDS
 
 // Phase timing for tools/attn_timing.py (compiled in only with -DSIG3D_ATTN_TIMING): workgroup
 // (0,0,0), lane 0 of the wave that passes a mark stores the 100 MHz real-time counter.
@@ -47,19 +49,20 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// lane (row = l31, half) <- 32 contiguous floats base[row*stride + half*32 ...]; zero when !valid
-__device__ __forceinline__ void load_half_row(float (&f)[32], const float *base, unsigned row,
+// lane (row = l31, half) <- DH = D/2 contiguous floats base[row*stride + half*DH ...]; zero when !valid
+template <int DH>
+__device__ __forceinline__ void load_half_row(float (&f)[DH], const float *base, unsigned row,
                                               unsigned stride, int half, bool valid) {
   if (valid) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + row * stride + half * 32);
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * stride + half * DH);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < DH / 4; ++i) {
       const float4 t = p[i];
       f[4 * i + 0] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 32; ++i) f[i] = 0.f;
+    for (int i = 0; i < DH; ++i) f[i] = 0.f;
   }
 }
 
@@ -79,9 +82,10 @@ __device__ __forceinline__ unsigned tok_row(int i, int bi, int n, int seg, int b
 }
 
 // Storage rows that hold no token -- the gap between the segments and the tail up to `rows` -- get
-// zeros in columns [hi*64, hi*64+64) of an output tensor (row stride ld): padded layouts (qformer.py
+// zeros in columns [hi*D, hi*D+D) of an output tensor (row stride ld): padded layouts (qformer.py
 // pads both segments to a common row count so that per-segment GEMMs batch) must never leak
 // uninitialised memory into the row-wise kernels and weight-gradient GEMMs that follow.
+template <int D>
 __device__ __forceinline__ void zero_pad_rows(float *base, unsigned ld, int hi, int nb, int n, int seg,
                                               int base2, int rows) {
   if (rows <= 0) return;
@@ -89,10 +93,12 @@ __device__ __forceinline__ void zero_pad_rows(float *base, unsigned ld, int hi, 
   const int end1 = two ? nb * seg : nb * n;
   const int start2 = two ? base2 : end1, end2 = two ? base2 + nb * (n - seg) : end1;
   const int npad = (start2 - end1) + max(rows - end2, 0);
-  for (int i = threadIdx.x; i < npad * 16; i += blockDim.x) {
-    int r = i >> 4;
+  constexpr int PER = D / 4;  // float4 pieces per row
+  for (int i = threadIdx.x; i < npad * PER; i += blockDim.x) {
+    int r = i / PER;
+    const int c4 = i - r * PER;
     r = r < start2 - end1 ? end1 + r : end2 + (r - (start2 - end1));
-    *reinterpret_cast<float4 *>(base + (unsigned)r * ld + hi * AT_D + (i & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4 *>(base + (unsigned)r * ld + hi * D + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -131,13 +137,15 @@ __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base,
 
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
+template <int D>
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int ldq, int ldk,
     int ldv, float scale, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
     const float *__restrict__ k, const float *__restrict__ v, const float *__restrict__ mask,
     float *__restrict__ out, float *__restrict__ lse, int key_splits, float *__restrict__ part) {
-  __shared__ float s_o[AT_WAVES][AT_D][32];
+  constexpr int DH = D / 2, NB = D / 32;
+  __shared__ float s_o[AT_WAVES][D][32];
   __shared__ float s_m[AT_WAVES][32];
   __shared__ float s_l[AT_WAVES][32];
 
@@ -148,24 +156,28 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   // pieces leave (max, sum, un-normalised O) partials that attention_combine_kernel folds.
   const int q0 = (blockIdx.x / key_splits) * 32, split = blockIdx.x % key_splits;
   const int hi = blockIdx.y, bi = blockIdx.z;
-  if (blockIdx.x == 0 && bi == 0) zero_pad_rows(out, (unsigned)(h * AT_D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
-  // token-major operands: storage row r of head hi starts at base + r*ld + hi*64, where ld is the
-  // row stride in floats (h*64 for a dense (b, n, h*d) tensor, 3*h*64 for a slice of a fused QKV
+  if (blockIdx.x == 0 && bi == 0) zero_pad_rows<D>(out, (unsigned)(h * D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
+  // token-major operands: storage row r of head hi starts at base + r*ld + hi*D, where ld is the
+  // row stride in floats (h*D for a dense (b, n, h*d) tensor, 3*h*D for a slice of a fused QKV
   // projection output) and r = tok_row(token, batch)
-  const float *Q = q + hi * AT_D;
-  const float *K = k + hi * AT_D;
-  const float *V = v + hi * AT_D;
+  const float *Q = q + hi * D;
+  const float *K = k + hi * D;
+  const float *V = v + hi * D;
   // no mask: the (unconditional) mask loads read any valid address -- the K base -- and are dropped
   const float *Mz = mask ? mask + (size_t)bi * nk : k;
   const bool has_mask = mask != nullptr;
 
-  float qf[32];
-  load_half_row(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, q_base2), ldq, half, q0 + l31 < nq);
+  float qf[DH];
+  load_half_row<DH>(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, q_base2), ldq, half, q0 + l31 < nq);
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
 
   float m_run = -INFINITY, l_run = 0.f;
-  f32x16 o0 = {0}, o1 = {0};
+  f32x16 o[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
   const int ntiles = (nk + 31) / 32;
   const int tps = (ntiles + key_splits - 1) / key_splits;
   const int t_begin = split * tps, t_end = min(ntiles, t_begin + tps);
@@ -175,26 +187,26 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     // values and the 32 V^T operands of the PV product -- and the scheduler is fenced so that it
     // cannot sink the loads down to their uses again (it did: 8 + 16 + 16 dependent round trips
     // per tile, the whole kernel was load latency)
-    float kf[32], mk[16], va0[16], va1[16];
-    load_half_row(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, k_base2), ldk, half, true);
+    float kf[DH], mk[16], va[NB][16];
+    load_half_row<DH>(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, k_base2), ldk, half, true);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = min(key0 + mfma_row(r, half), nk - 1);
       mk[r] = Mz[key];
       const unsigned voff = tok_row(key, bi, nk, k_seg, k_base2) * (unsigned)ldv + l31;
-      va0[r] = V[voff];
-      va1[r] = V[voff + 32];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) va[j][r] = V[voff + 32 * j];
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 st = {0};
 #pragma unroll
-    for (int s = 0; s < 32; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
+    for (int s = 0; s < DH; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
     float p[16];
     float tmax = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + mfma_row(r, half);
-      float sv = st[r] * scale;                     // Qformer.py:207 (/ sqrt(64) == * 0.125)
+      float sv = st[r] * scale;                     // Qformer.py:207 (/ sqrt(d))
       sv += has_mask ? mk[r] : 0.f;                 // Qformer.py:210
       sv = key < nk ? sv : -INFINITY;
       p[r] = sv;
@@ -215,30 +227,29 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] *= alpha;
-      o1[r] *= alpha;
-    }
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
-      o0 = mfma32(va0[s], p[s], o0);
-      o1 = mfma32(va1[s], p[s], o1);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) o[j] = mfma32(va[j][s], p[s], o[j]);
     }
   }
 
   // combine the AT_WAVES partial (m, l, O^T) triples
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    s_o[wave][mfma_row(r, half)][l31] = o0[r];
-    s_o[wave][32 + mfma_row(r, half)][l31] = o1[r];
-  }
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_o[wave][32 * j + mfma_row(r, half)][l31] = o[j][r];
   if (half == 0) {
     s_m[wave][l31] = m_run;
     s_l[wave][l31] = l_run;
   }
   __syncthreads();
   {
-    const int qq = threadIdx.x & 31, dg = threadIdx.x >> 5;  // 8 d-groups of 8 features
+    constexpr int FG = D / 8;                                // features per thread
+    const int qq = threadIdx.x & 31, dg = threadIdx.x >> 5;  // 8 d-groups of FG features
     float mt = -INFINITY;
 #pragma unroll
     for (int w = 0; w < AT_WAVES; ++w) mt = fmaxf(mt, s_m[w][qq]);
@@ -249,41 +260,43 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
       lt += s_l[w][qq] * wgt[w];
     }
     if (key_splits > 1) {
-      // partial of this key split: part[row][split] = {m, l, O[64] relative to m}, row = (b*h + head)*nq_pad + q
+      // partial of this key split: part[row][split] = {m, l, O[D] relative to m}, row = (b*h + head)*nq_pad + q
       if (q0 + qq < nq) {
         const int nq_pad = (nq + 31) / 32 * 32;
-        float *pp = part + (((size_t)(bi * h + hi) * nq_pad + q0 + qq) * key_splits + split) * (AT_D + 2);
+        float *pp = part + (((size_t)(bi * h + hi) * nq_pad + q0 + qq) * key_splits + split) * (D + 2);
         if (dg == 0) { pp[0] = mt; pp[1] = lt; }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < FG; ++i) {
           float acc = 0.f;
 #pragma unroll
-          for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * 8 + i][qq] * wgt[w];
-          pp[2 + dg * 8 + i] = acc;
+          for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * FG + i][qq] * wgt[w];
+          pp[2 + dg * FG + i] = acc;
         }
       }
       return;
     }
     const float inv = 1.f / lt;
     if (q0 + qq < nq) {
-      float res[8];
+      float res[FG];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < FG; ++i) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * 8 + i][qq] * wgt[w];
+        for (int w = 0; w < AT_WAVES; ++w) acc += s_o[w][dg * FG + i][qq] * wgt[w];
         res[i] = acc * inv;
       }
       // context_layer.permute(0,2,1,3).view(B, Nq, 768)  (Qformer.py:225-227)
-      float *o = out + tok_row(q0 + qq, bi, nq, q_seg, q_base2) * (unsigned)(h * AT_D) + hi * AT_D + dg * 8;
-      *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
-      *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
+      float *op = out + tok_row(q0 + qq, bi, nq, q_seg, q_base2) * (unsigned)(h * D) + hi * D + dg * FG;
+#pragma unroll
+      for (int i = 0; i < FG; i += 4)
+        *reinterpret_cast<float4 *>(op + i) = make_float4(res[i], res[i + 1], res[i + 2], res[i + 3]);
       if (lse && dg == 0) lse[(size_t)(bi * h + hi) * nq + q0 + qq] = mt + __logf(lt);
     }
   }
 }
 
 // fold the key-split partials of one (batch, head, query) row: one wave per row, lane = feature
+template <int D>
 __global__ __launch_bounds__(256) void attention_combine_kernel(int h, int nq, int q_seg, int q_base2,
                                                                 int key_splits, int nb,
                                                                 const float *__restrict__ part,
@@ -294,31 +307,42 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(int h, int nq, i
   if (row >= (long)nb * h * nq) return;
   const int qq = (int)(row % nq), bh = (int)(row / nq), hi = bh % h, bi = bh / h;
   const int nq_pad = (nq + 31) / 32 * 32;
-  const float *pp = part + ((size_t)bh * nq_pad + qq) * key_splits * (AT_D + 2);
+  const float *pp = part + ((size_t)bh * nq_pad + qq) * key_splits * (D + 2);
   float mt = -INFINITY;
-  for (int s2 = 0; s2 < key_splits; ++s2) mt = fmaxf(mt, pp[(size_t)s2 * (AT_D + 2)]);
-  float lt = 0.f, acc = 0.f;
+  for (int s2 = 0; s2 < key_splits; ++s2) mt = fmaxf(mt, pp[(size_t)s2 * (D + 2)]);
+  constexpr int FL = (D + 63) / 64;  // features per lane: lane, lane + 64
+  float lt = 0.f, acc[FL];
+#pragma unroll
+  for (int f = 0; f < FL; ++f) acc[f] = 0.f;
   for (int s2 = 0; s2 < key_splits; ++s2) {
-    const float *ps = pp + (size_t)s2 * (AT_D + 2);
+    const float *ps = pp + (size_t)s2 * (D + 2);
     const float wgt = __expf(ps[0] - mt);   // splits without keys: exp(-inf) = 0
     lt += ps[1] * wgt;
-    acc += ps[2 + lane] * wgt;
+#pragma unroll
+    for (int f = 0; f < FL; ++f) acc[f] += ps[2 + min(lane + 64 * f, D - 1)] * wgt;
   }
-  out[tok_row(qq, bi, nq, q_seg, q_base2) * (unsigned)(h * AT_D) + hi * AT_D + lane] = acc / lt;
+#pragma unroll
+  for (int f = 0; f < FL; ++f)
+    if (lane + 64 * f < D)
+      out[tok_row(qq, bi, nq, q_seg, q_base2) * (unsigned)(h * D) + hi * D + lane + 64 * f] = acc[f] / lt;
   if (lse && lane == 0) lse[row] = mt + __logf(lt);
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: grid (key_splits, h, b), 256 threads.  Work items are (32-key tile, 32-query tile)
+// backward: grid (key_splits * query_chunks, h, b), 256 threads.  A workgroup owns one chunk of at most
+// `qchunk` query rows (their statistics and dQ images live in LDS) and one range of key tiles; with more
+// than one chunk dK / dV are accumulated with atomics.  Work items are (32-key tile, 32-query tile)
 // pairs.  With >= 4 key tiles per workgroup a wave owns whole key tiles (dK / dV are plain stores
 // from its accumulators); with fewer (self-attention: 52 keys = 2 tiles) the query tiles of a key
 // tile are spread over the otherwise idle waves and their dK / dV partials meet in LDS.
 // dQ: every wave accumulates into its OWN LDS image (plain read-modify-write around the dQ MFMAs,
 // no zero fill: first visit starts from 0) and the images are summed once at the end --
 // ds_add_f32 from four waves onto one image cost 9 us of a 27 us launch (tools/attn_timing.py).
+template <int D>
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int k_rows,
-    int ldq, int ldk, int ldv, float scale, int tiles_per_split, int atomic_dq, int qsplit_max, float p_drop,
+    int ldq, int ldk, int ldv, float scale, int tiles_per_split, int nsplits, int qchunk, int atomic_dq,
+    int atomic_dkv, int qsplit_max, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter,
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
@@ -327,51 +351,53 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   __shared__ float s_D[AT_NQ_MAX];
   __shared__ float s_lse[AT_NQ_MAX];
   __shared__ float s_T[AT_WAVES][32][33];
-  // dynamic: dQ images [AT_WAVES][nq_pad][AT_D + 1], then (qsplit_max == 2 only) the dK/dV
-  // partials of the q-split mode [2 key slots][64 regs][64 lanes]
+  constexpr int DH = D / 2, NB = D / 32;
+  // dynamic: dQ images [AT_WAVES][qchunk][D + 1] (rows local to the chunk), then (qsplit_max == 2 only)
+  // the dK/dV partials of the q-split mode [2 key slots][2*NB*16 regs][64 lanes]
   extern __shared__ __attribute__((aligned(16))) float s_dq[];
-  const int nq_pad = (nq + 31) / 32 * 32;
-  auto dq_img = [&](int w, int qq, int d) -> float & { return s_dq[((size_t)w * nq_pad + qq) * (AT_D + 1) + d]; };
-  float *s_red = s_dq + (size_t)AT_WAVES * nq_pad * (AT_D + 1);
-  auto red = [&](int sl, int r, int ln) -> float & { return s_red[(sl * 64 + r) * 64 + ln]; };
+  auto dq_img = [&](int w, int ql, int d) -> float & { return s_dq[((size_t)w * qchunk + ql) * (D + 1) + d]; };
+  float *s_red = s_dq + (size_t)AT_WAVES * qchunk * (D + 1);
+  auto red = [&](int sl, int r, int ln) -> float & { return s_red[(sl * (2 * NB * 16) + r) * 64 + ln]; };
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int hi = blockIdx.y, bi = blockIdx.z;
+  const int ksplit = blockIdx.x % nsplits, chunk = blockIdx.x / nsplits;
+  const int qc0 = chunk * qchunk, q_end = min(nq, qc0 + qchunk), nql = q_end - qc0;  // this chunk's queries
   if (blockIdx.x == 0 && bi == 0) {
-    zero_pad_rows(dq, (unsigned)ldq, hi, gridDim.z, nq, q_seg, q_base2, q_rows);
-    zero_pad_rows(dk, (unsigned)ldk, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
-    zero_pad_rows(dv, (unsigned)ldv, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+    zero_pad_rows<D>(dq, (unsigned)ldq, hi, gridDim.z, nq, q_seg, q_base2, q_rows);
+    zero_pad_rows<D>(dk, (unsigned)ldk, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+    zero_pad_rows<D>(dv, (unsigned)ldv, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
   }
   const size_t bh = (size_t)(bi * h + hi);
-  const unsigned ostride = (unsigned)h * AT_D;  // out / grad_out are dense rows of h*d floats
-  const float *Q = q + hi * AT_D;       // storage row r at Q + r*ldq, r = tok_row(token, batch)
-  const float *K = k + hi * AT_D;
-  const float *V = v + hi * AT_D;
+  const unsigned ostride = (unsigned)h * D;  // out / grad_out are dense rows of h*d floats
+  const float *Q = q + hi * D;          // storage row r at Q + r*ldq, r = tok_row(token, batch)
+  const float *K = k + hi * D;
+  const float *V = v + hi * D;
   const float *M = mask ? mask + (size_t)bi * nk : nullptr;
-  const float *O = out + hi * AT_D;
-  const float *dO = grad_out + hi * AT_D;
+  const float *O = out + hi * D;
+  const float *dO = grad_out + hi * D;
   auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, q_base2); };
   auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, k_base2); };
 
   AT_MARK(1, 0);
-  // D[q] = sum_d dO[q][d] * O[q][d]; two threads per row
+  // D[q] = sum_d dO[q][d] * O[q][d]; two threads per (chunk-local) row
   {
-    const int qq = threadIdx.x >> 1, hh = threadIdx.x & 1;
+    const int ql = threadIdx.x >> 1, hh = threadIdx.x & 1;
     float part = 0.f;
-    if (qq < nq) {
-      const float4 *a = reinterpret_cast<const float4 *>(dO + qrow(qq) * ostride + hh * 32);
-      const float4 *c = reinterpret_cast<const float4 *>(O + qrow(qq) * ostride + hh * 32);
+    if (ql < nql) {
+      const float4 *a = reinterpret_cast<const float4 *>(dO + qrow(qc0 + ql) * ostride + hh * DH);
+      const float4 *c = reinterpret_cast<const float4 *>(O + qrow(qc0 + ql) * ostride + hh * DH);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < DH / 4; ++i) {
         const float4 x = a[i], y = c[i];
         part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       }
     }
     part += __shfl_xor(part, 1);
-    if (hh == 0 && qq < AT_NQ_MAX) {
-      s_D[qq] = qq < nq ? part : 0.f;
-      s_lse[qq] = qq < nq ? lse[bh * nq + qq] : 0.f;
+    if (hh == 0 && ql < AT_NQ_MAX) {
+      s_D[ql] = ql < nql ? part : 0.f;
+      s_lse[ql] = ql < nql ? lse[bh * nq + qc0 + ql] : 0.f;
     }
   }
   __syncthreads();
@@ -379,9 +405,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
   const int ntiles = (nk + 31) / 32;
-  const int t_begin = blockIdx.x * tiles_per_split;
+  const int t_begin = ksplit * tiles_per_split;
   const int t_end = min(ntiles, t_begin + tiles_per_split);
-  const int nqt = (nq + 31) / 32;
+  const int nqt = (nql + 31) / 32;
   // work assignment (uniform per wave): key slot = wave % nslots, query part = wave / nslots
   const int nt = t_end - t_begin;
   const int nslots = nt >= AT_WAVES ? AT_WAVES : max(nt, 1);
@@ -389,60 +415,67 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   const int slot = wave % nslots, qpart = wave / nslots;
   const bool active = qpart < qsplit;
   unsigned visited = 0;  // bit qt: this wave's dQ image holds q-tile qt
-  f32x16 dvt0 = {0}, dvt1 = {0}, dkt0 = {0}, dkt1 = {0};
+  f32x16 dvt[NB], dkt[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dvt[j][r] = dkt[j][r] = 0.f;
 
   for (int t = t_begin + slot; active && t < t_end; t += nslots) {
     const int key0 = t * 32;
     const int krow = min(key0 + l31, nk - 1);
     const bool key_ok = key0 + l31 < nk;
-    float kf[32], vf[32], kop0[16], kop1[16];
-    load_half_row(kf, K, krow_of(krow), ldk, half, true);
-    load_half_row(vf, V, krow_of(krow), ldv, half, true);
+    float kf[DH], vf[DH], kop[NB][16];
+    load_half_row<DH>(kf, K, krow_of(krow), ldk, half, true);
+    load_half_row<DH>(vf, V, krow_of(krow), ldv, half, true);
     const float mk = M ? M[krow] : 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // K^T operands of the dQ product: fixed for the whole key tile
       const unsigned koff = krow_of(min(key0 + mfma_row(s, half), nk - 1)) * (unsigned)ldk + l31;
-      kop0[s] = K[koff];
-      kop1[s] = K[koff + 32];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) kop[j][s] = K[koff + 32 * j];
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dvt0[r] = dvt1[r] = dkt0[r] = dkt1[r] = 0.f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvt[j][r] = dkt[j][r] = 0.f;
     AT_MARK(1, 2);
 
     for (int qt = qpart; qt < nqt; qt += qsplit) {
-      const int q0 = qt * 32;
+      const int q0 = qc0 + qt * 32;
       // all global operands of this (key tile, query tile) pair are requested before the first MFMA
       // and the scheduler is fenced (see the forward kernel): Q and dO rows for S and dP, and the
       // transposed dO / Q operands of the dV / dK products
-      float fr[32], fdo[32], g0[16], g1[16], x0[16], x1[16];
+      float fr[DH], fdo[DH], g[NB][16], x[NB][16];
       const unsigned my_qrow = qrow(min(q0 + l31, nq - 1));
-      load_half_row(fr, Q, my_qrow, ldq, half, q0 + l31 < nq);
-      load_half_row(fdo, dO, my_qrow, ostride, half, q0 + l31 < nq);
+      load_half_row<DH>(fr, Q, my_qrow, ldq, half, q0 + l31 < q_end);
+      load_half_row<DH>(fdo, dO, my_qrow, ostride, half, q0 + l31 < q_end);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const unsigned qq = qrow(min(q0 + mfma_row(s, half), nq - 1));
         const unsigned goff = qq * ostride + l31, xoff = qq * (unsigned)ldq + l31;
-        g0[s] = dO[goff];
-        g1[s] = dO[goff + 32];
-        x0[s] = Q[xoff];
-        x1[s] = Q[xoff + 32];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          g[j][s] = dO[goff + 32 * j];
+          x[j][s] = Q[xoff + 32 * j];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       AT_MARK(1, 3);
       f32x16 sacc = {0};
 #pragma unroll
-      for (int s = 0; s < 32; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
+      for (int s = 0; s < DH; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
       AT_MARK(1, 4);
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qq = q0 + mfma_row(r, half);
-        const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq, AT_NQ_MAX - 1)]);
-        p[r] = (key_ok && qq < nq) ? e : 0.f;
+        const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq - qc0, AT_NQ_MAX - 1)]);
+        p[r] = (key_ok && qq < q_end) ? e : 0.f;
       }
       f32x16 dpacc = {0};
 #pragma unroll
-      for (int s = 0; s < 32; ++s) dpacc = mfma32(fdo[s], vf[s], dpacc);  // dP[q][key]
+      for (int s = 0; s < DH; ++s) dpacc = mfma32(fdo[s], vf[s], dpacc);  // dP[q][key]
       float ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -452,20 +485,21 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
           const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)nk;
           const bool keep = at_keep(drop, row_base, key0 + l31);
           dp = keep ? dp * drop.inv_keep : 0.f;          // d(P_dropped)/dP
-          ds[r] = p[r] * (dp - s_D[min(qq, AT_NQ_MAX - 1)]);
+          ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
           p[r] = keep ? p[r] * drop.inv_keep : 0.f;      // dV uses the dropped probabilities
         } else {
-          ds[r] = p[r] * (dp - s_D[min(qq, AT_NQ_MAX - 1)]);
+          ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
         }
       }
       AT_MARK(1, 5);
       // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        dvt0 = mfma32(g0[s], p[s], dvt0);
-        dvt1 = mfma32(g1[s], p[s], dvt1);
-        dkt0 = mfma32(x0[s], ds[s], dkt0);
-        dkt1 = mfma32(x1[s], ds[s], dkt1);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          dvt[j] = mfma32(g[j][s], p[s], dvt[j]);
+          dkt[j] = mfma32(x[j][s], ds[s], dkt[j]);
+        }
       }
       AT_MARK(1, 6);
       // dQ^T[d][q] = K^T[d][key] dS^T[key][q]: transpose the dS tile through wave-private LDS
@@ -473,42 +507,56 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
       for (int r = 0; r < 16; ++r) s_T[wave][l31][mfma_row(r, half)] = ds[r];
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      f32x16 dqt0 = {0}, dqt1 = {0};
+      const int ql0 = qt * 32;  // chunk-local row of the tile
+      f32x16 dqt[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[j][r] = 0.f;
       if ((visited >> qt) & 1u) {  // continue this wave's running dQ of the q-tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dqt0[r] = dq_img(wave, q0 + l31, mfma_row(r, half));
-          dqt1[r] = dq_img(wave, q0 + l31, 32 + mfma_row(r, half));
-        }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dqt[j][r] = dq_img(wave, ql0 + l31, 32 * j + mfma_row(r, half));
       }
       visited |= 1u << qt;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const float bq = s_T[wave][mfma_row(s, half)][l31];
-        dqt0 = mfma32(kop0[s], bq, dqt0);
-        dqt1 = mfma32(kop1[s], bq, dqt1);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dqt[j] = mfma32(kop[j][s], bq, dqt[j]);
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       __builtin_amdgcn_wave_barrier();
       AT_MARK(1, 7);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dq_img(wave, q0 + l31, mfma_row(r, half)) = dqt0[r];
-        dq_img(wave, q0 + l31, 32 + mfma_row(r, half)) = dqt1[r];
-      }
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_img(wave, ql0 + l31, 32 * j + mfma_row(r, half)) = dqt[j][r];
       AT_MARK(1, 8);
     }
     if (key_ok && qsplit == 1) {
-      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * AT_D;  // grads mirror the inputs
-      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * AT_D;
+      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * D;  // grads mirror the inputs
+      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // regs 4g..4g+3 are four consecutive feature rows
-        const int d = 8 * g + 4 * half;
-        *reinterpret_cast<float4 *>(dvp + d) = make_float4(dvt0[4 * g], dvt0[4 * g + 1], dvt0[4 * g + 2], dvt0[4 * g + 3]);
-        *reinterpret_cast<float4 *>(dvp + 32 + d) = make_float4(dvt1[4 * g], dvt1[4 * g + 1], dvt1[4 * g + 2], dvt1[4 * g + 3]);
-        *reinterpret_cast<float4 *>(dkp + d) = make_float4(dkt0[4 * g] * scale, dkt0[4 * g + 1] * scale, dkt0[4 * g + 2] * scale, dkt0[4 * g + 3] * scale);
-        *reinterpret_cast<float4 *>(dkp + 32 + d) = make_float4(dkt1[4 * g] * scale, dkt1[4 * g + 1] * scale, dkt1[4 * g + 2] * scale, dkt1[4 * g + 3] * scale);
-      }
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {  // regs 4g..4g+3 are four consecutive feature rows
+          const int d = 32 * j + 8 * g4 + 4 * half;
+          const float a4[4] = {dvt[j][4 * g4], dvt[j][4 * g4 + 1], dvt[j][4 * g4 + 2], dvt[j][4 * g4 + 3]};
+          const float c4[4] = {dkt[j][4 * g4] * scale, dkt[j][4 * g4 + 1] * scale, dkt[j][4 * g4 + 2] * scale,
+                               dkt[j][4 * g4 + 3] * scale};
+          if (atomic_dkv) {  // several query chunks meet in dK / dV
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              unsafeAtomicAdd(dvp + d + i, a4[i]);
+              unsafeAtomicAdd(dkp + d + i, c4[i]);
+            }
+          } else {
+            *reinterpret_cast<float4 *>(dvp + d) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            *reinterpret_cast<float4 *>(dkp + d) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+          }
+        }
     }
   }
   AT_MARK(1, 9);
@@ -517,42 +565,48 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     // accumulators in LDS, the part-0 wave adds them and stores
     if (active && qpart == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        red(slot, r, lane) = dvt0[r];
-        red(slot, 16 + r, lane) = dvt1[r];
-        red(slot, 32 + r, lane) = dkt0[r];
-        red(slot, 48 + r, lane) = dkt1[r];
-      }
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          red(slot, 16 * j + r, lane) = dvt[j][r];
+          red(slot, 16 * (NB + j) + r, lane) = dkt[j][r];
+        }
     }
     __syncthreads();
     const int key0 = (t_begin + slot) * 32;
     if (active && qpart == 0 && t_begin + slot < t_end && key0 + l31 < nk) {
-      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * AT_D;
-      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * AT_D;
+      float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * D;
+      float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 8 * g + 4 * half;
-        float a[4], b2[4], c[4], e[4];
+      for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = 4 * g + i;
-          a[i] = dvt0[r] + red(slot, r, lane);
-          b2[i] = dvt1[r] + red(slot, 16 + r, lane);
-          c[i] = (dkt0[r] + red(slot, 32 + r, lane)) * scale;
-          e[i] = (dkt1[r] + red(slot, 48 + r, lane)) * scale;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d = 32 * j + 8 * g4 + 4 * half;
+          float a4[4], c4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g4 + i;
+            a4[i] = dvt[j][r] + red(slot, 16 * j + r, lane);
+            c4[i] = (dkt[j][r] + red(slot, 16 * (NB + j) + r, lane)) * scale;
+          }
+          if (atomic_dkv) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              unsafeAtomicAdd(dvp + d + i, a4[i]);
+              unsafeAtomicAdd(dkp + d + i, c4[i]);
+            }
+          } else {
+            *reinterpret_cast<float4 *>(dvp + d) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            *reinterpret_cast<float4 *>(dkp + d) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+          }
         }
-        *reinterpret_cast<float4 *>(dvp + d) = make_float4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<float4 *>(dvp + 32 + d) = make_float4(b2[0], b2[1], b2[2], b2[3]);
-        *reinterpret_cast<float4 *>(dkp + d) = make_float4(c[0], c[1], c[2], c[3]);
-        *reinterpret_cast<float4 *>(dkp + 32 + d) = make_float4(e[0], e[1], e[2], e[3]);
-      }
     }
   }
   __syncthreads();
   AT_MARK(1, 10);
   // sum the waves' images: 4 consecutive features per thread, all LDS reads issued before the adds
-  for (int it = threadIdx.x; it < nq * (AT_D / 4); it += AT_WAVES * 64) {
-    const int qq = it >> 4, d = (it & 15) * 4;
+  for (int it = threadIdx.x; it < nql * (D / 4); it += AT_WAVES * 64) {
+    const int qq = it / (D / 4), d = (it - qq * (D / 4)) * 4;  // qq: chunk-local row
     const int qt = qq >> 5;
     float part[AT_WAVES][4];
 #pragma unroll
@@ -565,7 +619,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     float val[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) val[i] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) * scale;
-    float *dst = dq + qrow(qq) * (unsigned)ldq + hi * AT_D + d;
+    float *dst = dq + qrow(qc0 + qq) * (unsigned)ldq + hi * D + d;
     if (atomic_dq) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) unsafeAtomicAdd(dst + i, val[i]);
@@ -593,7 +647,7 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
-  SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
+  SIG3D_REQUIRE(d == 64 || d == 96, "attention head size must be 64 or 96");
   SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
   SIG3D_REQUIRE((q_seg == 0 || q_seg == nq || q_base2 >= b * q_seg) && (k_seg == 0 || k_seg == nk || k_base2 >= b * k_seg),
                 "the second segment must start at or after the end of the first");
@@ -608,19 +662,26 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   const int ntiles_fwd = (nk + 31) / 32;
   if (key_splits > ntiles_fwd) key_splits = ntiles_fwd;
   SIG3D_REQUIRE(key_splits == 1 || workspace != nullptr,
-                "key_splits > 1 needs a workspace of b*h*roundup32(nq)*key_splits*66 floats");
+                "key_splits > 1 needs a workspace of b*h*roundup32(nq)*key_splits*(d+2) floats");
   dim3 grid(((nq + 31) / 32) * key_splits, h, b);
   (void)k_rows;
-  hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
-                     q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
-                     p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
-  SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
-  if (key_splits > 1) {
-    const long rows = (long)b * h * nq;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
-                       q_seg, q_base2, key_splits, b, workspace, out, lse);
-    SIG3D_LAUNCH_CHECK("attention_combine_kernel");
+  const long rows = (long)b * h * nq;
+  if (d == 64) {
+    hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
+                       q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
+                       p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
+    if (key_splits > 1)
+      hipLaunchKernelGGL(attention_combine_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
+                         q_seg, q_base2, key_splits, b, workspace, out, lse);
+  } else {
+    hipLaunchKernelGGL(attention_fwd_kernel<96>, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
+                       q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
+                       p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
+    if (key_splits > 1)
+      hipLaunchKernelGGL(attention_combine_kernel<96>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
+                         q_seg, q_base2, key_splits, b, workspace, out, lse);
   }
+  SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
 
@@ -634,8 +695,7 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
-  SIG3D_REQUIRE(d == AT_D, "attention head size must be 64");
-  SIG3D_REQUIRE(nq <= AT_NQ_MAX, "attention backward supports at most 128 query rows");
+  SIG3D_REQUIRE(d == 64 || d == 96, "attention head size must be 64 or 96");
   SIG3D_REQUIRE(q_seg >= 0 && q_seg <= nq && k_seg >= 0 && k_seg <= nk, "segment sizes must be in [0, n]");
   SIG3D_REQUIRE((q_seg == 0 || q_seg == nq || q_base2 >= b * q_seg) && (k_seg == 0 || k_seg == nk || k_base2 >= b * k_seg),
                 "the second segment must start at or after the end of the first");
@@ -661,23 +721,44 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
   {
     const int q_extent = (q_seg > 0 && q_seg < nq) ? q_base2 + b * (nq - q_seg) : b * nq;
-    SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * AT_D,
+    SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * d,
                                    (size_t)(q_rows > q_extent ? q_rows : q_extent), stream));
   }
-  dim3 grid(splits, h, b);
+  // query chunks: the per-row statistics and the four dQ images of a chunk must fit in LDS
+  const int chunk_max = d == 64 ? AT_NQ_MAX : 64;
   const int nq_pad = (nq + 31) / 32 * 32;
-  const int qsplit_max = nq_pad <= 64 ? 2 : 1;  // LDS budget: images (+ 32 KiB of dK/dV partials)
-  const size_t lds = sizeof(float) * (AT_WAVES * (size_t)nq_pad * (AT_D + 1) + (qsplit_max == 2 ? 2 * 64 * 64 : 0));
+  const int nchunks = (nq + chunk_max - 1) / chunk_max;
+  const int qchunk = nchunks == 1 ? nq_pad : chunk_max;
+  if (nchunks > 1) {  // dk / dv are accumulated with atomics across query chunks
+    const int k_extent = (k_seg > 0 && k_seg < nk) ? k_base2 + b * (nk - k_seg) : b * nk;
+    const size_t krows = (size_t)(k_rows > k_extent ? k_rows : k_extent);
+    SIG3D_HIP_TRY(hipMemset2DAsync(dk, sizeof(float) * ldk, 0, sizeof(float) * h * d, krows, stream));
+    SIG3D_HIP_TRY(hipMemset2DAsync(dv, sizeof(float) * ldv, 0, sizeof(float) * h * d, krows, stream));
+  }
+  dim3 grid(splits * nchunks, h, b);
+  const size_t img = sizeof(float) * AT_WAVES * (size_t)qchunk * (d + 1);
+  const size_t red_bytes = sizeof(float) * 2 * (2 * (d / 32) * 16) * 64;  // dK/dV partials of the q-split mode
+  const int qsplit_max = (qchunk <= 64 && img + red_bytes <= 136 * 1024) ? 2 : 1;
+  const size_t lds = img + (qsplit_max == 2 ? red_bytes : 0);
+  SIG3D_REQUIRE(lds <= 136 * 1024, "attention backward: LDS budget exceeded");
   static bool attr_done = false;
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<96>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(attention_bwd_kernel, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
-                     q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale,
-                     tiles_per_split, splits > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
-                     out, lse, grad_out, dq, dk, dv);
+  if (d == 64)
+    hipLaunchKernelGGL(attention_bwd_kernel<64>, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
+                       q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, tiles_per_split, splits, qchunk,
+                       splits > 1 ? 1 : 0, nchunks > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
+                       out, lse, grad_out, dq, dk, dv);
+  else
+    hipLaunchKernelGGL(attention_bwd_kernel<96>, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
+                       q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, tiles_per_split, splits, qchunk,
+                       splits > 1 ? 1 : 0, nchunks > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
+                       out, lse, grad_out, dq, dk, dv);
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
   return 0;
 }

@@ -244,7 +244,7 @@ class _AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None
 
 
-def _fwd_key_splits(b, heads, nq, nk, device):
+def _fwd_key_splits(b, heads, nq, nk, device, d=64):
     """(key_splits, workspace) for sig3d_attention_fwd: split the key range when (batch x heads x query
     tiles) alone cannot fill 256 CUs and there are enough 32-key tiles to share out (3D-LLM shapes)."""
     qtiles = (nq + 31) // 32
@@ -253,7 +253,7 @@ def _fwd_key_splits(b, heads, nq, nk, device):
     splits = min(max(1, 1024 // max(wgs, 1)), ntiles // 16, 64)
     if splits <= 1:
         return 1, None
-    work = torch.empty(b * heads * qtiles * 32 * splits * 66, dtype=torch.float32, device=device)
+    work = torch.empty(b * heads * qtiles * 32 * splits * (d + 2), dtype=torch.float32, device=device)
     return splits, work
 
 

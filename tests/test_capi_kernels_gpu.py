@@ -83,30 +83,34 @@ def _attn_ref(q, k, v, mask, scale):
 
 @pytest.mark.parametrize("b,h,nq,nk,use_mask", [(2, 12, 32, 256, True), (1, 3, 52, 52, True),
                                                 (2, 2, 32, 5000, False), (1, 1, 5, 33, True),
-                                                (1, 2, 32, 1, False), (1, 2, 100, 77, True)])
-def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
+                                                (1, 2, 32, 1, False), (1, 2, 100, 77, True),
+                                                (2, 2, 256, 256, True), (1, 2, 300, 48, False), (1, 1, 129, 129, True)])
+@pytest.mark.parametrize("D", [64, 96])
+def test_attention_fwd_bwd(b, h, nq, nk, use_mask, D):
+    """Head sizes 64 (Q-Former) and 96 (MCAN blocks); more than 128 query rows run the backward in query
+    chunks with atomic dK / dV."""
     L = _lib()
-    g = torch.Generator().manual_seed(nq * 131 + nk)
-    q = torch.randn(b, h, nq, 64, generator=g)
-    k = torch.randn(b, h, nk, 64, generator=g)
-    v = torch.randn(b, h, nk, 64, generator=g)
+    g = torch.Generator().manual_seed(nq * 131 + nk + D)
+    q = torch.randn(b, h, nq, D, generator=g)
+    k = torch.randn(b, h, nk, D, generator=g)
+    v = torch.randn(b, h, nk, D, generator=g)
     mask = None
     if use_mask:
         keep = (torch.rand(b, nk, generator=g) > 0.2).float()
         keep[:, 0] = 1.0
         mask = (1.0 - keep) * -10000.0  # Qformer.py:731
-    scale = 1.0 / math.sqrt(64)
-    go = torch.randn(b, nq, h * 64, generator=g)
+    scale = 1.0 / math.sqrt(D)
+    go = torch.randn(b, nq, h * D, generator=g)
 
     # C ABI takes token-major (b, n, h*d) operands (what nn.Linear produces)
     tm = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], -1).contiguous()
-    untm = lambda t: t.reshape(t.shape[0], t.shape[1], h, 64).permute(0, 2, 1, 3)
+    untm = lambda t: t.reshape(t.shape[0], t.shape[1], h, D).permute(0, 2, 1, 3)
     qd, kd, vd, god = tm(q).to(DEV), tm(k).to(DEV), tm(v).to(DEV), go.to(DEV)
     md = mask.to(DEV) if mask is not None else None
-    out = torch.empty(b, nq, h * 64, device=DEV)
+    out = torch.empty(b, nq, h * D, device=DEV)
     lse = torch.empty(b, h, nq, device=DEV)
-    ld = h * 64  # dense token-major operands
-    L.call("sig3d_attention_fwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    ld = h * D  # dense token-major operands
+    L.call("sig3d_attention_fwd", b, h, nq, nk, D, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
            L.ptr(None), 1, L.ptr(None), L.stream_ptr())
 
@@ -122,7 +126,7 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask):
     dq = torch.empty_like(qd)
     dk = torch.empty_like(kd)
     dv = torch.empty_like(vd)
-    L.call("sig3d_attention_bwd", b, h, nq, nk, 64, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
+    L.call("sig3d_attention_bwd", b, h, nq, nk, D, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(qd), L.ptr(kd),
            L.ptr(vd), L.ptr(md), L.ptr(out), L.ptr(lse), L.ptr(god), L.ptr(dq), L.ptr(dk),
            L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
     torch.testing.assert_close(untm(dq.cpu()).double(), q64.grad, rtol=1e-4, atol=1e-4)
