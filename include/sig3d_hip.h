@@ -285,6 +285,20 @@ int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, co
                              const unsigned short *mask, float *dx, float *dres, float *dparams,
                              float *workspace, void *stream);
 
+/* The same fused tails with the MCAN blocks' own normalisation (situation3d/models/mcan_sqa_module.py:57-69:
+ * a_2 * (x - mean) / (std + eps) + b_2 with the UNBIASED standard deviation and eps added to the std):
+ * SA / SGA compute norm(x + dropout(sublayer(x))) (mcan_sqa_module.py:216-224, 249-261).  rstd receives
+ * 1/(std + eps); the backward needs eps again. */
+int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+                                    const unsigned *rng_counter, const float *x, const float *bias,
+                                    const float *res, const float *gamma, const float *beta, float eps,
+                                    float *out, float *v, float *mean, float *rstd, unsigned short *mask,
+                                    void *stream);
+int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, float p_drop, float eps, const float *dy,
+                                    const float *v, const float *mean, const float *rstd, const float *gamma,
+                                    const unsigned short *mask, float *dx, float *dres, float *dparams,
+                                    float *workspace, void *stream);
+
 /* *counter += 1 (uint32) on the stream: the per-forward seed of the dropout hash. */
 int sig3d_counter_increment(unsigned *counter, void *stream);
 

@@ -470,7 +470,12 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qq = q0 + mfma_row(r, half);
-        const float e = __expf(sacc[r] * scale + mk - s_lse[min(qq - qc0, AT_NQ_MAX - 1)]);
+        // a row whose every key carries a fill mask (-1e9, the MCAN blocks' masked_fill) has all scores equal
+        // to the fill and log-sum-exp = fill + log(nk), which float32 cannot hold next to 1e9: such a row
+        // attends uniformly, p = 1/nk -- and, the scores having been REPLACED by a constant, passes no
+        // gradient to q / k (dS = 0 below); dV still sees p
+        const float row_lse = s_lse[min(qq - qc0, AT_NQ_MAX - 1)];
+        const float e = row_lse < -1e8f ? 1.f / (float)nk : __expf(sacc[r] * scale + mk - row_lse);
         p[r] = (key_ok && qq < q_end) ? e : 0.f;
       }
       f32x16 dpacc = {0};
@@ -490,6 +495,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         } else {
           ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
         }
+        if (s_lse[min(qq - qc0, AT_NQ_MAX - 1)] < -1e8f) ds[r] = 0.f;  // fully fill-masked row, see above
       }
       AT_MARK(1, 5);
       // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]

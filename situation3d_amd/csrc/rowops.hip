@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ res,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     float *__restrict__ out, float *__restrict__ v_out, float *__restrict__ mean_out,
-    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows) {
+    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows, int mcan) {
   const int lane = lane_id();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i)
     if (lane + 64 * i < cols) sq += (v[i] - mean) * (v[i] - mean);
-  const float rstd = rsqrtf(wave_allreduce_sum_f32(sq) / cols + eps);
+  // mcan: the MCAN blocks' own LayerNorm (mcan_sqa_module.py:57-69): unbiased std, eps added to the STD
+  const float ssq = wave_allreduce_sum_f32(sq);
+  const float rstd = mcan ? 1.f / (sqrtf(ssq / (cols - 1)) + eps) : rsqrtf(ssq / cols + eps);
 #pragma unroll
   for (int i = 0; i < PER_LANE; ++i) {
     const int c = lane + 64 * i;
@@ -130,7 +132,8 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     int rows, int cols, float p_drop, int rows_per_wave, const float *__restrict__ dy,
     const float *__restrict__ v, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const unsigned short *__restrict__ mask,
-    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial, int part_rows) {
+    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial, int part_rows,
+    int mcan, float eps) {
   // partial: (gridDim.x, 3*cols) = per-workgroup [d gamma | d beta | d bias] column sums
   __shared__ float part[3][3][64 * PER_LANE];  // waves 1..3 park their sums here
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -170,7 +173,10 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
       ab[i] += d;
     }
     c1 = wave_allreduce_sum_f32(c1) / cols;
-    c2 = wave_allreduce_sum_f32(c2) / cols;
+    c2 = wave_allreduce_sum_f32(c2);
+    // y = gamma*(v-mu)*r + beta.  standard: r = rsqrt(var+eps)  -> dv = r*(g - mean g - xh*mean(g xh));
+    // mcan: r = 1/(s+eps), s = unbiased std       -> dv = r*(g - mean g) - xh*sum(g xh)/((n-1)*s)
+    c2 = mcan ? c2 / ((cols - 1) * (1.f / rs - eps) * rs) : c2 / cols;
 #pragma unroll
     for (int i = 0; i < PER_LANE; ++i) {
       const int c = lane + 64 * i;
@@ -252,13 +258,12 @@ extern "C" int sig3d_counter_increment(unsigned *counter, void *stream_) {
   return 0;
 }
 
-extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
-                                        const unsigned *rng_counter, const float *x,
-                                        const float *bias, const float *res, const float *gamma,
-                                        const float *beta, float eps, float *out, float *v,
-                                        float *mean, float *rstd, unsigned short *mask,
-                                        void *stream_) {
+static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+                       const unsigned *rng_counter, const float *x, const float *bias, const float *res,
+                       const float *gamma, const float *beta, float eps, float *out, float *v, float *mean,
+                       float *rstd, unsigned short *mask, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(!mcan || cols >= 2, "the unbiased standard deviation needs at least two columns");
   SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
   SIG3D_REQUIRE((long)rows * cols < (1L << 32), "rows*cols must fit 32 bits (dropout hash index)");
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
@@ -269,20 +274,39 @@ extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<12>, grid, dim3(256), 0, stream, rows, cols, p_drop,
                        call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask,
-                       part_rows);
+                       part_rows, mcan);
   else
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<LN_MAX_PER_LANE>, grid, dim3(256), 0, stream, rows, cols,
                        p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd,
-                       mask, part_rows);
+                       mask, part_rows, mcan);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_fwd_kernel");
   return 0;
 }
 
-extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, const float *dy,
-                                        const float *v, const float *mean, const float *rstd,
-                                        const float *gamma, const unsigned short *mask, float *dx,
-                                        float *dres, float *dparams, float *workspace,
+extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+                                        const unsigned *rng_counter, const float *x,
+                                        const float *bias, const float *res, const float *gamma,
+                                        const float *beta, float eps, float *out, float *v,
+                                        float *mean, float *rstd, unsigned short *mask,
                                         void *stream_) {
+  return ln_tail_fwd(0, rows, cols, part_rows, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
+                     mean, rstd, mask, stream_);
+}
+
+extern "C" int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+                                               const unsigned *rng_counter, const float *x,
+                                               const float *bias, const float *res, const float *gamma,
+                                               const float *beta, float eps, float *out, float *v,
+                                               float *mean, float *rstd, unsigned short *mask,
+                                               void *stream_) {
+  return ln_tail_fwd(1, rows, cols, part_rows, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
+                     mean, rstd, mask, stream_);
+}
+
+static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, float p_drop, const float *dy,
+                       const float *v, const float *mean, const float *rstd, const float *gamma,
+                       const unsigned short *mask, float *dx, float *dres, float *dparams, float *workspace,
+                       void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
   SIG3D_REQUIRE(p_drop == 0.f || mask != nullptr, "the forward's mask buffer is required when p_drop > 0");
@@ -303,16 +327,35 @@ extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float
   const int blocks = sig3d_ceil_div(sig3d_ceil_div(rows, rpw), 4);
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<12>, dim3(blocks), dim3(256), 0, stream, rows, cols, p_drop,
-                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows);
+                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan, eps);
   else
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<LN_MAX_PER_LANE>, dim3(blocks), dim3(256), 0, stream, rows,
-                       cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows);
+                       cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan,
+                       eps);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
   // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols)
   hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(3 * cols, 64), parts), dim3(CS_WAVES * 64), 0,
                      stream, blocks / parts, 3 * cols, workspace, dparams);
   SIG3D_LAUNCH_CHECK("column_sum_kernel");
   return 0;
+}
+
+extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, const float *dy,
+                                        const float *v, const float *mean, const float *rstd,
+                                        const float *gamma, const unsigned short *mask, float *dx,
+                                        float *dres, float *dparams, float *workspace,
+                                        void *stream_) {
+  return ln_tail_bwd(0, 0.f, rows, cols, part_rows, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
+                     workspace, stream_);
+}
+
+extern "C" int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, float p_drop, float eps,
+                                               const float *dy, const float *v, const float *mean,
+                                               const float *rstd, const float *gamma,
+                                               const unsigned short *mask, float *dx, float *dres,
+                                               float *dparams, float *workspace, void *stream_) {
+  return ln_tail_bwd(1, eps, rows, cols, part_rows, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
+                     workspace, stream_);
 }
 
 extern "C" int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x, const float *bias,

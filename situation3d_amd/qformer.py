@@ -114,9 +114,10 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
-def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0):
+def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, mcan=False):
     """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask.
-    part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows."""
+    part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows.
+    mcan: the MCAN blocks' normalisation (unbiased std, eps on the std) instead of nn.LayerNorm's."""
     dev = x2.device
     rows, cols = x2.shape
     out = torch.empty_like(x2)
@@ -124,7 +125,8 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0):
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
-        _lib.call("sig3d_dropout_add_ln_fwd", rows, cols, part_rows, ctypes.c_float(p_drop),
+        _lib.call("sig3d_dropout_add_mcan_norm_fwd" if mcan else "sig3d_dropout_add_ln_fwd", rows, cols, part_rows,
+                  ctypes.c_float(p_drop),
                   ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
                   _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
                   _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
@@ -132,7 +134,7 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0):
     return out, v, stats, mask
 
 
-def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0):
+def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
     dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0)."""
     rows, cols = v.shape
@@ -141,11 +143,14 @@ def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0):
     shape = (rows // part_rows, 3, cols) if part_rows > 0 else (3, cols)
     dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
     work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
+    tail = (_lib.ptr(dy2), _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma), _lib.ptr(mask),
+            _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work), _lib.stream_ptr(v.device))
     with torch.cuda.device(v.device):
-        _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, ctypes.c_float(p_drop), _lib.ptr(dy2),
-                  _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma),
-                  _lib.ptr(mask), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work),
-                  _lib.stream_ptr(v.device))
+        if mcan_eps is None:
+            _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, ctypes.c_float(p_drop), *tail)
+        else:
+            _lib.call("sig3d_dropout_add_mcan_norm_bwd", rows, cols, part_rows, ctypes.c_float(p_drop),
+                      ctypes.c_float(mcan_eps), *tail)
     return dx, dres, dparams
 
 
@@ -172,13 +177,15 @@ class _DropoutAddLayerNormFn(torch.autograd.Function):
     (Qformer.py:241-246, 323-328) as one kernel each way (csrc/rowops.hip)."""
 
     @staticmethod
-    def forward(ctx, x, bias, residual, gamma, beta, p_drop, eps, call_id):
+    def forward(ctx, x, bias, residual, gamma, beta, p_drop, eps, call_id, mcan=False):
         cols = x.shape[-1]
         x2 = x.reshape(-1, cols).contiguous()
         r2 = residual.reshape(-1, cols).contiguous()
-        out, v, stats, mask = _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id)
+        out, v, stats, mask = _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, mcan=mcan)
         ctx.save_for_backward(v, stats, gamma, mask)
         ctx.p_drop = p_drop
+        ctx.mcan_eps = eps if mcan else None
+        ctx.has_bias = bias is not None
         ctx.shape = x.shape
         return out.view(x.shape)
 
@@ -187,9 +194,9 @@ class _DropoutAddLayerNormFn(torch.autograd.Function):
         v, stats, gamma, mask = ctx.saved_tensors
         rows, cols = v.shape
         dx, dres, dparams = _ln_tail_bwd(dy.reshape(rows, cols).contiguous(), v, stats, gamma, mask,
-                                         ctx.p_drop)
-        return (dx.view(ctx.shape), dparams[2], dres.view(ctx.shape), dparams[0], dparams[1], None,
-                None, None)
+                                         ctx.p_drop, mcan_eps=ctx.mcan_eps)
+        return (dx.view(ctx.shape), dparams[2] if ctx.has_bias else None, dres.view(ctx.shape), dparams[0],
+                dparams[1], None, None, None, None)
 
 
 def dense_dropout_add_layer_norm(dense, dropout, layer_norm, hidden_states, input_tensor, call_id):
@@ -217,7 +224,7 @@ class _AttentionFn(torch.autograd.Function):
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
-        _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev)
+        _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev, d)
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, nq, nk, 0, 0, 0, 0, hd, hd, hd, ctypes.c_float(scale),
                       _lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(mask), _lib.ptr(out),
