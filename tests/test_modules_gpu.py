@@ -335,3 +335,32 @@ def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split):
         graph = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(5)]
     torch.cuda.synchronize()
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
+
+
+def test_graphed_forward_with_prefetched_geometry_matches_inline():
+    """serve.GraphedForward: the forward of batch i as one hipGraph with the geometry chain of batch i+1 on a
+    forked branch; every output must equal the inline eval forward bit for bit, also when the caller breaks
+    the announced order."""
+    import bench
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.serve import GraphedForward
+    dev = torch.device(DEV)
+    torch.manual_seed(3)
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64)
+    model = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(dev).eval()
+    batches = []
+    for i in range(3):
+        bt = bench.synthetic_batch(2, 6000, 50 + i, dev)
+        bt["q_feat"]["input_ids"] = bt["q_feat"]["input_ids"] % 100
+        batches.append(bt)
+    work = torch.cuda.Stream(dev)
+    with torch.cuda.stream(work), torch.no_grad():
+        refs = [model(dict(bt))["answer_scores"].clone() for bt in batches]
+        step = GraphedForward(model, batches[0])
+        order = [0, 1, 2, 0, 2, 1, 1]   # the last entries break the announced order
+        for k, i in enumerate(order):
+            nxt = order[k + 1] if k + 1 < len(order) and k != 3 else (i + 1) % 3
+            out = step(batches[i], batches[nxt])
+            assert torch.equal(out["answer_scores"], refs[i]), (k, i)
+    torch.cuda.synchronize()

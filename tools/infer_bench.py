@@ -33,5 +33,21 @@ with torch.cuda.stream(work), torch.no_grad():
         g.replay()
     torch.cuda.synchronize()
     graphed = (time.perf_counter() - t0) / 20
+    # serving loop: geometry of batch i+1 under the forward of batch i (situation3d_amd/serve.py)
+    from situation3d_amd.serve import GraphedForward
+    batches = [bench.synthetic_batch(B, bench.N_POINTS, 100 + i, dev) for i in range(3)]
+    step = GraphedForward(model, batches[0])
+    refs = [model(dict(bt))["answer_scores"].clone() for bt in batches]
+    for i in range(6):
+        out = step(batches[i % 3], batches[(i + 1) % 3])
+        assert torch.equal(out["answer_scores"], refs[i % 3]), "prefetched forward differs from the inline one"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(30):
+        step(batches[i % 3], batches[(i + 1) % 3])
+    torch.cuda.synchronize()
+    piped = (time.perf_counter() - t0) / 30
+print("forward only, B=%d x %d pts, geometry prefetched one batch ahead: %.2f ms (%.0f samples/s)"
+      % (B, bench.N_POINTS, piped * 1e3, B / piped))
 print("forward only, B=%d x %d pts: eager %.2f ms (%.0f samples/s), hipGraph %.2f ms (%.0f samples/s)"
       % (B, bench.N_POINTS, eager * 1e3, B / eager, graphed * 1e3, B / graphed))
