@@ -28,6 +28,15 @@ def test_fps_sizes(hip_ext, oracle, n, m):
     _fps_case(hip_ext, oracle, 2, n, m, seed=n)
 
 
+@pytest.mark.parametrize("b,n,m", [(3, 8193, 200), (9, 10000, 150), (2, 16384, 200), (2, 16385, 100), (2, 24576, 150),
+                                   (1, 24577, 100), (2, 40960, 100), (1, 40961, 80), (2, 65536, 80), (1, 65537, 60),
+                                   (1, 98304, 60), (1, 98305, 50), (1, 150000, 40)])
+def test_fps_cooperative_instances(hip_ext, oracle, b, n, m):
+    """Every (points per thread) instance of the 8 x 512 cooperative kernel at and just past its size limit,
+    batches that are not a multiple of the 8 scenes of one launch, ties and a zero tail included."""
+    _fps_case(hip_ext, oracle, b, n, m, seed=n + b, dup=n // 20, zero_tail=n // 50)
+
+
 def test_fps_ties_and_skips(hip_ext, oracle):
     # duplicated points (exact ties in min-distance) and an all-zero padded tail
     # (skipped by the mag <= 1e-3 rule, sampling_gpu.cu:100-101)
