@@ -190,8 +190,8 @@ def main():
         # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
         # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
         # issued once more eagerly right after the timed region and bracketed there.
-        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_transpose_cn",
-                            "sig3d_ball_query", "sig3d_ball_query_grid",
+        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
+                            "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query", "sig3d_ball_query_grid",
                             "sig3d_furthest_point_sampling"])
         if reducer is not None:
             reducer.hooks_enabled = True
@@ -213,9 +213,23 @@ def main():
 
         # the grouping launches of a step: the narrow SA1 level through query_group_fused_kernel, the wide
         # levels through its point-major twin (plus the small transposes that feed it, reported apart)
-        grp = kernel_ms("sig3d_query_group_fused") + kernel_ms("sig3d_query_group_fused_pm")
+        # Levels whose neighbour lists are mostly padding run in compact mode (distinct neighbours only:
+        # DESIGN.md 5d) and never form the dense grouped tensor; the roofline is taken over the launches
+        # that do, with the algorithmic bytes of exactly those launches (shapes from the recorded arguments).
+        grp, grp_bytes = [], 0
+        for name, pm in (("sig3d_query_group_fused", False), ("sig3d_query_group_fused_pm", True)):
+            for s_ev, e_ev, ints in recs[name]:
+                bb, nn, mm, cc = ints[0], ints[1], ints[2], ints[3]
+                ns_ = ints[5] if pm else ints[4]
+                grp.append(s_ev.elapsed_time(e_ev))
+                grp_bytes += group_algorithmic_bytes(bb, nn, mm, ns_, cc)
+        cgrp = kernel_ms("sig3d_query_group_compact")
+        # the largest HBM-bound kernel of the step by time is the flat AdamW update: per parameter it reads
+        # p, g, m, v and writes p, m, v and the zeroed g (32 B, clip + update + zero_grad in one pass)
+        adam = kernel_ms("sig3d_adamw_table") + kernel_ms("sig3d_adamw_flat")
+        n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        adam_gbs = 32.0 * n_params * KSTEPS / (sum(adam) * 1e-3) / 1e9 if adam else 0.0
         tr = kernel_ms("sig3d_transpose_cn")
-        grp_bytes = sum(group_algorithmic_bytes(BATCH, *lvl) for lvl in SA_LEVELS) * KSTEPS
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid")
         fps = kernel_ms("sig3d_furthest_point_sampling")
@@ -243,7 +257,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),
                          "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
+            "roofline_adamw": {"bound": "hbm", "kernel": "adamw_table_kernel", "achieved": round(adam_gbs, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adam_gbs / HBM_PEAK_GBS, 4),
+                               "algorithmic_bytes_per_launch": 32 * n_params,
+                               "avg_launch_us": round(sum(adam) / max(len(adam), 1) * 1e3, 1)},
             "kernels_ms_per_step": {"query_group_fused": round(sum(grp) / KSTEPS, 4),
+                                    "query_group_compact": round(sum(cgrp) / KSTEPS, 4),
                                     "point_major_transposes": round(sum(tr) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
                                     "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},

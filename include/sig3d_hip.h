@@ -376,6 +376,46 @@ int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,
                         const unsigned *rng_counter, void *stream);
 
+/* ---- compact mode: set abstraction over the DISTINCT neighbours only ------------------------------------
+ * ball_query pads a short list by repeating its first hit (ball_query_gpu.cu:30-40); every padded entry is
+ * an identical column of the grouped tensor, of each SharedMLP layer above it (pytorch_utils.py:11-36) and of
+ * the max-pool (pointnet2_modules.py:251-262).  sig3d_compact_neighbour_lists lists the distinct
+ * (centre, neighbour) pairs of every batch element back to back:
+ *   idx (b,m,nsample) -> cidx (b,m*nsample) point index, centre_of (b,m*nsample) centre, mult (b,m*nsample) f32
+ *   how many equal columns the entry stands for, seg_off (b,m+1) first entry of every centre, n_act (b) count;
+ *   only the first n_act[b] entries of a row are defined.
+ * The *_compact entry points below are the dense ones restricted to positions [0, n_act[b]) of every
+ * (batch, channel) row (row stride e = m*nsample unchanged); batch statistics are weighted by mult and the
+ * BatchNorm backward correction terms carry mult, so results equal the dense ones up to summation order.
+ * Gradients of a position are the SUM over the columns it stands for. */
+int sig3d_compact_neighbour_lists(int b, int m, int nsample, const int *idx, int *cidx, int *centre_of,
+                                  float *mult, int *seg_off, int *n_act, void *stream);
+/* grouped tensor of the distinct neighbours: features_pm (b,n,ld) point-major (wide levels) or NULL, then
+ * features (b,c,n) channel-major is gathered; out (b, (use_xyz?3:0)+c, m*nsample) */
+int sig3d_query_group_compact(int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz,
+                              float radius, const float *xyz, const float *new_xyz, const float *features,
+                              const float *features_pm, const int *cidx, const int *centre_of,
+                              const int *n_act, float *out, void *stream);
+/* point_major != 0: grad (b,n,ld); else grad (b,c,n); zeroed here */
+int sig3d_query_group_compact_grad(int b, int n, int m, int c, int ld, int nsample, int c_total, int c_off,
+                                   const float *grad_out, const int *cidx, const int *n_act, int point_major,
+                                   float *grad, void *stream);
+int sig3d_mlp_layer_fwd_compact(int b, int cin, int cout, long e, const float *x, const float *w,
+                                const float *pscale, const float *pshift, float *y, double *stat_sum,
+                                double *stat_sq, int accumulate, const int *n_act, const float *mult,
+                                void *stream);
+int sig3d_mlp_layer_dw_compact(int b, int cin, int cout, long e, const float *dY, const float *x,
+                               const float *pscale, const float *pshift, float *dW, int accumulate,
+                               const int *n_act, void *stream);
+/* arg = offset of the first maximum inside the centre's segment */
+int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const float *y, const float *scale,
+                                  const float *shift, const int *seg_off, float *out, int *arg, void *stream);
+int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const float *dA, const float *dOut, const int *arg,
+                              const float *y, const float *scale, const float *shift, const float *mean,
+                              const float *invstd, double *s1, double *s2, float *dY, int accumulate,
+                              const int *n_act, const float *mult, const int *centre_of, const int *seg_off,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

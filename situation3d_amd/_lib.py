@@ -24,6 +24,14 @@ SIGNATURES = {
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "sig3d_ball_query_grid": [_I, _I, _I, _F, _I, _P, _P, _P, _P, ctypes.c_long, _P],
+    "sig3d_compact_neighbour_lists": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_query_group_compact": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_query_group_compact_grad": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
+    "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
+    "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_bn_relu_bwd_compact": [_I, _I, ctypes.c_long, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                  _P, _P, _P, _P, _P],
     "sig3d_voxelize": [_I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                        ctypes.c_long, ctypes.c_long, _P],
     "sig3d_fnv_hash_vec": [ctypes.c_long, _I, _P, _P, _P],

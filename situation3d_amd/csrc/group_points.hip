@@ -232,17 +232,22 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
 constexpr int GPM_P = 64;    // grouped elements per tile
 constexpr int GPM_C = 128;   // channels per tile
 
+// Compact mode (centre_of / n_act given, compact.hip): idx holds the DISTINCT neighbours of a batch element
+// back to back, centre_of their centres, n_act[b] how many there are; positions >= n_act[b] are not written.
 __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
     int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
-    const int *__restrict__ idx, float *__restrict__ out) {
+    const int *__restrict__ idx, float *__restrict__ out, const int *__restrict__ centre_of,
+    const int *__restrict__ n_act) {
   __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
   const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int total = m * nsample;
+  const int stride = m * nsample;                       // positions per (batch, channel) row of out
+  const int total = n_act ? n_act[bi] : stride;         // positions that exist
   const int e0 = blockIdx.x * GPM_P;
+  if (e0 >= total) return;
   const int c_total = (use_xyz ? 3 : 0) + c;
-  const int *ip = idx + (size_t)bi * total;
+  const int *ip = idx + (size_t)bi * stride;
   const float *fb = feat_pm + (size_t)bi * n * ld;
   // rows: wave w, round r, half h -> tile row p = r*8 + w*2 + h; the half-wave's 32 lanes cover 128 channels
   const int half = lane >> 5, j = lane & 31;
@@ -267,14 +272,14 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
   if (use_xyz && blockIdx.y == 0 && wave == 0) {
     const int e = e0 + lane;
     if (e < total) {
-      const int a = ip[e], jc = e / nsample;
+      const int a = ip[e], jc = centre_of ? centre_of[(size_t)bi * stride + e] : e / nsample;
       const float *pt = xyz + ((size_t)bi * n + a) * 3;
       const float *ctr = new_xyz + ((size_t)bi * m + jc) * 3;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         float t = __fsub_rn(pt[k], ctr[k]);
         if (normalize_xyz) t = __fdiv_rn(t, radius);
-        __builtin_nontemporal_store(t, out + ((size_t)bi * c_total + k) * total + e);
+        __builtin_nontemporal_store(t, out + ((size_t)bi * c_total + k) * stride + e);
       }
     }
   }
@@ -289,10 +294,10 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int cc = c0 + 4 * (wave * 8 + q);
-      float *o = out + ((size_t)bi * c_total + c_off + cc) * total + e;
+      float *o = out + ((size_t)bi * c_total + c_off + cc) * stride + e;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (cc + k < c) __builtin_nontemporal_store(w4[q][k], o + (size_t)k * total);
+        if (cc + k < c) __builtin_nontemporal_store(w4[q][k], o + (size_t)k * stride);
     }
   }
 }
@@ -322,23 +327,25 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
 // A half-wave walks 8 consecutive elements and merges runs of equal indices in registers first: ball
 // query pads a short neighbour list with its first hit, so most of a list is one repeated index.
 __global__ __launch_bounds__(GP_THREADS) void group_points_grad_pm_kernel(
-    int n, int c, int ld, int total, int c_total, int c_off, const float *__restrict__ grad_out,
-    const int *__restrict__ idx, float *__restrict__ grad_pm) {
+    int n, int c, int ld, int stride, int c_total, int c_off, const float *__restrict__ grad_out,
+    const int *__restrict__ idx, float *__restrict__ grad_pm, const int *__restrict__ n_act) {
   __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
   const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int e0 = blockIdx.x * GPM_P;
+  const int total = n_act ? n_act[bi] : stride;   // compact mode: only the distinct neighbours exist
+  if (e0 >= total) return;
   {
     const int p = lane, e = e0 + p;
     const bool ok = e < total;
-    const float *g = grad_out + ((size_t)bi * c_total + c_off) * total + (ok ? e : total - 1);
+    const float *g = grad_out + ((size_t)bi * c_total + c_off) * stride + (ok ? e : total - 1);
     float v[8][4];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int cc = c0 + 4 * (wave * 8 + q) + k;
-        v[q][k] = g[(size_t)(cc < c ? cc : c - 1) * total];
+        v[q][k] = g[(size_t)(cc < c ? cc : c - 1) * stride];
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_pm_kernel(
   }
   __syncthreads();
   const int hw = wave * 2 + (lane >> 5), j = lane & 31;
-  const int *ip = idx + (size_t)bi * total;
+  const int *ip = idx + (size_t)bi * stride;
   int a[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -388,6 +395,44 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_pm_kernel(
     }
   }
   flush();
+}
+
+// Compact-mode grouping for narrow levels (c < 32, e.g. SA1's 3 colour channels): lane = distinct neighbour.
+__global__ __launch_bounds__(GP_THREADS) void query_group_compact_kernel(
+    int n, int m, int c, int stride, int use_xyz, int normalize_xyz, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ features,
+    const int *__restrict__ cidx, const int *__restrict__ centre_of, const int *__restrict__ n_act,
+    float *__restrict__ out) {
+  const int bi = blockIdx.y, e = blockIdx.x * GP_THREADS + threadIdx.x;
+  if (e >= n_act[bi]) return;
+  const int a = cidx[(size_t)bi * stride + e], jc = centre_of[(size_t)bi * stride + e];
+  const int c_total = (use_xyz ? 3 : 0) + c;
+  float *o = out + (size_t)bi * c_total * stride + e;
+  if (use_xyz) {
+    const float *pt = xyz + ((size_t)bi * n + a) * 3;
+    const float *ctr = new_xyz + ((size_t)bi * m + jc) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float t = __fsub_rn(pt[k], ctr[k]);
+      if (normalize_xyz) t = __fdiv_rn(t, radius);
+      o[(size_t)k * stride] = t;
+    }
+    o += (size_t)3 * stride;
+  }
+  const float *f = features + (size_t)bi * c * n + a;
+  for (int l = 0; l < c; ++l) o[(size_t)l * stride] = f[(size_t)l * n];
+}
+
+// ... and its backward: one atomic per (distinct neighbour, channel) into the channel-major gradient
+__global__ __launch_bounds__(GP_THREADS) void query_group_compact_grad_kernel(
+    int n, int c, int stride, int c_total, int c_off, const float *__restrict__ grad_out,
+    const int *__restrict__ cidx, const int *__restrict__ n_act, float *__restrict__ grad_features) {
+  const int bi = blockIdx.y, e = blockIdx.x * GP_THREADS + threadIdx.x;
+  if (e >= n_act[bi]) return;
+  const int a = cidx[(size_t)bi * stride + e];
+  const float *g = grad_out + ((size_t)bi * c_total + c_off) * stride + e;
+  float *d = grad_features + (size_t)bi * c * n + a;
+  for (int l = 0; l < c; ++l) unsafeAtomicAdd(d + (size_t)l * n, g[(size_t)l * stride]);
 }
 
 }  // namespace
@@ -504,10 +549,9 @@ extern "C" int sig3d_transpose_cn(int b, int c, int n, const float *in, float *o
   return 0;
 }
 
-extern "C" int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, int nsample, int use_xyz,
-                                          int normalize_xyz, float radius, const float *xyz,
-                                          const float *new_xyz, const float *features_pm, const int *idx,
-                                          float *out, void *stream_) {
+static int launch_group_pm(int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz,
+                           float radius, const float *xyz, const float *new_xyz, const float *features_pm,
+                           const int *idx, float *out, const int *centre_of, const int *n_act, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && c >= 4 && n >= 0 && m >= 0 && nsample >= 0, "bad size (c >= 4)");
   SIG3D_REQUIRE(c % 4 == 0 && ld % 4 == 0 && ld >= c, "point-major rows: c and ld multiples of 4, ld >= c");
@@ -518,14 +562,42 @@ extern "C" int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, in
   SIG3D_REQUIRE(n >= 1, "query_group_fused_pm: n must be >= 1 when idx is non-empty");
   dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
   hipLaunchKernelGGL(query_group_fused_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample, use_xyz,
-                     normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out);
+                     normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
   SIG3D_LAUNCH_CHECK("query_group_fused_pm_kernel");
   return 0;
 }
 
-extern "C" int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total,
-                                               int c_off, const float *grad_out, const int *idx,
-                                               float *grad_features_pm, void *stream_) {
+extern "C" int sig3d_query_group_fused_pm(int b, int n, int m, int c, int ld, int nsample, int use_xyz,
+                                          int normalize_xyz, float radius, const float *xyz,
+                                          const float *new_xyz, const float *features_pm, const int *idx,
+                                          float *out, void *stream_) {
+  return launch_group_pm(b, n, m, c, ld, nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx,
+                         out, nullptr, nullptr, stream_);
+}
+
+extern "C" int sig3d_query_group_compact(int b, int n, int m, int c, int ld, int nsample, int use_xyz,
+                                         int normalize_xyz, float radius, const float *xyz, const float *new_xyz,
+                                         const float *features, const float *features_pm, const int *cidx,
+                                         const int *centre_of, const int *n_act, float *out, void *stream_) {
+  SIG3D_REQUIRE(cidx && centre_of && n_act, "compact lists missing (sig3d_compact_neighbour_lists)");
+  if (features_pm != nullptr)
+    return launch_group_pm(b, n, m, c, ld, nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, cidx,
+                           out, centre_of, n_act, stream_);
+  SIG3D_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0 && nsample >= 0, "negative size");
+  SIG3D_REQUIRE(use_xyz || c > 0, "Cannot have not features and not use xyz as a feature!");
+  SIG3D_REQUIRE(c == 0 || features != nullptr, "features pointer is NULL with c > 0");
+  const long total = (long)m * nsample;
+  if (b == 0 || total == 0) return 0;
+  hipLaunchKernelGGL(query_group_compact_kernel, dim3(sig3d_ceil_div(total, GP_THREADS), b), dim3(GP_THREADS), 0,
+                     (hipStream_t)stream_, n, m, c, (int)total, use_xyz, normalize_xyz, radius, xyz, new_xyz,
+                     features, cidx, centre_of, n_act, out);
+  SIG3D_LAUNCH_CHECK("query_group_compact_kernel");
+  return 0;
+}
+
+static int launch_group_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total, int c_off,
+                                const float *grad_out, const int *idx, float *grad_features_pm,
+                                const int *n_act, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 0 && nsample >= 0 && ld >= c, "bad size");
   SIG3D_REQUIRE(c_off >= 0 && c_off + c <= c_total, "channel window out of range");
@@ -536,8 +608,36 @@ extern "C" int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int l
   if (total == 0) return 0;
   dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
   hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, c, ld, (int)total, c_total,
-                     c_off, grad_out, idx, grad_features_pm);
+                     c_off, grad_out, idx, grad_features_pm, n_act);
   SIG3D_LAUNCH_CHECK("group_points_grad_pm_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                               int c_off, const float *grad_out, const int *idx,
+                                               float *grad_features_pm, void *stream_) {
+  return launch_group_grad_pm(b, n, m, c, ld, nsample, c_total, c_off, grad_out, idx, grad_features_pm, nullptr,
+                              stream_);
+}
+
+// compact mode: grad_out holds one (duplicate-summed) gradient column per distinct neighbour.
+// point_major != 0: -> grad (b,n,ld) point-major (zeroed here); else -> grad (b,c,n) channel-major (zeroed here)
+extern "C" int sig3d_query_group_compact_grad(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                              int c_off, const float *grad_out, const int *cidx,
+                                              const int *n_act, int point_major, float *grad, void *stream_) {
+  SIG3D_REQUIRE(cidx && n_act, "compact lists missing (sig3d_compact_neighbour_lists)");
+  if (point_major)
+    return launch_group_grad_pm(b, n, m, c, ld, nsample, c_total, c_off, grad_out, cidx, grad, n_act, stream_);
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 0 && nsample >= 0, "bad size");
+  SIG3D_REQUIRE(c_off >= 0 && c_off + c <= c_total, "channel window out of range");
+  const long total = (long)m * nsample;
+  if (b == 0 || n == 0) return 0;
+  SIG3D_HIP_TRY(hipMemsetAsync(grad, 0, sizeof(float) * (size_t)b * c * n, stream));
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(query_group_compact_grad_kernel, dim3(sig3d_ceil_div(total, GP_THREADS), b), dim3(GP_THREADS), 0,
+                     stream, n, c, (int)total, c_total, c_off, grad_out, cidx, n_act, grad);
+  SIG3D_LAUNCH_CHECK("query_group_compact_grad_kernel");
   return 0;
 }
 

@@ -77,7 +77,11 @@ template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
 __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
-    float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq) {
+    float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq,
+    const int *__restrict__ n_act, const float *__restrict__ mult) {
+  // Compact mode (n_act given, compact.hip): only the first n_act[b] positions of every row exist -- the
+  // distinct neighbours -- and position u stands for mult[b][u] equal columns: the statistics are weighted.
+  // E stays the row stride; En is the number of positions.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin);
@@ -116,6 +120,8 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   ML_MARK(1);
   const float *xb = x + (size_t)bi * cin * E;
   float *yb = y + (size_t)bi * cout * E;
+  const long En = n_act ? (long)n_act[bi] : E;
+  const float *mb = mult ? mult + (size_t)bi * E : nullptr;
   float s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   // of the grid: wave-global index wg = blockIdx.y*ML_WAVES + wave owns tiles wg, wg + stride, ...
   // The launcher sizes gridDim.y so that the grid is ONE full round of resident workgroups
   // (weights staged once per workgroup, no tail round, neighbouring waves stream neighbouring tiles).
-  const long n_tiles = (E + 31) / 32;
+  const long n_tiles = (En + 31) / 32;
   const long tile0 = (long)blockIdx.y * ML_WAVES + wave;
   const long tile_stride = (long)gridDim.y * ML_WAVES;
   int my_tiles = 0;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     // 32-bit offsets from the uniform batch base (launcher: cin*E, cout*E < 2^31): one VGPR and
     // one multiply-add per address instead of a 64-bit pair
     const long e = e0_of(t) + l31;
-    const unsigned eo = (unsigned)(e < E ? e : E - 1);
+    const unsigned eo = (unsigned)(e < En ? e : En - 1);
 #pragma unroll
     for (int i = 0; i < ML_KC; ++i) {
       const int k = (c * ML_KC + i) * 2 + half;
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     if (c != nchunks - 1) return;
     // epilogue: acc[nt][4g..4g+3] = positions e0 + 8g + 4*half + (0..3) of channel co0+32nt+l31
     const long e0 = e0_of(t);
-    const bool full = e0 + 32 <= E;
+    const bool full = e0 + 32 <= En;
+    // (multiplicities are fetched where they are used, compact mode only: a 16-register array here cost the
+    // dense NT = 4 instances their third wave per SIMD)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = co0 + nt * 32 + l31;
@@ -206,16 +214,24 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const float v0 = acc[nt][4 * g4], v1 = acc[nt][4 * g4 + 1], v2 = acc[nt][4 * g4 + 2], v3 = acc[nt][4 * g4 + 3];
           if (VEC && full) {
-            s1[nt] += (v0 + v1) + (v2 + v3);
-            s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            if (mb) {
+              const float4 m4 = *reinterpret_cast<const float4 *>(mb + e0 + 8 * g4 + 4 * half);
+              const float w0 = m4.x, w1 = m4.y, w2 = m4.z, w3 = m4.w;
+              s1[nt] += (w0 * v0 + w1 * v1) + (w2 * v2 + w3 * v3);
+              s2[nt] += (w0 * v0 * v0 + w1 * v1 * v1) + (w2 * v2 * v2 + w3 * v3 * v3);
+            } else {
+              s1[nt] += (v0 + v1) + (v2 + v3);
+              s2[nt] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
           } else {
             const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (e0 + 8 * g4 + 4 * half + q < E) {
+              if (e0 + 8 * g4 + 4 * half + q < En) {
+                const float wq = mb ? mb[e0 + 8 * g4 + 4 * half + q] : 1.f;
                 yrow[8 * g4 + q] = vv[q];
-                s1[nt] += vv[q];
-                s2[nt] += vv[q] * vv[q];
+                s1[nt] += wq * vv[q];
+                s2[nt] += wq * vv[q] * vv[q];
               }
           }
         }
@@ -561,6 +577,102 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_kernel(
   }
 }
 
+// ---- compact mode (compact.hip): BatchNorm+ReLU+max-pool and their backward over the distinct neighbours ----
+// Row layout (b, c, E) as in dense mode, but only positions [0, n_act[b]) exist; the distinct neighbours of
+// centre j are positions [seg[j], seg[j+1]), position u stands for mult[u] equal columns.  These tensors are
+// a few per cent of the dense ones, so the kernels are plain one-element-per-thread loops.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_seg_kernel(int c, int P, long E, const float *__restrict__ y,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift,
+                                                                  const int *__restrict__ seg,
+                                                                  float *__restrict__ out, int *__restrict__ arg) {
+  const int bi = blockIdx.z, ch = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const int *sg = seg + (size_t)bi * (P + 1);
+  const int lo = sg[j], hi = sg[j + 1];
+  const float sc = scale[ch], sh = shift[ch];
+  const float *row = y + ((size_t)bi * c + ch) * E;
+  float best = -1.f;
+  int bt = 0;
+  for (int u = lo; u < hi; ++u) {
+    const float v = fmaxf(0.f, row[u] * sc + sh);
+    if (v > best) { best = v; bt = u - lo; }  // first maximum, like max_pool2d over the padded list
+  }
+  out[((size_t)bi * c + ch) * P + j] = best;
+  arg[((size_t)bi * c + ch) * P + j] = bt;
+}
+
+template <bool TOP>
+__device__ __forceinline__ float upstream_grad_c(const float *__restrict__ dA, const float *__restrict__ dOut,
+                                                 const int *__restrict__ arg, const int *__restrict__ cent,
+                                                 const int *__restrict__ sg, size_t row, size_t grow, unsigned e) {
+  if (!TOP) return dA[row + e];
+  const int j = cent[e];
+  return (arg[grow + j] == (int)e - sg[j]) ? dOut[grow + j] : 0.f;
+}
+
+template <bool TOP>
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_c_kernel(
+    int c, long E, int P, const float *__restrict__ dA, const float *__restrict__ dOut,
+    const int *__restrict__ arg, const float *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const int *__restrict__ n_act, const int *__restrict__ cent_all, const int *__restrict__ seg_all,
+    double *__restrict__ s1, double *__restrict__ s2) {
+  __shared__ float red[2][BNB_THREADS / 64];
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const unsigned En = (unsigned)n_act[bi];
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
+  if (e0 >= En) return;
+  const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
+  const int *cent = cent_all + (size_t)bi * E, *sg = seg_all + (size_t)bi * (P + 1);
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  // upstream gradients are already summed over the columns a position stands for: no weights here
+  float a1 = 0.f, a2 = 0.f;
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+    const float yv = y[row + e];
+    const float g = upstream_grad_c<TOP>(dA, dOut, arg, cent, sg, row, grow, e);
+    const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
+    a1 += dz;
+    a2 += dz * ((yv - mu) * is);
+  }
+  a1 = wave_allreduce_sum_f32(a1);
+  a2 = wave_allreduce_sum_f32(a2);
+  if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < BNB_THREADS / 64; ++w) t += (double)red[threadIdx.x][w];
+    unsafeAtomicAdd((threadIdx.x ? s2 : s1) + ch, t);
+  }
+}
+
+// dY[u] = sum over the mult[u] equal columns of gamma*invstd*(dz - S1/n - xhat*S2/n)
+//       = gamma*invstd*(dZ[u] - mult[u]*(S1/n + xhat[u]*S2/n)),  dZ[u] = the summed upstream gradient
+template <bool TOP>
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_c_kernel(
+    int c, long E, int P, double count, const float *__restrict__ dA, const float *__restrict__ dOut,
+    const int *__restrict__ arg, const float *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const int *__restrict__ n_act, const float *__restrict__ mult_all, const int *__restrict__ cent_all,
+    const int *__restrict__ seg_all, const double *__restrict__ s1, const double *__restrict__ s2,
+    float *__restrict__ dY) {
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const unsigned En = (unsigned)n_act[bi];
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
+  if (e0 >= En) return;
+  const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
+  const int *cent = cent_all + (size_t)bi * E, *sg = seg_all + (size_t)bi * (P + 1);
+  const float *mult = mult_all + (size_t)bi * E;
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS) {
+    const float yv = y[row + e];
+    const float g = upstream_grad_c<TOP>(dA, dOut, arg, cent, sg, row, grow, e);
+    const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
+    dY[row + e] = sc * (dz - mult[e] * (m1 + (yv - mu) * is * m2));
+  }
+}
+
 // ---- stand-alone batch statistics / BN+ReLU apply (small levels: the 1x1 conv is a library GEMM) ----
 // sum(y), sum(y^2) per channel of y (B, C, E); same launch geometry as the backward statistics.
 __global__ __launch_bounds__(BNB_THREADS) void channel_stats_kernel(int c, long E, const float *__restrict__ y,
@@ -638,7 +750,7 @@ template <bool PROLOGUE, bool VEC>
 __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     int cin, int cout, long E, int steps_per_wave, int nblk_n, const float *__restrict__ dY,
     const float *__restrict__ x, const float *__restrict__ pscale, const float *__restrict__ pshift,
-    float *__restrict__ dW) {
+    float *__restrict__ dW, const int *__restrict__ n_act) {
   // one private image of the 2x2 tile block per wave (plain stores), summed once at the end: four
   // waves doing ds_add_f32 onto ONE image cost ~10 us per workgroup (cf. the attention backward)
   __shared__ float s_tile[DW_WAVES][4][32][33];
@@ -671,9 +783,14 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
   // 32-row tiles without any channel are skipped, loads and MFMAs alike (uniform per workgroup)
   const int ni = (cout - co0 > 32) ? 2 : 1, nj = (cin - ci0 > 32) ? 2 : 1;
 
-  const long n_steps = (E + 31) / 32;
+  // compact mode: positions [0, n_act[b]) of every row exist (E stays the row stride); the steps are
+  // re-dealt over the launched waves so that the whole grid shares the shorter range
+  const long En = n_act ? (long)n_act[bi] : E;
+  const long n_steps = (En + 31) / 32;
+  if (n_act) steps_per_wave = (int)((n_steps + (long)gridDim.x * DW_WAVES - 1) / ((long)gridDim.x * DW_WAVES));
   const long st_begin = ((long)blockIdx.x * DW_WAVES + wave) * steps_per_wave;
   const long st_end = min(n_steps, st_begin + steps_per_wave);
+  if (n_act && (long)blockIdx.x * DW_WAVES * steps_per_wave >= n_steps) return;  // whole workgroup idle
 
   auto load_frag = [&](float (&f)[16], const float *row, long e0, bool ok) {
     const long eb = e0 + 16 * half;
@@ -711,7 +828,7 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
             if (t < nj) load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
           }
         }
-        const bool tail = !VEC && (cur * 32 + 32 > E);
+        const bool tail = (!VEC || n_act != nullptr) && (cur * 32 + 32 > En);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           float av[2], bv[2];
@@ -720,7 +837,7 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
             av[t] = aok[t] ? fa[ph][t][k] : 0.f;
             float v = fb[ph][t][k];
             if (PROLOGUE) v = fmaxf(0.f, v * bsc[t] + bsh[t]);
-            if (tail && (cur * 32 + 16 * half + k >= E)) v = 0.f;
+            if (tail && (cur * 32 + 16 * half + k >= En)) { v = 0.f; av[t] = 0.f; }  // (memory past En is not ours)
             bv[t] = bok[t] ? v : 0.f;
           }
 #pragma unroll
@@ -766,6 +883,11 @@ extern "C" int sig3d_debug_mlp_marks(unsigned long long *host_out, int *n) {
 }
 #endif
 
+// compact-mode operands of the call in flight (set by the *_compact entry points around the regular
+// dispatch, so that the four template layers below keep their signatures)
+static thread_local const int *tl_n_act = nullptr;
+static thread_local const float *tl_mult = nullptr;
+
 template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
 static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                           const float *pscale, const float *pshift, float *y, double *stat_sum,
@@ -794,7 +916,7 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
   const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
   dim3 grid(cblocks, (unsigned)gy, b);
   hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED>), grid, dim3(ML_WAVES * 64), lds, stream,
-                     cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq);
+                     cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq, tl_n_act, tl_mult);
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
   return 0;
 }
@@ -976,7 +1098,7 @@ static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, cons
   const long wgs = (n_steps + spw * DW_WAVES - 1) / (spw * DW_WAVES);
   dim3 grid((unsigned)wgs, nblk_m * nblk_n, b);
   hipLaunchKernelGGL((mlp_dw_kernel<PROLOGUE, VEC>), grid, dim3(DW_WAVES * 64), 0, stream, cin, cout, e,
-                     (int)spw, nblk_n, dY, x, pscale, pshift, dW);
+                     (int)spw, nblk_n, dY, x, pscale, pshift, dW, tl_n_act);
   SIG3D_LAUNCH_CHECK("mlp_dw_kernel");
   return 0;
 }
@@ -994,4 +1116,69 @@ extern "C" int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float 
                          : launch_mlp_dw<true, false>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
   return vec ? launch_mlp_dw<false, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
              : launch_mlp_dw<false, false>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
+}
+
+// ---- compact-mode entry points (distinct neighbours only; compact.hip) ------------------------------------
+extern "C" int sig3d_mlp_layer_fwd_compact(int b, int cin, int cout, long e, const float *x, const float *w,
+                                           const float *pscale, const float *pshift, float *y, double *stat_sum,
+                                           double *stat_sq, int accumulate, const int *n_act, const float *mult,
+                                           void *stream_) {
+  SIG3D_REQUIRE(n_act != nullptr && (stat_sum == nullptr || mult != nullptr), "n_act (and mult with statistics) required");
+  tl_n_act = n_act;
+  tl_mult = mult;
+  const int rc = sig3d_mlp_layer_fwd(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, accumulate, stream_);
+  tl_n_act = nullptr;
+  tl_mult = nullptr;
+  return rc;
+}
+
+extern "C" int sig3d_mlp_layer_dw_compact(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                          const float *pscale, const float *pshift, float *dW, int accumulate,
+                                          const int *n_act, void *stream_) {
+  SIG3D_REQUIRE(n_act != nullptr, "n_act required");
+  tl_n_act = n_act;
+  const int rc = sig3d_mlp_layer_dw(b, cin, cout, e, dY, x, pscale, pshift, dW, accumulate, stream_);
+  tl_n_act = nullptr;
+  return rc;
+}
+
+extern "C" int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const float *y, const float *scale,
+                                             const float *shift, const int *seg_off, float *out, int *arg,
+                                             void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && p >= 0 && e >= 0 && seg_off != nullptr, "bad size");
+  if (b == 0 || p == 0) return 0;
+  hipLaunchKernelGGL(bn_relu_maxpool_seg_kernel, dim3(sig3d_ceil_div(p, 256), c, b), dim3(256), 0,
+                     (hipStream_t)stream_, c, p, e, y, scale, shift, seg_off, out, arg);
+  SIG3D_LAUNCH_CHECK("bn_relu_maxpool_seg_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const float *dA, const float *dOut,
+                                         const int *arg, const float *y, const float *scale, const float *shift,
+                                         const float *mean, const float *invstd, double *s1, double *s2,
+                                         float *dY, int accumulate, const int *n_act, const float *mult,
+                                         const int *centre_of, const int *seg_off, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && e >= 0 && p >= 1, "bad size");
+  SIG3D_REQUIRE((dA != nullptr) != (dOut != nullptr && arg != nullptr),
+                "pass either a dense dA or the (dOut, arg) pair of the max-pool");
+  SIG3D_REQUIRE(n_act && mult && centre_of && seg_off, "compact lists missing");
+  SIG3D_REQUIRE(e < (1L << 31), "positions per row must stay below 2^31");
+  if (int rc = zero_pair(s1, s2, c, accumulate, stream)) return rc;
+  if (b == 0 || e == 0) return 0;
+  const double count = (double)b * (double)e;  // the statistics are over ALL columns, padded ones included
+  dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
+  if (dA) {
+    hipLaunchKernelGGL((bn_relu_bwd_stats_c_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, dA, dOut, arg,
+                       y, scale, shift, mean, invstd, n_act, centre_of, seg_off, s1, s2);
+    hipLaunchKernelGGL((bn_relu_bwd_apply_c_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, count, dA,
+                       dOut, arg, y, scale, shift, mean, invstd, n_act, mult, centre_of, seg_off, s1, s2, dY);
+  } else {
+    hipLaunchKernelGGL((bn_relu_bwd_stats_c_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, dA, dOut, arg,
+                       y, scale, shift, mean, invstd, n_act, centre_of, seg_off, s1, s2);
+    hipLaunchKernelGGL((bn_relu_bwd_apply_c_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, count, dA,
+                       dOut, arg, y, scale, shift, mean, invstd, n_act, mult, centre_of, seg_off, s1, s2, dY);
+  }
+  SIG3D_LAUNCH_CHECK("bn_relu_bwd compact kernels");
+  return 0;
 }

@@ -17,7 +17,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .pointnet2 import _ext
+from .pointnet2 import _ext, fused_mlp
 
 
 class GeometryPlan:
@@ -26,7 +26,7 @@ class GeometryPlan:
     def __init__(self, batch, n_points, levels, device):
         self.levels = list(levels)
         self.batch, self.n_points = batch, n_points
-        self.inds, self.new_xyz, self.ball_idx, self._temp = [], [], [], []
+        self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self._bq_work = None  # scratch of the grid ball query (allocated once: static under hipGraph)
         n = n_points
         for npoint, radius, nsample in self.levels:
@@ -34,6 +34,9 @@ class GeometryPlan:
             self.new_xyz.append(torch.zeros(batch, npoint, 3, dtype=torch.float32, device=device))
             self.ball_idx.append(torch.zeros(batch, npoint, nsample, dtype=torch.int32, device=device))
             self._temp.append(torch.zeros(batch, max(n, 128), dtype=torch.float32, device=device))
+            # distinct neighbours of the padded lists (csrc/compact.hip), for the levels that run the MFMA path
+            big = fused_mlp.COMPACT and batch * npoint * nsample >= fused_mlp.MIN_POSITIONS
+            self.compact.append(fused_mlp.CompactLists(batch, npoint, nsample, device) if big else None)
             n = npoint
 
     def compute(self, xyz):
@@ -61,13 +64,19 @@ class GeometryPlan:
                 else:
                     _lib.call("sig3d_ball_query", b, n, npoint, ctypes.c_float(radius), nsample,
                               _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
+                if self.compact[lvl] is not None:
+                    self.compact[lvl].compute(self.ball_idx[lvl])
                 cur, n = self.new_xyz[lvl], npoint
         return self
 
     def level(self, i):
-        return self.inds[i], self.new_xyz[i], self.ball_idx[i]
+        return self.inds[i], self.new_xyz[i], self.ball_idx[i], self.compact[i]
 
     def copy_from(self, other):
         for a, b in zip(self.inds + self.new_xyz + self.ball_idx,
                         other.inds + other.new_xyz + other.ball_idx):
             a.copy_(b, non_blocking=True)
+        for mine, theirs in zip(self.compact, other.compact):
+            if mine is not None:
+                for a, b in zip(mine.tensors(), theirs.tensors()):
+                    a.copy_(b, non_blocking=True)

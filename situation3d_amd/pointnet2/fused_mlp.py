@@ -10,6 +10,7 @@ place like nn.BatchNorm2d), so this is a pure execution-path change; `can_fuse` 
 given SharedMLP / call qualifies, otherwise the caller keeps the layer-by-layer torch path.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -62,6 +63,91 @@ def can_fuse(mlp, x, min_positions=None):
     return not needs_grad
 
 
+class CompactLists:
+    """Distinct (centre, neighbour) pairs of a ball-query result (csrc/compact.hip): the first n_act[b]
+    entries of every row of cidx / centre_of / mult are defined, seg_off[b, j] is the first entry of centre j.
+    Buffers are allocated once (static under hipGraph) and refilled by compute()."""
+
+    def __init__(self, batch, npoint, nsample, device):
+        e = npoint * nsample
+        self.shape = (batch, npoint, nsample)
+        self.cidx = torch.zeros(batch, e, dtype=torch.int32, device=device)
+        self.centre_of = torch.zeros(batch, e, dtype=torch.int32, device=device)
+        self.mult = torch.zeros(batch, e, dtype=torch.float32, device=device)
+        self.seg_off = torch.zeros(batch, npoint + 1, dtype=torch.int32, device=device)
+        self.n_act = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def compute(self, idx):
+        assert tuple(idx.shape) == self.shape and idx.dtype == torch.int32 and idx.is_contiguous()
+        b, m, ns = self.shape
+        with torch.cuda.device(idx.device):
+            _lib.call("sig3d_compact_neighbour_lists", b, m, ns, _lib.ptr(idx), _lib.ptr(self.cidx),
+                      _lib.ptr(self.centre_of), _lib.ptr(self.mult), _lib.ptr(self.seg_off), _lib.ptr(self.n_act),
+                      _lib.stream_ptr(idx.device))
+        return self
+
+    def tensors(self):
+        return self.cidx, self.centre_of, self.mult, self.seg_off, self.n_act
+
+
+def compact_lists(idx):
+    return CompactLists(idx.shape[0], idx.shape[1], idx.shape[2], idx.device).compute(idx.contiguous())
+
+
+# SIG3D_COMPACT=0 keeps every set-abstraction level dense
+COMPACT = os.environ.get("SIG3D_COMPACT", "1") != "0"
+
+
+class _QueryGroupCompact(torch.autograd.Function):
+    """QueryAndGroup's grouped tensor (pointnet2_utils.py:348-359) for the DISTINCT neighbours only:
+    out (B, 3+C, npoint, nsample) where only the first n_act[b] positions of every row are written."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, cidx, centre_of, n_act, nsample, radius, use_xyz, normalize_xyz):
+        dev = _lib.require_device(xyz, new_xyz, features, cidx)
+        b, n, _ = xyz.shape
+        m = new_xyz.shape[1]
+        c = 0 if features is None else features.shape[1]
+        c_total = (3 if use_xyz else 0) + c
+        out = torch.empty((b, c_total, m, nsample), dtype=torch.float32, device=dev)
+        wide = c >= 32 and c % 4 == 0
+        feat_pm = None
+        with torch.cuda.device(dev):
+            if wide:
+                feat_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                _lib.call("sig3d_transpose_cn", b, c, n, _lib.ptr(features), _lib.ptr(feat_pm), _lib.stream_ptr(dev))
+            _lib.call("sig3d_query_group_compact", b, n, m, c, c, nsample, int(use_xyz), int(normalize_xyz),
+                      ctypes.c_float(radius), _lib.ptr(xyz), _lib.ptr(new_xyz), _lib.ptr(features),
+                      _lib.ptr(feat_pm), _lib.ptr(cidx), _lib.ptr(centre_of), _lib.ptr(n_act), _lib.ptr(out),
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(cidx, n_act)
+        ctx.dims = (b, n, m, c, nsample, c_total, 3 if use_xyz else 0, wide)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        cidx, n_act = ctx.saved_tensors
+        b, n, m, c, nsample, c_total, c_off, wide = ctx.dims
+        grad_features = None
+        if c > 0 and ctx.needs_input_grad[2]:
+            grad_out = grad_out.contiguous()
+            dev = grad_out.device
+            grad_features = torch.empty((b, c, n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                if wide:
+                    grad_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_query_group_compact_grad", b, n, m, c, c, nsample, c_total, c_off,
+                              _lib.ptr(grad_out), _lib.ptr(cidx), _lib.ptr(n_act), 1, _lib.ptr(grad_pm),
+                              _lib.stream_ptr(dev))
+                    _lib.call("sig3d_transpose_cn", b, n, c, _lib.ptr(grad_pm), _lib.ptr(grad_features),
+                              _lib.stream_ptr(dev))
+                else:
+                    _lib.call("sig3d_query_group_compact_grad", b, n, m, c, c, nsample, c_total, c_off,
+                              _lib.ptr(grad_out), _lib.ptr(cidx), _lib.ptr(n_act), 0, _lib.ptr(grad_features),
+                              _lib.stream_ptr(dev))
+        return None, None, grad_features, None, None, None, None, None, None, None
+
+
 def _aff_rows(t):
     return t[0], t[1], t[2], t[3]  # scale, shift, mean, invstd
 
@@ -74,9 +160,14 @@ class _FusedMLPMax(torch.autograd.Function):
     separate ReLU / threshold / max-reduce / scatter launches."""
 
     @staticmethod
-    def forward(ctx, x, layers, library_gemm, *flat):
+    def forward(ctx, x, layers, library_gemm, compact, *flat):
         # flat = (W_1, gamma_1, beta_1, W_2, gamma_2, beta_2, ...) so that autograd tracks them
+        # compact: None, or CompactLists.tensors(): x then holds the DISTINCT neighbours only (first n_act[b]
+        # positions of every row) and every kernel below runs in compact mode (csrc/compact.hip)
         dev = x.device
+        if compact is not None:
+            assert not library_gemm
+            c_cidx, c_cent, c_mult, c_seg, c_nact = compact
         x = x.contiguous()
         b, c0, p, s = x.shape
         e = p * s
@@ -102,6 +193,11 @@ class _FusedMLPMax(torch.autograd.Function):
                     y = torch.bmm(w.unsqueeze(0).expand(b, cout, cin), act.view(b, cin, e)).view(b, cout, p, s)
                     _lib.call("sig3d_channel_stats", b, cout, e, _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
                               1, stream)
+                elif compact is not None:
+                    y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_mlp_layer_fwd_compact", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
+                              _lib.ptr(ps), _lib.ptr(pb), _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
+                              1, _lib.ptr(c_nact), _lib.ptr(c_mult), stream)
                 else:
                     y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
                     _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
@@ -121,9 +217,14 @@ class _FusedMLPMax(torch.autograd.Function):
             c_last = ws[-1].shape[0]
             out = torch.empty((b, c_last, p), dtype=torch.float32, device=dev)
             arg = torch.empty((b, c_last, p), dtype=torch.int32, device=dev)
-            _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps),
-                      _lib.ptr(pb), _lib.ptr(out), _lib.ptr(arg), stream)
+            if compact is not None:
+                _lib.call("sig3d_bn_relu_maxpool_compact", b, c_last, p, e, _lib.ptr(cur), _lib.ptr(ps),
+                          _lib.ptr(pb), _lib.ptr(c_seg), _lib.ptr(out), _lib.ptr(arg), stream)
+            else:
+                _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps),
+                          _lib.ptr(pb), _lib.ptr(out), _lib.ptr(arg), stream)
         ctx.save_for_backward(x, arg, *ys, *affs, *ws)
+        ctx.compact = compact
         ctx.nl = len(layers)
         ctx.dims = (b, p, s)
         ctx.library_gemm = library_gemm
@@ -144,6 +245,9 @@ class _FusedMLPMax(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grads = [None] * (3 * nl)
         grad_x = None
+        compact = ctx.compact
+        if compact is not None:
+            c_cidx, c_cent, c_mult, c_seg, c_nact = compact
         with torch.cuda.device(dev):
             dA = None
             # one fill each for every BatchNorm-gradient accumulator and every dW of the stack
@@ -158,7 +262,14 @@ class _FusedMLPMax(torch.autograd.Function):
                 scale, shift, mean, invstd = _aff_rows(affs[k])
                 sums = sums_all[k]
                 dY = torch.empty_like(ys[k])
-                if k == nl - 1:
+                if compact is not None:
+                    top = k == nl - 1
+                    _lib.call("sig3d_bn_relu_bwd_compact", b, cout, e, p, _lib.ptr(None if top else dA),
+                              _lib.ptr(grad_out if top else None), _lib.ptr(arg if top else None), _lib.ptr(ys[k]),
+                              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]),
+                              _lib.ptr(sums[1]), _lib.ptr(dY), 1, _lib.ptr(c_nact), _lib.ptr(c_mult),
+                              _lib.ptr(c_cent), _lib.ptr(c_seg), stream)
+                elif k == nl - 1:
                     _lib.call("sig3d_bn_relu_bwd", b, cout, e, s, _lib.ptr(None), _lib.ptr(grad_out),
                               _lib.ptr(arg), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
@@ -173,8 +284,12 @@ class _FusedMLPMax(torch.autograd.Function):
                 ppb = affs[k - 1][1] if k > 0 else None
                 dW = dw_all[dw_off:dw_off + cout * cin].view(cout, cin)
                 dw_off += cout * cin
-                _lib.call("sig3d_mlp_layer_dw", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
-                          _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, stream)
+                if compact is not None:
+                    _lib.call("sig3d_mlp_layer_dw_compact", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
+                              _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, _lib.ptr(c_nact), stream)
+                else:
+                    _lib.call("sig3d_mlp_layer_dw", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
+                              _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, stream)
                 grads[3 * k] = dW.view(cout, cin, 1, 1)
                 if k > 0 or ctx.needs_input_grad[0]:
                     if ctx.library_gemm:
@@ -182,9 +297,14 @@ class _FusedMLPMax(torch.autograd.Function):
                     else:
                         wt = ws[k].t().contiguous()  # (cin, cout): dA = W^T dY through the same GEMM
                         dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
-                        _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
-                                  _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
-                                  _lib.ptr(None), 0, stream)   # no statistics for an input gradient
+                        if compact is not None:
+                            _lib.call("sig3d_mlp_layer_fwd_compact", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
+                                      _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
+                                      _lib.ptr(None), 0, _lib.ptr(c_nact), _lib.ptr(None), stream)
+                        else:
+                            _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
+                                      _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
+                                      _lib.ptr(None), 0, stream)   # no statistics for an input gradient
                     if k == 0:
                         grad_x = dA
             sums32 = sums_all.to(torch.float32)                # one conversion launch for the whole stack
@@ -192,7 +312,7 @@ class _FusedMLPMax(torch.autograd.Function):
                 cout = ws[k].shape[0]
                 grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma
                 grads[3 * k + 2] = sums32[k, 0, :cout]         # d beta
-        return (grad_x, None, None) + tuple(grads)
+        return (grad_x, None, None, None) + tuple(grads)
 
 
 def _fused_mlp_max_eval(layers, x):
@@ -234,4 +354,29 @@ def fused_mlp_max(mlp, x, library_gemm=None):
         flat += [conv.weight, bn.weight, bn.bias]
     if library_gemm is None:
         library_gemm = x.shape[0] * x.shape[2] * x.shape[3] < MIN_POSITIONS
-    return _FusedMLPMax.apply(x, layers, bool(library_gemm), *flat)
+    return _FusedMLPMax.apply(x, layers, bool(library_gemm), None, *flat)
+
+
+def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_xyz, normalize_xyz):
+    """One set-abstraction level over the distinct neighbours only (training mode, MFMA path):
+    grouped tensor -> SharedMLP -> max over the neighbourhood, same result as the dense path up to
+    floating-point summation order.  compact: CompactLists of this level's ball-query result."""
+    layers = _layers(mlp)
+    cidx, centre_of, mult, seg_off, n_act = compact.tensors()
+    feats = None if features is None else features.contiguous()
+    x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
+                                 float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
+    flat = []
+    for conv, bn in layers:
+        flat += [conv.weight, bn.weight, bn.bias]
+    return _FusedMLPMax.apply(x, layers, False, (cidx, centre_of, mult, seg_off, n_act), *flat)
+
+
+def compact_applies(mlp, xyz, features, npoint, nsample):
+    """Compact mode serves the training-mode MFMA path (large levels) of plain max-pooled SA layers."""
+    if not (COMPACT and mlp.training and xyz.is_cuda and _layers(mlp) is not None):
+        return False
+    if features is not None and (not features.is_cuda or features.dtype != torch.float32):
+        return False
+    differentiable_xyz = torch.is_grad_enabled() and xyz.requires_grad
+    return (not differentiable_xyz) and xyz.shape[0] * npoint * nsample >= MIN_POSITIONS

@@ -127,10 +127,32 @@ class PointnetSAModuleVotes(nn.Module):
                 inds: torch.Tensor = None, geometry=None):
         """`geometry` (optional, not in the reference signature): a precomputed
         (inds, new_xyz, ball_idx) triple for this layer from geometry.GeometryPlan."""
+        compactable = (self.pooling == 'max' and self.npoint is not None and not self.ret_unique_cnt
+                       and not getattr(self.grouper, "sample_uniformly", True)
+                       and fused_mlp.compact_applies(self.mlp_module, xyz, features, self.npoint, self.nsample))
+        if geometry is not None and compactable:
+            # distinct neighbours only: ball query pads short lists with copies of the first hit, and a copy
+            # is an identical column all the way up to the max-pool (csrc/compact.hip)
+            inds, new_xyz, ball_idx = geometry[:3]
+            compact = geometry[3] if len(geometry) > 3 and geometry[3] is not None else fused_mlp.compact_lists(ball_idx)
+            new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features, compact, self.nsample,
+                                                      self.grouper.radius, self.grouper.use_xyz,
+                                                      self.grouper.normalize_xyz)
+            return new_xyz, new_features, inds
         if geometry is not None:
-            inds, new_xyz, ball_idx = geometry
+            inds, new_xyz, ball_idx = geometry[:3]
             assert inds.shape[1] == self.npoint
             grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
+        elif compactable:
+            if inds is not None:
+                assert inds.shape[1] == self.npoint
+            new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
+            ball_idx = pointnet2_utils.ball_query(self.grouper.radius, self.nsample, xyz, new_xyz)
+            new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features,
+                                                      fused_mlp.compact_lists(ball_idx), self.nsample,
+                                                      self.grouper.radius, self.grouper.use_xyz,
+                                                      self.grouper.normalize_xyz)
+            return new_xyz, new_features, inds
         else:
             if inds is not None:
                 assert inds.shape[1] == self.npoint

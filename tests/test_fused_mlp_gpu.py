@@ -61,8 +61,10 @@ def test_fused_path_is_taken_by_sa_module_in_train_and_inference():
                                                   use_xyz=True).to(DEV)
     xyz, f = scene(2, 500, seed=1).to(DEV), feats(2, 5, 500).to(DEV)
     calls = []
-    orig, orig_min = fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS
+    orig, orig_min, orig_c = fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS, fused_mlp.fused_sa_compact
     fused_mlp.fused_mlp_max = lambda m, x: calls.append(1) or orig(m, x)
+    # training mode above MIN_POSITIONS runs over the distinct neighbours only: also a fused path
+    fused_mlp.fused_sa_compact = lambda *a, **k: calls.append(1) or orig_c(*a, **k)
     fused_mlp.MIN_POSITIONS = 0
     try:
         mod.train()
@@ -76,7 +78,7 @@ def test_fused_path_is_taken_by_sa_module_in_train_and_inference():
         assert calls == [1, 1]
         torch.testing.assert_close(cc, bb, rtol=1e-4, atol=1e-4)
     finally:
-        fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS = orig, orig_min
+        fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS, fused_mlp.fused_sa_compact = orig, orig_min, orig_c
     assert a.shape == bb.shape == (2, 64, 64)
 
 
@@ -102,3 +104,73 @@ def test_bn_relu_maxpool_first_maximum_on_ties(s):
            L.stream_ptr())
     assert torch.equal(out.cpu(), exp.squeeze(-1))
     assert torch.equal(arg.cpu().long(), idx.squeeze(-1) % s)
+
+
+@pytest.mark.parametrize("c_feat,mlp,npoint,nsample,radius", [(3, [3, 64, 64, 128], 1024, 64, 0.2),
+                                                               (128, [128, 128, 128, 256], 1024, 32, 0.4),
+                                                               (36, [36, 32, 64], 2048, 32, 0.3)])
+def test_compact_sa_level_matches_dense(c_feat, mlp, npoint, nsample, radius):
+    """One SA level over the DISTINCT neighbours only (csrc/compact.hip) against the dense fused path:
+    outputs, input-feature gradient, every weight / BatchNorm gradient and the running statistics.
+    Same arithmetic up to summation order: 2e-5 relative to the largest magnitude (observed ~1e-6)."""
+    import copy
+    from situation3d_amd.pointnet2 import fused_mlp
+    from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(7)
+    b, n = 2, 6000
+    xyz = (torch.rand(b, n, 3) * torch.tensor([8.0, 8.0, 3.0])).to(DEV)
+    feats = torch.randn(b, c_feat, n).to(DEV)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=nsample, mlp=list(mlp), use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sa2 = copy.deepcopy(sa)
+    g = None
+    results = []
+    for module, compact in ((sa, True), (sa2, False)):
+        fused_mlp.COMPACT = compact
+        try:
+            f = feats.clone().requires_grad_(True)
+            new_xyz, out, inds = module(xyz, f)
+            if g is None:
+                g = torch.randn_like(out)
+            (out * g).sum().backward()
+        finally:
+            fused_mlp.COMPACT = True
+        results.append((out.detach(), f.grad, [p.grad for p in module.parameters()],
+                        [bf.clone() for bf in module.buffers()]))
+    (o1, f1, p1, b1), (o2, f2, p2, b2) = results
+
+    def close(a, b_, what):
+        err = (a - b_).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b_.abs().max().item()), (what, err)
+    close(o1, o2, "output")
+    close(f1, f2, "feature gradient")
+    for i, (a, b_) in enumerate(zip(p1, p2)):
+        close(a, b_, "parameter gradient %d" % i)
+    for i, (a, b_) in enumerate(zip(b1, b2)):
+        close(a.float(), b_.float(), "buffer %d" % i)
+
+
+def test_compact_lists_structure():
+    """sig3d_compact_neighbour_lists against a direct construction from the padded lists."""
+    from situation3d_amd.pointnet2 import fused_mlp
+    g = torch.Generator().manual_seed(3)
+    b, m, ns, n = 3, 300, 16, 900
+    idx = torch.zeros(b, m, ns, dtype=torch.int32)
+    for bi in range(b):
+        for j in range(m):
+            k = int(torch.randint(1, ns + 1, (1,), generator=g))
+            hits = torch.sort(torch.randperm(n, generator=g)[:k]).values.int()
+            idx[bi, j, :k] = hits
+            idx[bi, j, k:] = hits[0]
+    cl = fused_mlp.compact_lists(idx.to(DEV))
+    cidx, cent, mult, seg, nact = [t.cpu() for t in cl.tensors()]
+    for bi in range(b):
+        u = 0
+        for j in range(m):
+            row = idx[bi, j]
+            k = 1 + int((row[1:] != row[0]).sum())
+            assert seg[bi, j] == u
+            assert torch.equal(cidx[bi, u:u + k], row[:k]) and (cent[bi, u:u + k] == j).all()
+            assert mult[bi, u] == ns - k + 1 and (mult[bi, u + 1:u + k] == 1).all()
+            u += k
+        assert seg[bi, m] == u and nact[bi] == u
