@@ -35,7 +35,7 @@ class GeometryPlan:
             self.ball_idx.append(torch.zeros(batch, npoint, nsample, dtype=torch.int32, device=device))
             self._temp.append(torch.zeros(batch, max(n, 128), dtype=torch.float32, device=device))
             # distinct neighbours of the padded lists (csrc/compact.hip), for the levels that run the MFMA path
-            big = fused_mlp.COMPACT and batch * npoint * nsample >= fused_mlp.MIN_POSITIONS
+            big = fused_mlp.COMPACT and batch * npoint * nsample >= fused_mlp.COMPACT_MIN_POSITIONS
             self.compact.append(fused_mlp.CompactLists(batch, npoint, nsample, device) if big else None)
             n = npoint
 

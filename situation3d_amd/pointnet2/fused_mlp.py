@@ -96,6 +96,8 @@ def compact_lists(idx):
 
 # SIG3D_COMPACT=0 keeps every set-abstraction level dense
 COMPACT = os.environ.get("SIG3D_COMPACT", "1") != "0"
+# levels with at least this many (dense) positions run compact; the others keep the library-GEMM hybrid
+COMPACT_MIN_POSITIONS = int(os.environ.get("SIG3D_COMPACT_MIN_POSITIONS", str(MIN_POSITIONS)))
 
 
 class _QueryGroupCompact(torch.autograd.Function):
@@ -315,10 +317,11 @@ class _FusedMLPMax(torch.autograd.Function):
         return (grad_x, None, None, None) + tuple(grads)
 
 
-def _fused_mlp_max_eval(layers, x):
+def _fused_mlp_max_eval(layers, x, compact=None):
     """Inference: BatchNorm2d.eval() is the affine map scale = gamma / sqrt(running_var + eps),
     shift = beta - running_mean * scale, so a layer is one sig3d_mlp_layer_fwd (previous layer's
-    BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool."""
+    BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool.
+    compact: CompactLists.tensors() when x holds the distinct neighbours only."""
     dev = x.device
     x = x.contiguous()
     b, _, p, s = x.shape
@@ -330,16 +333,25 @@ def _fused_mlp_max_eval(layers, x):
             w = conv.weight.reshape(conv.out_channels, conv.in_channels).contiguous()
             cout, cin = w.shape
             y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
-            _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w), _lib.ptr(ps),
-                      _lib.ptr(pb), _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0, stream)
+            if compact is not None:
+                _lib.call("sig3d_mlp_layer_fwd_compact", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w), _lib.ptr(ps),
+                          _lib.ptr(pb), _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0, _lib.ptr(compact[4]),
+                          _lib.ptr(None), stream)
+            else:
+                _lib.call("sig3d_mlp_layer_fwd", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w), _lib.ptr(ps),
+                          _lib.ptr(pb), _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0, stream)
             scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
             shift = (bn.bias - bn.running_mean * scale).contiguous()
             cur, ps, pb = y, scale, shift
         c_last = cur.shape[1]
         out = torch.empty((b, c_last, p), dtype=torch.float32, device=dev)
         arg = torch.empty((b, c_last, p), dtype=torch.int32, device=dev)
-        _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
-                  _lib.ptr(out), _lib.ptr(arg), stream)
+        if compact is not None:
+            _lib.call("sig3d_bn_relu_maxpool_compact", b, c_last, p, e, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                      _lib.ptr(compact[3]), _lib.ptr(out), _lib.ptr(arg), stream)
+        else:
+            _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                      _lib.ptr(out), _lib.ptr(arg), stream)
     return out
 
 
@@ -366,6 +378,8 @@ def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_
     feats = None if features is None else features.contiguous()
     x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
                                  float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
+    if not mlp.training:
+        return _fused_mlp_max_eval(layers, x, (cidx, centre_of, mult, seg_off, n_act))
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
@@ -373,10 +387,16 @@ def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_
 
 
 def compact_applies(mlp, xyz, features, npoint, nsample):
-    """Compact mode serves the training-mode MFMA path (large levels) of plain max-pooled SA layers."""
-    if not (COMPACT and mlp.training and xyz.is_cuda and _layers(mlp) is not None):
+    """Compact mode serves the MFMA path (large levels) of plain max-pooled SA layers: training mode, and
+    eval mode when no gradient is wanted (the fused inference path)."""
+    if not (COMPACT and xyz.is_cuda and _layers(mlp) is not None):
         return False
+    if not mlp.training:
+        wants_grad = torch.is_grad_enabled() and ((features is not None and features.requires_grad)
+                                                  or any(p.requires_grad for p in mlp.parameters()))
+        if wants_grad:
+            return False
     if features is not None and (not features.is_cuda or features.dtype != torch.float32):
         return False
     differentiable_xyz = torch.is_grad_enabled() and xyz.requires_grad
-    return (not differentiable_xyz) and xyz.shape[0] * npoint * nsample >= MIN_POSITIONS
+    return (not differentiable_xyz) and xyz.shape[0] * npoint * nsample >= COMPACT_MIN_POSITIONS

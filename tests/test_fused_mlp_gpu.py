@@ -148,6 +148,18 @@ def test_compact_sa_level_matches_dense(c_feat, mlp, npoint, nsample, radius):
         close(a, b_, "parameter gradient %d" % i)
     for i, (a, b_) in enumerate(zip(b1, b2)):
         close(a.float(), b_.float(), "buffer %d" % i)
+    # the fused inference path (eval mode, no gradient) takes the compact route too
+    sa.eval()
+    sa2.load_state_dict(sa.state_dict())
+    sa2.eval()
+    with torch.no_grad():
+        e1 = sa(xyz, feats)[1]
+        fused_mlp.COMPACT = False
+        try:
+            e2 = sa2(xyz, feats)[1]
+        finally:
+            fused_mlp.COMPACT = True
+    close(e1, e2, "eval output")
 
 
 def test_compact_lists_structure():
