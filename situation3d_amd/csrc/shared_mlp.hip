@@ -673,6 +673,66 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_c_kernel(
   }
 }
 
+// Top layer (upstream gradient = max-pool gradient): only the arg-max entry of a centre's segment carries
+// gradient, so the statistics need ONE gathered y per (batch, channel, centre) and the apply pass splits into
+// a coalesced sweep (the correction term of every position) plus one fix-up per centre.
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_stats_c_kernel(
+    int c, long E, int P, const float *__restrict__ dOut, const int *__restrict__ arg,
+    const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const int *__restrict__ seg_all,
+    double *__restrict__ s1, double *__restrict__ s2) {
+  __shared__ float red[2][BNB_THREADS / 64];
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
+  const int *sg = seg_all + (size_t)bi * (P + 1);
+  const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
+  float a1 = 0.f, a2 = 0.f;
+  for (int j = blockIdx.x * BNB_THREADS + threadIdx.x; j < P; j += gridDim.x * BNB_THREADS) {
+    const float yv = y[row + sg[j] + arg[grow + j]];
+    const float dz = (yv * sc + sh > 0.f) ? dOut[grow + j] : 0.f;
+    a1 += dz;
+    a2 += dz * ((yv - mu) * is);
+  }
+  a1 = wave_allreduce_sum_f32(a1);
+  a2 = wave_allreduce_sum_f32(a2);
+  if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double t = 0.0;
+    for (int w = 0; w < BNB_THREADS / 64; ++w) t += (double)red[threadIdx.x][w];
+    unsafeAtomicAdd((threadIdx.x ? s2 : s1) + ch, t);
+  }
+}
+
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_sweep_c_kernel(
+    int c, long E, double count, const float *__restrict__ y, const float *__restrict__ scale,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const int *__restrict__ n_act,
+    const float *__restrict__ mult_all, const double *__restrict__ s1, const double *__restrict__ s2,
+    float *__restrict__ dY) {
+  const int ch = blockIdx.y, bi = blockIdx.z;
+  const unsigned En = (unsigned)n_act[bi];
+  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
+  if (e0 >= En) return;
+  const size_t row = ((size_t)bi * c + ch) * E;
+  const float *mult = mult_all + (size_t)bi * E;
+  const float sc = scale[ch], mu = mean[ch], is = invstd[ch];
+  const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
+  for (unsigned e = e0 + threadIdx.x; e < e1; e += BNB_THREADS)
+    dY[row + e] = -sc * mult[e] * (m1 + (y[row + e] - mu) * is * m2);
+}
+
+__global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_fix_c_kernel(
+    int c, long E, int P, const float *__restrict__ dOut, const int *__restrict__ arg,
+    const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+    const int *__restrict__ seg_all, float *__restrict__ dY) {
+  const int ch = blockIdx.y, bi = blockIdx.z, j = blockIdx.x * BNB_THREADS + threadIdx.x;
+  if (j >= P) return;
+  const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
+  const size_t u = row + seg_all[(size_t)bi * (P + 1) + j] + arg[grow + j];
+  const float sc = scale[ch], sh = shift[ch];
+  if (y[u] * sc + sh > 0.f) dY[u] += sc * dOut[grow + j];  // one writer per position: segments are disjoint
+}
+
 // ---- stand-alone batch statistics / BN+ReLU apply (small levels: the 1x1 conv is a library GEMM) ----
 // sum(y), sum(y^2) per channel of y (B, C, E); same launch geometry as the backward statistics.
 __global__ __launch_bounds__(BNB_THREADS) void channel_stats_kernel(int c, long E, const float *__restrict__ y,
@@ -1174,10 +1234,13 @@ extern "C" int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const floa
     hipLaunchKernelGGL((bn_relu_bwd_apply_c_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, count, dA,
                        dOut, arg, y, scale, shift, mean, invstd, n_act, mult, centre_of, seg_off, s1, s2, dY);
   } else {
-    hipLaunchKernelGGL((bn_relu_bwd_stats_c_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, dA, dOut, arg,
-                       y, scale, shift, mean, invstd, n_act, centre_of, seg_off, s1, s2);
-    hipLaunchKernelGGL((bn_relu_bwd_apply_c_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, count, dA,
-                       dOut, arg, y, scale, shift, mean, invstd, n_act, mult, centre_of, seg_off, s1, s2, dY);
+    dim3 ggrid(sig3d_ceil_div(p, BNB_THREADS), c, b);
+    hipLaunchKernelGGL(bn_relu_bwd_top_stats_c_kernel, dim3(p >= 4 * BNB_THREADS ? 4 : 1, c, b), dim3(BNB_THREADS), 0,
+                       stream, c, e, p, dOut, arg, y, scale, shift, mean, invstd, seg_off, s1, s2);
+    hipLaunchKernelGGL(bn_relu_bwd_top_sweep_c_kernel, grid, dim3(BNB_THREADS), 0, stream, c, e, count, y, scale, mean,
+                       invstd, n_act, mult, s1, s2, dY);
+    hipLaunchKernelGGL(bn_relu_bwd_top_fix_c_kernel, ggrid, dim3(BNB_THREADS), 0, stream, c, e, p, dOut, arg, y, scale,
+                       shift, seg_off, dY);
   }
   SIG3D_LAUNCH_CHECK("bn_relu_bwd compact kernels");
   return 0;
