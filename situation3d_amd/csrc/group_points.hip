@@ -234,6 +234,7 @@ constexpr int GPM_C = 128;   // channels per tile
 
 // Compact mode (centre_of / n_act given, compact.hip): idx holds the DISTINCT neighbours of a batch element
 // back to back, centre_of their centres, n_act[b] how many there are; positions >= n_act[b] are not written.
+template <bool COMPACT>
 __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
     int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
   const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stride = m * nsample;                       // positions per (batch, channel) row of out
-  const int total = n_act ? n_act[bi] : stride;         // positions that exist
+  const int total = COMPACT ? n_act[bi] : stride;       // positions that exist
   const int e0 = blockIdx.x * GPM_P;
   if (e0 >= total) return;
   const int c_total = (use_xyz ? 3 : 0) + c;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
   if (use_xyz && blockIdx.y == 0 && wave == 0) {
     const int e = e0 + lane;
     if (e < total) {
-      const int a = ip[e], jc = centre_of ? centre_of[(size_t)bi * stride + e] : e / nsample;
+      const int a = ip[e], jc = COMPACT ? centre_of[(size_t)bi * stride + e] : e / nsample;
       const float *pt = xyz + ((size_t)bi * n + a) * 3;
       const float *ctr = new_xyz + ((size_t)bi * m + jc) * 3;
 #pragma unroll
@@ -561,8 +562,12 @@ static int launch_group_pm(int b, int n, int m, int c, int ld, int nsample, int 
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused_pm: n must be >= 1 when idx is non-empty");
   dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
-  hipLaunchKernelGGL(query_group_fused_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample, use_xyz,
-                     normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
+  if (n_act != nullptr)
+    hipLaunchKernelGGL(query_group_fused_pm_kernel<true>, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample,
+                       use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
+  else
+    hipLaunchKernelGGL(query_group_fused_pm_kernel<false>, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample,
+                       use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
   SIG3D_LAUNCH_CHECK("query_group_fused_pm_kernel");
   return 0;
 }
