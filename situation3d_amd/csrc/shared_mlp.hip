@@ -98,6 +98,8 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   const int nt_act = min(NT, (cout - co0 + 31) / 32);  // 32-channel tiles of this block that hold channels
   float *s_tr = s_red + ML_WAVES * 2 * CT + wave * (16 * ML_TRLD);  // [ML_WAVES][16][ML_TRLD], wave-private
 
+  // compact mode: the grid is sized for the dense row; workgroups without a tile leave before staging weights
+  if (n_act != nullptr && (long)blockIdx.y * ML_WAVES * 32 >= (long)n_act[bi]) return;
   ML_MARK(0);
   // weight tile -> LDS: a wave takes 8 rows at a time and issues their (clamped, unconditional)
   // loads together; one load -> wait -> ds_write per element took 20 us per workgroup at 128x128
