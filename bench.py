@@ -239,6 +239,13 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_query_group_fused.json")
         if os.path.exists(pmc):
             traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
+        compact_info = {}
+        plan = getattr(graphed, "plan_cur", None) if use_graph else None
+        if plan is not None:
+            for li, cl in enumerate(plan.compact):
+                if cl is not None:
+                    bsz, mpt, nsm = cl.shape
+                    compact_info["SA%d" % (li + 1)] = round(float(cl.n_act.float().mean().item()) / (mpt * nsm), 4)
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -266,6 +273,9 @@ def main():
                                     "point_major_transposes": round(sum(tr) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
                                     "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},
+            # set-abstraction levels that ran over the distinct neighbours only, with the fraction of their
+            # (centre, sample) positions that are distinct on this batch
+            "compact_levels": compact_info,
             "launch_mode": "hipGraph replay" if use_graph else "eager",
             "library_gemms": "default heuristic" if args.no_gemm_tuning else "tuned (TunableOp)",
             "final_loss": round(final_loss, 5),
