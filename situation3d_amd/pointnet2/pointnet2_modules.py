@@ -123,6 +123,22 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
+    # compact mode is kept for a layer while at most this fraction of its (centre, sample) positions is distinct
+    COMPACT_MAX_FRACTION = 0.6
+
+    def _compact_pays(self, compact):
+        """Decided ONCE per layer from the first batch it sees (one host read of the counts, outside any
+        hipGraph capture: warm-up steps come first), then static -- the launch structure of a captured step
+        cannot follow the data.  Dense scans (full lists) keep the dense kernels."""
+        decided = getattr(self, "_compact_decision", None)
+        if decided is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False   # never decide inside a capture
+            b, m, ns = compact.shape
+            frac = float(compact.n_act.float().mean().item()) / (m * ns)
+            decided = self._compact_decision = frac <= self.COMPACT_MAX_FRACTION
+        return decided
+
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None,
                 inds: torch.Tensor = None, geometry=None):
         """`geometry` (optional, not in the reference signature): a precomputed
@@ -135,6 +151,8 @@ class PointnetSAModuleVotes(nn.Module):
             # is an identical column all the way up to the max-pool (csrc/compact.hip)
             inds, new_xyz, ball_idx = geometry[:3]
             compact = geometry[3] if len(geometry) > 3 and geometry[3] is not None else fused_mlp.compact_lists(ball_idx)
+            compactable = self._compact_pays(compact)
+        if geometry is not None and compactable:
             new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features, compact, self.nsample,
                                                       self.grouper.radius, self.grouper.use_xyz,
                                                       self.grouper.normalize_xyz)
@@ -148,11 +166,13 @@ class PointnetSAModuleVotes(nn.Module):
                 assert inds.shape[1] == self.npoint
             new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
             ball_idx = pointnet2_utils.ball_query(self.grouper.radius, self.nsample, xyz, new_xyz)
-            new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features,
-                                                      fused_mlp.compact_lists(ball_idx), self.nsample,
-                                                      self.grouper.radius, self.grouper.use_xyz,
-                                                      self.grouper.normalize_xyz)
-            return new_xyz, new_features, inds
+            compact = fused_mlp.compact_lists(ball_idx)
+            if self._compact_pays(compact):
+                new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features, compact,
+                                                          self.nsample, self.grouper.radius, self.grouper.use_xyz,
+                                                          self.grouper.normalize_xyz)
+                return new_xyz, new_features, inds
+            grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
         else:
             if inds is not None:
                 assert inds.shape[1] == self.npoint

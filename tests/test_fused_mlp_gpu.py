@@ -186,3 +186,16 @@ def test_compact_lists_structure():
             assert mult[bi, u] == ns - k + 1 and (mult[bi, u + 1:u + k] == 1).all()
             u += k
         assert seg[bi, m] == u and nact[bi] == u
+
+
+def test_compact_mode_is_declined_for_full_neighbour_lists():
+    """The per-layer decision is taken from the first batch: sparse lists -> compact, full lists -> dense."""
+    from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(1)
+    b, n = 2, 6000
+    xyz = (torch.rand(b, n, 3) * torch.tensor([8.0, 8.0, 3.0])).to(DEV)
+    feats = torch.randn(b, 3, n).to(DEV)
+    for radius, expect in ((0.2, True), (3.0, False)):
+        sa = PointnetSAModuleVotes(npoint=1024, radius=radius, nsample=64, mlp=[3, 32, 32], use_xyz=True).to(DEV).train()
+        out = sa(xyz, feats)[1]
+        assert sa._compact_decision is expect and torch.isfinite(out).all()
