@@ -29,6 +29,8 @@ preallocated buffers.
 Inputs live in static device buffers that are refreshed (device-to-device copy) before each
 replay; outputs (loss, answer_scores, ...) are read from static buffers after it.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -99,26 +101,38 @@ class GraphedTrainStep:
             return loss
 
         def fwd_bwd_head():
-            """Split mode, part 1: forward, then backward of everything DOWNSTREAM of the point encoder
-            (down to the token features), gradients gathered into the flat buffers."""
+            """Split mode, part 1: forward, then backward of the heads and the UPPER Q-Former layers (down to
+            the cut inside the Q-Former and to the visual tokens), gradients gathered into the flat buffers."""
             batch = dict(self.static_batch)
             batch["_split_backward"] = True
+            batch["_qf_cut"] = self._qf_cut
             if self.prefetch:
                 batch["geometry_plan"] = self.plan_cur
             out = model(batch)
             self._boundary = out.pop("_boundary")
+            self._qf_boundary = out.pop("_qf_boundary", None)
             out.pop("_split_backward", None)
+            out.pop("_qf_cut", None)
             loss, out = get_loss(out)
             self.static_out = out
-            loss.backward(inputs=self._head_params + [self._boundary[1]])
+            leaves = [self._boundary[1]] + ([self._qf_boundary[1]] if self._qf_boundary is not None else [])
+            loss.backward(inputs=self._upper_params + leaves)
             optimizer.gather_grads(slot=0, zero=True)
             return loss
 
-        def bwd_encoder():
-            """Split mode, part 2: the encoder's backward from the boundary gradient, own gather."""
-            tok_feat, leaf = self._boundary
-            tok_feat.backward(leaf.grad)
+        def bwd_lower():
+            """Split mode, part 2: the lower Q-Former layers and its embeddings from the cut's gradient; the
+            gradient of the visual tokens keeps accumulating in their boundary leaf."""
+            hidden, leaf = self._qf_boundary
+            hidden.backward(leaf.grad, inputs=self._lower_params + [self._boundary[1]])
             optimizer.gather_grads(slot=1, zero=False)
+            self._qf_boundary = None
+
+        def bwd_encoder():
+            """Split mode, last part: position MLP and point encoder from the tokens' gradient, own gather."""
+            tokens, leaf = self._boundary
+            tokens.backward(leaf.grad)
+            optimizer.gather_grads(slot=2, zero=False)
             self._boundary = None
 
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
@@ -128,17 +142,35 @@ class GraphedTrainStep:
         # downstream (Q-Former, heads: 99 % of the gradient bytes) runs while the encoder's backward
         # (a third of the step) is still computing.  Two graphs + two bucket sets; no collective captured.
         self._split = False
-        if self._bucketed_update and split_backward and hasattr(model, "encoder"):
-            enc = [p for p in model.encoder.parameters() if p.requires_grad]
-            parts = optimizer.flat_grad_split(enc)
-            if parts is not None and parts[0] and parts[1]:
-                from .ddp import GradBucketReducer
-                enc_ids = {id(p) for p in enc}
-                self._head_params = [p for p in params if id(p) not in enc_ids]
-                self._red_enc = GradBucketReducer.from_flat(parts[0], process_group=reducer.group)
-                self._red_head = GradBucketReducer.from_flat(parts[1], process_group=reducer.group)
+        self._qf_cut = None
+        if self._bucketed_update and split_backward and hasattr(model, "encoder") and hasattr(model, "Qformer"):
+            from .ddp import GradBucketReducer
+            layers = list(model.Qformer.bert.encoder.layer)
+            # SIG3D_QF_CUT=k (default 0 = off): also cut the backward after Q-Former layer k, so that the upper
+            # layers' gradients travel under the lower layers' backward.  Measured on one GPU the third graph and
+            # gather cost ~1.2 ms of host-side launch time per step, about what the extra overlap can hide on
+            # xGMI, so it stays opt-in until it can be measured on the 8-GPU node.
+            cut = 0
+            if getattr(model.Qformer.bert, "segmented_layout", False) and len(layers) >= 2:
+                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", "0")), len(layers) - 1))
+            up_mods = layers[cut:] + [model.position_head, model.rotation_head, model.aux_reg, model.answer_cls]
+            upper = [p for mod in up_mods for p in mod.parameters() if p.requires_grad]
+            up_ids = {id(p) for p in upper}
+            lower = [p for p in model.Qformer.parameters() if p.requires_grad and id(p) not in up_ids]
+            lower += [model.query_tokens] if model.query_tokens.requires_grad else []
+            if cut == 0:           # no cut inside the Q-Former: everything downstream of the tokens is one part
+                upper, lower = upper + lower, []
+            parts = optimizer.flat_grad_parts([upper, lower])
+            if parts[0] and parts[2]:
+                self._qf_cut = cut or None
+                self._upper_params, self._lower_params = upper, lower
+                self._red_head = GradBucketReducer.from_flat(parts[0], process_group=reducer.group)
+                self._red_low = GradBucketReducer.from_flat(parts[1], process_group=reducer.group) if lower else None
+                self._red_enc = GradBucketReducer.from_flat(parts[2], process_group=reducer.group)
+                self.graph_low = torch.cuda.CUDAGraph() if lower else None
                 self.graph_enc = torch.cuda.CUDAGraph()
-                optimizer._tables(1)   # second gather's staging buffers: pinned allocation is illegal in capture
+                optimizer._tables(1)   # later gathers' staging buffers: pinned allocation is illegal in capture
+                optimizer._tables(2)
                 self._split = True
 
         def update():
@@ -182,6 +214,10 @@ class GraphedTrainStep:
                 if not self._split:
                     self.plan_cur.copy_from(self.plan_next)      # hand over for the next replay
         if self._split:
+            if self.graph_low is not None:
+                with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_low, stream=stream, pool=self.graph.pool(),
+                                                               capture_error_mode=cap_mode):
+                    bwd_lower()
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(), capture_error_mode=cap_mode):
                 bwd_encoder()
                 if self.prefetch:  # the encoder's backward still reads plan_cur: hand over after it
@@ -212,12 +248,17 @@ class GraphedTrainStep:
         self.graph.replay()
         if self.reducer is not None:
             if self._split:
-                self._red_head.launch_all()      # Q-Former / head gradients: on the wire ...
-                self.graph_enc.replay()          # ... while the encoder's backward runs
+                self._red_head.launch_all()      # heads + upper Q-Former layers: on the wire ...
+                if self.graph_low is not None:
+                    self.graph_low.replay()      # ... while the lower layers' backward runs,
+                    self._red_low.launch_all()   # whose gradients then travel ...
+                self.graph_enc.replay()          # ... under the point encoder's backward
                 self._red_enc.launch_all()
                 self.optimizer.mark_gathered()
                 self.optimizer.begin_bucketed_step()
                 self.optimizer.update_buckets(self._red_head)
+                if self._red_low is not None:
+                    self.optimizer.update_buckets(self._red_low)
                 self.optimizer.update_buckets(self._red_enc)
                 self.optimizer.end_bucketed_step()
             elif self._bucketed_update:

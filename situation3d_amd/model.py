@@ -86,12 +86,6 @@ class SIG3DQFormer(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
         tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("geometry_plan"))
         tok_feat = tok_feat.transpose(1, 2).contiguous()            # (B,T,256)
-        if data_dict.get("_split_backward"):
-            # data-parallel step (graph_step.py): the backward pass is cut here so that the gradient
-            # all-reduce of everything downstream (99 % of the parameters) overlaps the encoder's backward
-            leaf = tok_feat.detach().requires_grad_(True)
-            data_dict["_boundary"] = (tok_feat, leaf)
-            tok_feat = leaf
         data_dict["scene_positions"] = tok_xyz
         data_dict["att_feat_pre"] = tok_feat
 
@@ -101,6 +95,14 @@ class SIG3DQFormer(nn.Module):
         data_dict["situational_positions"] = sit_xyz
         data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose[:, :3])
         tokens = tok_feat + self.pos_embed(sit_xyz)
+        if data_dict.get("_split_backward"):
+            # data-parallel step (graph_step.py): the backward pass is cut at the visual tokens (and, with
+            # `_qf_cut`, once more inside the Q-Former) so that the gradient all-reduce of everything
+            # downstream of a cut overlaps the backward of everything upstream of it
+            leaf = tokens.detach().requires_grad_(True)
+            data_dict["_boundary"] = (tokens, leaf)
+            tokens = leaf
+            self.Qformer.bert.encoder.cut_after = data_dict.get("_qf_cut")
 
         data_dict["pred_pos_likelihood"] = self.position_head(tokens).squeeze(-1)
         data_dict["pred_rotation"] = self.rotation_head(tokens)
@@ -116,6 +118,9 @@ class SIG3DQFormer(nn.Module):
                           attention_mask=torch.cat([ones, q["attention_mask"]], dim=1))
         out = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=tokens,
                                 encoder_attention_mask=None, return_dict=True, **kwargs)
+        if data_dict.get("_split_backward"):
+            data_dict["_qf_boundary"] = self.Qformer.bert.encoder.cut   # None when no cut was requested / taken
+            self.Qformer.bert.encoder.cut = None
         fused = getattr(out, "query_hidden_state", None)   # two-segment layout: a free view
         if fused is None:
             fused = out.last_hidden_state[:, :query_tokens.shape[1], :]

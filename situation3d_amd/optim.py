@@ -174,6 +174,31 @@ class FlatAdamW(torch.optim.Optimizer):
                 rest.append(f["g"][hi:])
         return part, rest
 
+    def flat_grad_parts(self, parts):
+        """parts: list of parameter lists.  -> one list of flat-gradient slices per part (every maximal run of
+        the part's parameters in storage order is a slice) plus a last list for all other parameters."""
+        self.flat_grad_buffers()
+        owner = {}
+        for k, ps in enumerate(parts):
+            for p in ps:
+                owner[id(p)] = k
+        out = [[] for _ in range(len(parts) + 1)]
+        for gi, f in enumerate(self._groups):
+            if f is None:
+                continue
+            mine = [(p, off) for p, g2, off in self._params if g2 == gi]
+            i = 0
+            while i < len(mine):
+                k = owner.get(id(mine[i][0]), len(parts))
+                j = i
+                while j < len(mine) and owner.get(id(mine[j][0]), len(parts)) == k:
+                    j += 1
+                lo = mine[i][1]
+                hi = mine[j][1] if j < len(mine) else f["total"]
+                out[k].append(f["g"][lo:hi])
+                i = j
+        return out
+
     @torch.no_grad()
     def step_after(self, reducer):
         """Data-parallel update overlapped with the gradient exchange: every bucket's all-reduce is

@@ -891,6 +891,8 @@ class BertEncoder(nn.Module):
         super().__init__()
         self.config = config
         self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.cut_after = None   # set for ONE forward: detach after this many layers, (output, leaf) left in .cut
+        self.cut = None
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
@@ -899,10 +901,17 @@ class BertEncoder(nn.Module):
         if segments is not None:
             # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
             batch, tq, tt, part_rows = segments
-            for layer_module in self.layer:
+            cut, self.cut_after, self.cut = self.cut_after, None, None
+            for i, layer_module in enumerate(self.layer):
                 hidden_states = layer_module.forward_segmented(
                     hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
                     batch, tq, tt, part_rows)
+                if cut is not None and i + 1 == cut:
+                    # data-parallel step (graph_step.py): the backward pass is cut here so that the gradient
+                    # all-reduce of the layers above overlaps the backward of the layers below
+                    leaf = hidden_states.detach().requires_grad_(True)
+                    self.cut = (hidden_states, leaf)
+                    hidden_states = leaf
             return _SegmentedOutput(hidden_states, batch, tq, tt, part_rows)
         all_hidden_states = () if output_hidden_states else None
         for layer_module in self.layer:

@@ -286,13 +286,16 @@ def test_graphed_step_matches_eager(prefetch):
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split):
+@pytest.mark.parametrize("split", [False, True, "qf"])
+def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split, monkeypatch):
     """The N > 1 step structure at world size 1: graph (forward + backward + gradient gather) ->
     per-bucket all-reduce -> AdamW bucket by bucket (optim.FlatAdamW.step_after) must follow the
     same loss trajectory as the plain eager FlatAdamW step.  split=True: the backward pass is cut at
     the point encoder's output (two graphs, two bucket sets) so that the Q-Former gradients are on
-    the wire while the encoder's backward runs."""
+    the wire while the encoder's backward runs.  split="qf": a third piece, the cut inside the Q-Former
+    (SIG3D_QF_CUT, opt-in)."""
+    if split == "qf":
+        monkeypatch.setenv("SIG3D_QF_CUT", "1")
     from situation3d_amd.ddp import GradBucketReducer
     from situation3d_amd.graph_step import GraphedTrainStep
     from situation3d_amd.model import SIG3DQFormer
@@ -330,8 +333,9 @@ def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split):
         reducer = GradBucketReducer.from_flat(o2.flat_grad_buffers(), bucket_bytes=1 << 20)
         assert reducer.num_collectives() > 2
         gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=True, reducer=reducer,
-                              split_backward=split)
-        assert gs._bucketed_update and gs._split == split
+                              split_backward=bool(split))
+        assert gs._bucketed_update and gs._split == bool(split)
+        assert (gs._qf_cut == 1) == (split == "qf")
         graph = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(5)]
     torch.cuda.synchronize()
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
