@@ -143,7 +143,8 @@ class GraphedTrainStep:
         # (a third of the step) is still computing.  Two graphs + two bucket sets; no collective captured.
         self._split = False
         self._qf_cut = None
-        if self._bucketed_update and split_backward and hasattr(model, "encoder") and hasattr(model, "Qformer"):
+        if (self._bucketed_update and split_backward and os.environ.get("SIG3D_NO_SPLIT") is None
+                and hasattr(model, "encoder") and hasattr(model, "Qformer")):
             from .ddp import GradBucketReducer
             layers = list(model.Qformer.bert.encoder.layer)
             # SIG3D_QF_CUT=k (default 0 = off): also cut the backward after Q-Former layer k, so that the upper
