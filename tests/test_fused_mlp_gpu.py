@@ -199,3 +199,35 @@ def test_compact_mode_is_declined_for_full_neighbour_lists():
         sa = PointnetSAModuleVotes(npoint=1024, radius=radius, nsample=64, mlp=[3, 32, 32], use_xyz=True).to(DEV).train()
         out = sa(xyz, feats)[1]
         assert sa._compact_decision is expect and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("npoint,nsample,radius", [(333, 6, 0.25), (500, 7, 0.05), (64, 16, 0.6)])
+def test_compact_sa_level_odd_shapes(npoint, nsample, radius, monkeypatch):
+    """Compact mode on shapes outside the vector paths: positions per row not a multiple of 4, partial last
+    tiles, centres without any neighbour (all-zero list = point 0 repeated), nearly full lists."""
+    import copy
+    from situation3d_amd.pointnet2 import fused_mlp
+    from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    monkeypatch.setattr(fused_mlp, "MIN_POSITIONS", 0)
+    monkeypatch.setattr(fused_mlp, "COMPACT_MIN_POSITIONS", 0)
+    monkeypatch.setattr(PointnetSAModuleVotes, "COMPACT_MAX_FRACTION", 1.0)
+    torch.manual_seed(11)
+    b, n = 3, 1500
+    xyz = (torch.rand(b, n, 3) * torch.tensor([4.0, 4.0, 2.0])).to(DEV)
+    xyz[:, :200] += 100.0          # far-away points: their own ball only
+    feats = torch.randn(b, 5, n).to(DEV)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=nsample, mlp=[5, 32, 64], use_xyz=True).to(DEV).train()
+    sa2 = copy.deepcopy(sa)
+    g, res = None, []
+    for module, compact in ((sa, True), (sa2, False)):
+        monkeypatch.setattr(fused_mlp, "COMPACT", compact)
+        f = feats.clone().requires_grad_(True)
+        out = module(xyz, f)[1]
+        g = torch.randn_like(out) if g is None else g
+        (out * g).sum().backward()
+        res.append((out.detach(), f.grad, [p.grad for p in module.parameters()]))
+    assert sa._compact_decision is True and getattr(sa2, "_compact_decision", None) is None
+    (o1, f1, p1), (o2, f2, p2) = res
+    for a, b_, what in [(o1, o2, "out"), (f1, f2, "dfeat")] + [(x, y, "dparam") for x, y in zip(p1, p2)]:
+        err = (a - b_).abs().max().item()
+        assert err <= 3e-5 * max(1.0, b_.abs().max().item()), (what, err)
