@@ -49,5 +49,19 @@ with torch.cuda.stream(work), torch.no_grad():
     piped = (time.perf_counter() - t0) / 30
 print("forward only, B=%d x %d pts, geometry prefetched one batch ahead: %.2f ms (%.0f samples/s)"
       % (B, bench.N_POINTS, piped * 1e3, B / piped))
+# the FPS chain of the prefetch branch costs the same for 8 scenes as for 4 (one cooperative launch holds 8):
+with torch.cuda.stream(work), torch.no_grad():
+    b8 = [bench.synthetic_batch(8, bench.N_POINTS, 200 + i, dev) for i in range(3)]
+    step8 = GraphedForward(model, b8[0])
+    for i in range(4):
+        step8(b8[i % 3], b8[(i + 1) % 3])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(30):
+        step8(b8[i % 3], b8[(i + 1) % 3])
+    torch.cuda.synchronize()
+    p8 = (time.perf_counter() - t0) / 30
+print("forward only, B=8 x %d pts, geometry prefetched one batch ahead: %.2f ms (%.0f samples/s)"
+      % (bench.N_POINTS, p8 * 1e3, 8 / p8))
 print("forward only, B=%d x %d pts: eager %.2f ms (%.0f samples/s), hipGraph %.2f ms (%.0f samples/s)"
       % (B, bench.N_POINTS, eager * 1e3, B / eager, graphed * 1e3, B / graphed))
