@@ -89,6 +89,42 @@ def test_fp_module():
                   {"grad_unknow_feats": uf, "grad_known_feats": kf})
 
 
+def test_sa_msg_votes_module():
+    """PointnetSAModuleMSGVotes (pointnet2_modules.py:279-358) against the reference class's golden."""
+    g = _load("pointnet2_modules_msgvotes.npz")
+    f = g["features"].to(DEV).requires_grad_(True)
+    mod = _mods().PointnetSAModuleMSGVotes(mlps=[[4, 8], [4, 8, 12]], npoint=24, radii=[0.6, 1.2],
+                                           nsamples=[8, 16])
+    _check_module(mod, g, (g["xyz"].to(DEV), f), 1, {"grad_features": f})
+
+
+def test_lfp_msg_module():
+    """PointnetLFPModuleMSG (pointnet2_modules.py:423-501): one shared post_mlp applied per scale."""
+    g = _load("pointnet2_modules_lfp.npz")
+    f2 = g["features2"].to(DEV).requires_grad_(True)
+    f1 = g["features1"].to(DEV).requires_grad_(True)
+    mod = _mods().PointnetLFPModuleMSG(mlps=[[5, 8], [5, 8]], radii=[1.0, 2.0], nsamples=[6, 12],
+                                       post_mlp=[14, 10])
+    _check_module(mod, g, (g["xyz2"].to(DEV), g["xyz1"].to(DEV), f2, f1), 0,
+                  {"grad_features2": f2, "grad_features1": f1})
+
+
+def test_query_and_group_sample_uniformly_and_group_all():
+    """pointnet2_utils.py:336-345 (host RNG loop, seeded like the fixture) and GroupAll (:379-425)."""
+    from situation3d_amd.pointnet2 import pointnet2_utils as U
+    g = _load("pointnet2_groupers.npz")
+    xyz, new_xyz, f = g["su.xyz"].to(DEV), g["su.new_xyz"].to(DEV), g["su.features"].to(DEV)
+    q = U.QueryAndGroup(0.9, 10, use_xyz=True, ret_grouped_xyz=True, sample_uniformly=True, ret_unique_cnt=True)
+    torch.manual_seed(int(g["su.seed"]))
+    nf, gx, cnt = q(xyz, new_xyz, f)
+    assert torch.equal(cnt.cpu(), g["su.unique_cnt"])
+    assert torch.equal(nf.cpu(), g["su.new_features"]) and torch.equal(gx.cpu(), g["su.grouped_xyz"])
+    assert torch.equal(U.GroupAll(use_xyz=True)(xyz, None, f).cpu(), g["ga.out"])
+    a, b = U.GroupAll(use_xyz=True, ret_grouped_xyz=True)(xyz, None, f)
+    assert torch.equal(a.cpu(), g["ga.out"]) and torch.equal(b.cpu(), g["ga.out_xyz"])
+    assert torch.equal(U.GroupAll(use_xyz=False)(xyz, None, f).cpu(), g["ga.out_nofeat_xyz"])
+
+
 def test_fused_grouping_equals_unfused_composition(hip_ext):
     """sig3d_query_group_fused == group(xyz)-centre(/r) ++ group(features), bit for bit."""
     from situation3d_amd.pointnet2 import pointnet2_utils as U

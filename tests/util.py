@@ -28,3 +28,26 @@ def poses(b, seed=2):
     ang = (torch.rand(b, generator=g) * 2 - 1) * 3.14159265
     q = torch.stack([torch.zeros(b), torch.zeros(b), torch.sin(ang / 2), torch.cos(ang / 2)], 1)
     return torch.cat([t, q], 1).contiguous()
+
+
+def tiny_head(din=12, hidden=16, num_answers=9):
+    """The model of tests/golden/harness_trajectory.npz (make_golden_r2.py::TinyHead): parameter names
+    cover both optimizer groups ("bias" / "LayerNorm.weight" vs the rest, train.py:186)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class TinyHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(din, hidden)
+            self.LayerNorm = nn.LayerNorm(hidden)
+            self.aux_reg = nn.Linear(hidden, 7)
+            self.answer_cls = nn.Linear(hidden, num_answers)
+
+        def forward(self, data_dict):
+            h = F.gelu(self.LayerNorm(self.proj(data_dict["x"])))
+            data_dict["aux_scores"] = self.aux_reg(h)
+            data_dict["answer_scores"] = self.answer_cls(h)
+            return data_dict
+
+    return TinyHead()
