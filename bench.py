@@ -225,10 +225,10 @@ def main():
                 grp_bytes += group_algorithmic_bytes(bb, nn, mm, ns_, cc)
         cgrp = kernel_ms("sig3d_query_group_compact")
         # the largest HBM-bound kernel of the step by time is the flat AdamW update: per parameter it reads
-        # p, g, m, v and writes p, m, v and the zeroed g (32 B, clip + update + zero_grad in one pass)
+        # p, g, m, v and writes p, m, v (28 B: clip + update in one pass; the gradients are dropped, not zeroed)
         adam = kernel_ms("sig3d_adamw_table") + kernel_ms("sig3d_adamw_flat")
         n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-        adam_gbs = 32.0 * n_params * KSTEPS / (sum(adam) * 1e-3) / 1e9 if adam else 0.0
+        adam_gbs = 28.0 * n_params * KSTEPS / (sum(adam) * 1e-3) / 1e9 if adam else 0.0
         tr = kernel_ms("sig3d_transpose_cn")
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid")
@@ -266,7 +266,7 @@ def main():
                          "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
             "roofline_adamw": {"bound": "hbm", "kernel": "adamw_table_kernel", "achieved": round(adam_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adam_gbs / HBM_PEAK_GBS, 4),
-                               "algorithmic_bytes_per_launch": 32 * n_params,
+                               "algorithmic_bytes_per_launch": 28 * n_params,
                                "avg_launch_us": round(sum(adam) / max(len(adam), 1) * 1e3, 1)},
             "kernels_ms_per_step": {"query_group_fused": round(sum(grp) / KSTEPS, 4),
                                     "query_group_compact": round(sum(cgrp) / KSTEPS, 4),

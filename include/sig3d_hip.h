@@ -49,6 +49,15 @@ int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,
 int sig3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
                              const int *idx, float *grad_points, void *stream);
 
+/* Health of the cooperative FPS (n > 8192: one scene is sampled by 8 workgroups that exchange their
+ * per-round candidates through memory and therefore must be co-resident).  A workgroup that waits
+ * for a peer longer than 2^22 polls gives up, fills the rest of that scene's indices with -1 and
+ * counts the event; the gathers clamp such indices, so nothing reads out of bounds, but the batch is
+ * garbage.  The launch itself returned 0 long before, so the host asks here -- SYNCHRONOUSLY (a
+ * blocking device read; call it between steps, never inside a capture): *count = events since the
+ * library was loaded (or since the last call with reset != 0). */
+int sig3d_fps_timeout_count(unsigned *count, int reset);
+
 /* Fuses the centre gather of _PointnetSAModuleBase.forward / PointnetSAModuleVotes.forward
  *   lib/pointnet2/pointnet2_modules.py:52-56, 233-240
  * (xyz.transpose(1,2).contiguous() -> gather_operation -> .transpose(1,2).contiguous()):
@@ -308,19 +317,25 @@ int sig3d_counter_increment(unsigned *counter, void *stream);
  * situation3d/train/train.py:226-238 over FLAT storage: p, g, m, v are n-element arrays (one set
  * per parameter group), `step` a device scalar holding the 1-based step count t (advance it with
  * sig3d_step_increment BEFORE the update of a step).  clip_value <= 0 disables the clamp;
- * zero_grad != 0 writes zeros back to g.  Same update rule as torch.optim.AdamW. */
+ * zero_grad != 0 writes zeros back to g.  Same update rule as torch.optim.AdamW.
+ * lr_device (may be NULL): a device scalar that REPLACES `lr` when given -- the learning rate is
+ * then read when the kernel executes, so a captured launch follows the reference's StepLR /
+ * MultiStepLR schedule (lib/solver.py:239-247) across hipGraph replays. */
 int sig3d_step_increment(float *step, void *stream);
 int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float *step, float lr,
-                     float beta1, float beta2, float eps, float weight_decay, float clip_value,
-                     int zero_grad, void *stream);
+                     const float *lr_device, float beta1, float beta2, float eps, float weight_decay,
+                     float clip_value, int zero_grad, void *stream);
 
 /* Same update driven by a device-resident table of `nchunks` records
  *   struct { float *p, *g, *m, *v; long long n; float weight_decay; float pad; }   (48 bytes)
  * one workgroup per record (n <= 65536 recommended): gradients may live wherever autograd
- * allocated them.  sig3d_gather_table copies g -> m for every record (used to gather scattered
- * gradients into flat storage before a data-parallel all-reduce). */
-int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr, float beta1,
-                      float beta2, float eps, float clip_value, void *stream);
+ * allocated them.  A record with n <= 0 is skipped entirely (a parameter that received no gradient
+ * is neither decayed nor stepped, like torch.optim.AdamW).  sig3d_gather_table copies g -> m for
+ * every record (used to gather scattered gradients into flat storage before a data-parallel
+ * all-reduce). */
+int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr,
+                      const float *lr_device, float beta1, float beta2, float eps, float clip_value,
+                      void *stream);
 int sig3d_gather_table(int nchunks, const void *table, void *stream);
 
 /* ---- Q-Former attention ---------------------------------------------------------------- */

@@ -19,6 +19,7 @@ _F = ctypes.c_float
 # name -> argtypes (restype is int status everywhere); order == include/sig3d_hip.h
 SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "sig3d_fps_timeout_count": [_P, _I],
     "sig3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],
@@ -65,8 +66,8 @@ SIGNATURES = {
     "sig3d_dropout_add_mcan_norm_bwd": [_I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_counter_increment": [_P, _P],
     "sig3d_step_increment": [_P, _P],
-    "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P],
-    "sig3d_adamw_table": [_I, _P, _P, _F, _F, _F, _F, _F, _P],
+    "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _I, _P],
+    "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],
     "sig3d_gather_table": [_I, _P, _P],
     "sig3d_attention_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F,
                             ctypes.c_uint, _P, _I, _P, _P],
@@ -144,6 +145,15 @@ def call(name, *args):
         rec.append((start, end, tuple(a for a in args if isinstance(a, int))))
     if status != 0:
         raise Sig3dError("%s failed: %s" % (name, lib.sig3d_last_error().decode()))
+
+
+def fps_timeouts(reset=False):
+    """Scenes whose cooperative furthest-point sampling gave up waiting for a peer workgroup since the
+    library was loaded / the last reset (blocking device read: call between steps).  Non-zero means
+    batches were sampled with poisoned indices -- treat as an error."""
+    n = ctypes.c_uint(0)
+    call("sig3d_fps_timeout_count", ctypes.byref(n), int(bool(reset)))
+    return int(n.value)
 
 
 def require_device(*tensors):

@@ -7,7 +7,8 @@
 // torch runs this as ~36 multi-tensor launches (pointer tables are limited by kernel-argument
 // size) that reach ~1.8 TB/s; parameters, gradients and both moments live here in FLAT buffers
 // (one per parameter group), so the whole update is ONE streaming kernel per group with 16-byte
-// accesses: read p, g, m, v -- write p, m, v and the zeroed gradient (32 B/element, HBM-bound).
+// accesses: read p, g, m, v -- write p, m, v (28 B/element, HBM-bound; sig3d_adamw_flat can also write
+// zeros back to g, the table kernel never does: its gradients are dropped by the host afterwards).
 // The step counter lives on the device (hipGraph replay must not bake it into the graph).
 //
 // Update rule == torch.optim.AdamW (amsgrad=False, maximize=False):
@@ -35,8 +36,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(long n, float *__restri
                                                          float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v,
                                                          const float *__restrict__ step, float lr,
+                                                         const float *__restrict__ lr_device,
                                                          float b1, float b2, float eps, float wd,
                                                          float clip, int zero_grad) {
+  if (lr_device) lr = *lr_device;  // a scheduler's value, read at execution time (hipGraph replays)
   const float t = *step;
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -81,8 +84,11 @@ struct OptChunk {
 
 __global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__restrict__ table,
                                                           const float *__restrict__ step, float lr,
+                                                          const float *__restrict__ lr_device,
                                                           float b1, float b2, float eps, float clip) {
   const OptChunk c = table[blockIdx.x];
+  if (c.n <= 0) return;            // a parameter without a gradient this step: untouched (torch skips it)
+  if (lr_device) lr = *lr_device;  // a scheduler's value, read at execution time (hipGraph replays)
   const float t = *step;
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -149,12 +155,12 @@ __global__ __launch_bounds__(256) void gather_table_kernel(const OptChunk *__res
 }  // namespace
 
 extern "C" int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr,
-                                 float beta1, float beta2, float eps, float clip_value,
-                                 void *stream_) {
+                                 const float *lr_device, float beta1, float beta2, float eps,
+                                 float clip_value, void *stream_) {
   SIG3D_REQUIRE(nchunks >= 0, "negative size");
   if (nchunks == 0) return 0;
   hipLaunchKernelGGL(adamw_table_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream_,
-                     (const OptChunk *)table, step, lr, beta1, beta2, eps, clip_value);
+                     (const OptChunk *)table, step, lr, lr_device, beta1, beta2, eps, clip_value);
   SIG3D_LAUNCH_CHECK("adamw_table_kernel");
   return 0;
 }
@@ -175,8 +181,8 @@ extern "C" int sig3d_step_increment(float *step, void *stream_) {
 }
 
 extern "C" int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float *step,
-                                float lr, float beta1, float beta2, float eps, float weight_decay,
-                                float clip_value, int zero_grad, void *stream_) {
+                                float lr, const float *lr_device, float beta1, float beta2, float eps,
+                                float weight_decay, float clip_value, int zero_grad, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(n >= 0, "negative size");
   if (n == 0) return 0;
@@ -184,7 +190,7 @@ extern "C" int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, 
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, p, g, m, v, step,
-                     lr, beta1, beta2, eps, weight_decay, clip_value, zero_grad);
+                     lr, lr_device, beta1, beta2, eps, weight_decay, clip_value, zero_grad);
   SIG3D_LAUNCH_CHECK("adamw_flat_kernel");
   return 0;
 }

@@ -152,6 +152,9 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr int FPS_SLOT_U64 = 64;  // per scene: 2 parities x W <= 16 workgroups x {val,key}
 
+// scenes whose cooperative FPS gave up waiting for a peer workgroup (see the poison path below)
+__device__ unsigned g_fps_timeouts = 0;
+
 template <int NT, int PPT, int W>
 __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L,
                                                       const float *__restrict__ dataset_all,
@@ -260,6 +263,9 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
     if (gvu == (int)0x80000001) {  // a peer never showed up: poison instead of hanging
       if (w == 0)
         for (int jj = j + tid; jj < m; jj += NT) idxs[jj] = -1;
+      // ... and REPORT it: the entry point returned 0 long ago (asynchronous launch, possibly a graph
+      // replay), so the host reads this counter through sig3d_fps_timeout_count (once per step / epoch)
+      if (w == 0 && tid == 0) atomicAdd(&g_fps_timeouts, 1u);
       return;
     }
     old = (gvu < 0) ? 0 : (int)fps_unkey(gku, L);
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(256) void gather_points_kernel(int c, int n, int m,
   const int bi = blockIdx.z;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
-  const int a = idx[(size_t)bi * m + j];
+  // clamped: a poisoned FPS result (-1, see fps_coop_kernel) must not become an out-of-bounds read
+  const int a = min(max(idx[(size_t)bi * m + j], 0), n - 1);
   for (int l = blockIdx.y; l < c; l += gridDim.y)
     out[((size_t)bi * c + l) * m + j] = points[((size_t)bi * c + l) * n + a];
 }
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void gather_xyz_kernel(int n, int m, const flo
   const int bi = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
-  const int a = idx[(size_t)bi * m + j];
+  const int a = min(max(idx[(size_t)bi * m + j], 0), n - 1);  // poisoned FPS indices stay in bounds
   const float *src = xyz + ((size_t)bi * n + a) * 3;
   float *dst = out + ((size_t)bi * m + j) * 3;
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
@@ -369,6 +376,16 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
     return 0;
   }
   return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
+}
+
+extern "C" int sig3d_fps_timeout_count(unsigned *count, int reset) {
+  SIG3D_REQUIRE(count != nullptr, "count must not be null");
+  SIG3D_HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_fps_timeouts), sizeof(unsigned)));
+  if (reset) {
+    const unsigned zero = 0;
+    SIG3D_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fps_timeouts), &zero, sizeof(unsigned)));
+  }
+  return 0;
 }
 
 extern "C" int sig3d_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -51,6 +51,31 @@ def _clone(d):
     return {k: (_clone(v) if isinstance(v, dict) else v.clone()) for k, v in d.items()}
 
 
+class Announced:
+    """Identity of the batch whose geometry the forked branch computed during the previous replay.
+    A device address is NOT an identity (the caching allocator recycles addresses; a loader that refills one
+    staging buffer in place passes the same address every step), so the hand-over is keyed on
+      * an explicit `token` (step / sequence id) when the caller passes one, else
+      * the announced tensor OBJECT (kept referenced here, so its storage cannot be recycled) together with
+        its autograd version counter, which every in-place write through any view of it advances.
+    Anything else -- a different object, a refilled buffer, a missing token -- recomputes the geometry inline."""
+
+    def __init__(self):
+        self.tensor = self.version = self.token = None
+
+    def set(self, tensor, token=None):
+        self.tensor, self.version, self.token = tensor, tensor._version, token
+
+    def matches(self, tensor, token=None):
+        if token is not None or self.token is not None:
+            return token is not None and token == self.token
+        return tensor is self.tensor and tensor._version == self.version
+
+
+def _bn_momenta(model):
+    return [m.momentum for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+
+
 class GraphedTrainStep:
     """Captures `zero_grad -> forward -> get_loss -> backward -> clip_grad_value_ -> step`
     (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
@@ -75,7 +100,7 @@ class GraphedTrainStep:
             reducer.hooks_enabled = False
         self.prefetch = bool(prefetch_geometry)
         self._primed = False
-        self._expected = None
+        self._announced = Announced()
         params =[p for p in model.parameters() if p.requires_grad]
 
         if self.prefetch:
@@ -229,6 +254,11 @@ class GraphedTrainStep:
                                                            capture_error_mode=cap_mode):
                 update()
         torch.cuda.synchronize()
+        # hyper-parameters that are baked into captured launches by VALUE: BatchNorm momentum
+        # (sig3d_bn_finalize; the reference's BNMomentumScheduler changes it per epoch, lib/solver.py:248-257)
+        # and, for optimizers other than FlatAdamW with fused kernels, nothing else.  The learning rate is a
+        # device scalar (optim.FlatAdamW.sync_lr) and follows a scheduler across replays.
+        self._captured_bn_momenta = _bn_momenta(model)
 
     def prime(self, batch):
         """Prefetch mode: compute the geometry of the FIRST batch (pipeline prologue)."""
@@ -236,15 +266,24 @@ class GraphedTrainStep:
             self.plan_cur.compute(batch["point_clouds"][..., :3].contiguous())
         self._primed = True
 
-    def __call__(self, batch, next_batch=None):
+    def __call__(self, batch, next_batch=None, token=None, next_token=None):
+        """`token` / `next_token` (optional): the caller's ids of `batch` / `next_batch` (step or sequence
+        numbers).  Without them the hand-over is keyed on tensor identity + version (see Announced); a caller
+        that refills ONE buffer in place must pass tokens to keep the prefetch, or pays an inline geometry
+        chain per step -- never a wrong plan."""
+        if _bn_momenta(self.model) != self._captured_bn_momenta:
+            raise RuntimeError("BatchNorm momentum changed since capture (BNMomentumScheduler): the captured "
+                               "sig3d_bn_finalize launches hold the old value -- build a new GraphedTrainStep")
+        sync_lr = getattr(self.optimizer, "sync_lr", None)
+        if sync_lr is not None:
+            sync_lr()   # a scheduler's new learning rate -> the device scalar the captured AdamW reads
         if self.prefetch:
             if next_batch is None:
                 raise ValueError("prefetch_geometry=True needs the batch of the NEXT step")
-            key = batch["point_clouds"].data_ptr()
-            if not self._primed or self._expected != key:
+            if not self._primed or not self._announced.matches(batch["point_clouds"], token):
                 self.prime(batch)  # pipeline prologue, or the caller broke the announced order
-            self._expected = next_batch["point_clouds"].data_ptr()
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
+            self._announced.set(next_batch["point_clouds"], next_token)
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         if self.reducer is not None:

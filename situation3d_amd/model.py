@@ -54,6 +54,13 @@ class PointNet2Encoder(nn.Module):
         return xyz2, f2u
 
 
+def build_pos_embed(in_dim, feat_dim):
+    """The positional MLP of sqa_module.py:274-278: Linear(in_dim,128)-GELU-Linear(128,feat_dim).  The reference
+    feeds it the 2-D (x, y) token positions in the WORLD frame (:319-321, in_dim = 2); the north-star path feeds
+    it the 3-D token positions in the AGENT's frame (situational re-encode, in_dim = 3, the default here)."""
+    return nn.Sequential(nn.Linear(in_dim, 128), nn.GELU(), nn.Linear(128, feat_dim))
+
+
 class SIG3DQFormer(nn.Module):
     """data_dict in : point_clouds (B,N,3+C) f32 [xyz | per-point features],
                       auxiliary_task (B,7) f32 [x,y,z, quat_xyzw] (situation; sepdataset.py:306-315),
@@ -64,12 +71,16 @@ class SIG3DQFormer(nn.Module):
     """
 
     def __init__(self, num_answers=706, input_feature_dim=3, num_query_token=32, use_fp=False,
-                 qformer_overrides=None, vocab_size=30522):
+                 qformer_overrides=None, vocab_size=30522, pos_embed_dim=3):
         super().__init__()
         self.encoder = PointNet2Encoder(input_feature_dim, use_fp)
         feat_dim = 256
-        # sqa_module.py:274-278 uses a 2-D (x,y) MLP; the situational frame is 3-D here
-        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, feat_dim))
+        # pos_embed_dim = 3 (default): the MLP sees the situational (agent-frame) xyz of a token;
+        # pos_embed_dim = 2: the reference's layer (sqa_module.py:274-278, same state_dict keys and shapes, a
+        # reference checkpoint's `pos_embed.*` loads) on the world-frame (x, y) of a token, as :319-321
+        assert pos_embed_dim in (2, 3)
+        self.pos_embed_dim = pos_embed_dim
+        self.pos_embed = build_pos_embed(pos_embed_dim, feat_dim)
         overrides = dict(vocab_size=vocab_size)
         overrides.update(qformer_overrides or {})
         self.Qformer, self.query_tokens = init_Qformer(num_query_token, feat_dim, **overrides)
@@ -94,7 +105,7 @@ class SIG3DQFormer(nn.Module):
         sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
         data_dict["situational_positions"] = sit_xyz
         data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose[:, :3])
-        tokens = tok_feat + self.pos_embed(sit_xyz)
+        tokens = tok_feat + self.pos_embed(sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2])
         if data_dict.get("_split_backward"):
             # data-parallel step (graph_step.py): the backward pass is cut at the visual tokens (and, with
             # `_qf_cut`, once more inside the Q-Former) so that the gradient all-reduce of everything

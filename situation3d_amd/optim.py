@@ -13,9 +13,14 @@ Data parallel: `gather_grads()` copies the scattered gradients into flat buffers
 `flat_grad_buffers()` exposes them for an in-place bucketed all-reduce
 (ddp.GradBucketReducer.from_flat) and the following `step()` consumes the flat, reduced gradients.
 
-Numerically this is torch.optim.AdamW (amsgrad=False) preceded by clip_grad_value_.  The learning
-rate is read when step() is CALLED: under hipGraph replay it is baked into the captured launch
-(re-capture, or rebuild the optimizer, to change it).
+Numerically this is torch.optim.AdamW (amsgrad=False) preceded by clip_grad_value_.  A parameter
+that received no gradient in a step is left untouched on EVERY path (table, gathered, bucketed), like
+torch.optim.AdamW and the reference's DDP with find_unused_parameters=True (runner_base.py:91-93).
+The learning rate lives in a device scalar the kernels read when they EXECUTE: a scheduler that
+mutates `param_groups[*]["lr"]` (lib/solver.py:239-247) is honoured by captured hipGraph replays too --
+`sync_lr()` (called by step() and by graph_step.GraphedTrainStep before every replay) refreshes it.
+`state_dict()` / `load_state_dict()` speak torch.optim.AdamW's layout (per-parameter `step`, `exp_avg`,
+`exp_avg_sq`), so the reference's checkpoints (lib/solver.py:652-660, train.py:256-262) round-trip.
 """
 import ctypes
 
@@ -72,6 +77,10 @@ class FlatAdamW(torch.optim.Optimizer):
             self._groups.append(dict(p=flat_p, m=m, v=v, g=None, total=total))
         self._dev = dev
         self._step = torch.zeros((), dtype=torch.float32, device=dev)
+        self._lr_host = float(self.param_groups[0]["lr"])
+        self._lr_dev = torch.full((1,), self._lr_host, dtype=torch.float32, device=dev)
+        self._live = np.zeros(len(self._params), dtype=bool)   # which parameters the last gather saw a gradient for
+        self._flat_tables = {}
         self._static = np.array(recs, dtype=_REC)          # 'g' holds the byte offset inside the grad
         self._owners = np.array(owners, dtype=np.int64)
         self._host = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory()
@@ -103,6 +112,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.grad = g
             gptr[i] = g.data_ptr()
             live[i] = True
+        if dst_field_from_flat_g:
+            self._live |= live
         host, t, table = self._tables(slot)
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]
@@ -131,6 +142,7 @@ class FlatAdamW(torch.optim.Optimizer):
         cleared), the second with zero=False and its own `slot` (see _tables)."""
         self.flat_grad_buffers()
         if zero:
+            self._live[:] = False
             for g in self._groups:
                 if g is not None:
                     g["g"].zero_()  # parameters without a gradient contribute zeros to the all-reduce
@@ -218,14 +230,61 @@ class FlatAdamW(torch.optim.Optimizer):
     def end_bucketed_step(self):
         self._gathered = False
 
+    # ---- learning rate / liveness ---------------------------------------------------------------
+    def sync_lr(self):
+        """Push a changed `param_groups[*]["lr"]` to the device scalar the kernels read.  Never inside a
+        capture (the fill would be baked in): graph_step.GraphedTrainStep calls this before each replay."""
+        lr = float(self.param_groups[0]["lr"])
+        if any(float(g["lr"]) != lr for g in self.param_groups):
+            raise RuntimeError("FlatAdamW: groups may differ in weight_decay only")
+        if lr != self._lr_host and not torch.cuda.is_current_stream_capturing():
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    def _flat_table(self, ranges):
+        """Device chunk table for AdamW over slices [(group, lo, hi), ...] of the FLAT storage (gradients
+        included), restricted to the parameters the last gather saw a gradient for: dead parameters get
+        no record, so they are neither decayed nor stepped.  Cached per (ranges, liveness)."""
+        key = (tuple(ranges), self._live.tobytes())
+        hit = self._flat_tables.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
+        recs = []
+        for gi, lo, hi in ranges:
+            f = self._groups[gi]
+            wd = self.param_groups[gi]["weight_decay"]
+            for pi, (p, g2, off) in enumerate(self._params):
+                if g2 != gi or not self._live[pi]:
+                    continue
+                a, b = max(off, lo), min(off + p.numel(), hi)
+                for c0 in range(a, b, _CHUNK):
+                    n = min(_CHUNK, b - c0)
+                    recs.append((f["p"].data_ptr() + 4 * c0, f["g"].data_ptr() + 4 * c0,
+                                 f["m"].data_ptr() + 4 * c0, f["v"].data_ptr() + 4 * c0, n, wd, 0.0))
+        arr = np.array(recs, dtype=_REC)
+        host = torch.empty(max(len(recs), 1) * _REC.itemsize, dtype=torch.uint8).pin_memory()
+        host.numpy().view(_REC)[:len(recs)] = arr
+        table = torch.empty(host.numel(), dtype=torch.uint8, device=self._dev)
+        table.copy_(host, non_blocking=torch.cuda.is_current_stream_capturing())
+        self._flat_tables[key] = (table, len(recs), host)   # the staging buffer stays alive (memcpy node)
+        return table, len(recs)
+
+    def _adamw_ranges(self, ranges, stream):
+        table, n = self._flat_table(ranges)
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        _lib.call("sig3d_adamw_table", n, _lib.ptr(table), _lib.ptr(self._step), ctypes.c_float(g0["lr"]),
+                  _lib.ptr(self._lr_dev), ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
+                  ctypes.c_float(self.clip_value), stream)
+
     @torch.no_grad()
     def update_buckets(self, reducer):
         """AdamW on every bucket of `reducer` (slices of flat_grad_buffers()), each right behind its own
-        all-reduce; the collectives must have been launched (reducer.launch_all())."""
+        all-reduce; the collectives must have been launched (reducer.launch_all()).  The gradients stay in
+        place: the next gather_grads(zero=True) clears the buffers."""
         dev = self._dev
         stream = _lib.stream_ptr(dev)
-        g0 = self.param_groups[0]
-        b1, b2 = g0["betas"]
+        self.sync_lr()
         with torch.cuda.device(dev):
             for bucket in reducer.buckets:
                 reducer.wait(bucket)   # the current stream waits for this bucket's collective only
@@ -239,15 +298,7 @@ class FlatAdamW(torch.optim.Optimizer):
                         gi, off = f_i, (flat.data_ptr() - lo) // 4
                         break
                 assert gi is not None, "bucket is not a slice of this optimizer's flat gradients"
-                f, group = self._groups[gi], self.param_groups[gi]
-                n = flat.numel()
-                _lib.call("sig3d_adamw_flat", n, ctypes.c_void_p(f["p"].data_ptr() + 4 * off),
-                          ctypes.c_void_p(f["g"].data_ptr() + 4 * off),
-                          ctypes.c_void_p(f["m"].data_ptr() + 4 * off),
-                          ctypes.c_void_p(f["v"].data_ptr() + 4 * off), _lib.ptr(self._step),
-                          ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
-                          ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
-                          ctypes.c_float(self.clip_value), 0, stream)
+                self._adamw_ranges([(gi, off, off + flat.numel())], stream)
 
     def zero_grad(self, set_to_none=True):
         for p, _, _ in self._params:
@@ -260,24 +311,97 @@ class FlatAdamW(torch.optim.Optimizer):
         stream = _lib.stream_ptr(dev)
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
+        self.sync_lr()
         with torch.cuda.device(dev):
             _lib.call("sig3d_step_increment", _lib.ptr(self._step), stream)
             if self._gathered:
-                for group, f in zip(self.param_groups, self._groups):
-                    if f is None:
-                        continue
-                    _lib.call("sig3d_adamw_flat", f["total"], _lib.ptr(f["p"]), _lib.ptr(f["g"]),
-                              _lib.ptr(f["m"]), _lib.ptr(f["v"]), _lib.ptr(self._step),
-                              ctypes.c_float(group["lr"]), ctypes.c_float(b1), ctypes.c_float(b2),
-                              ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
-                              ctypes.c_float(self.clip_value), 0, stream)
+                self._adamw_ranges([(gi, 0, f["total"]) for gi, f in enumerate(self._groups) if f is not None],
+                                   stream)
                 self._gathered = False
             else:
                 self._upload()
                 _lib.call("sig3d_adamw_table", len(self._static), _lib.ptr(self._table),
-                          _lib.ptr(self._step), ctypes.c_float(g0["lr"]), ctypes.c_float(b1),
-                          ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
+                          _lib.ptr(self._step), ctypes.c_float(g0["lr"]), _lib.ptr(self._lr_dev),
+                          ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
                           ctypes.c_float(self.clip_value), stream)
                 for p, _, _ in self._params:
                     p.grad = None
         return loss
+
+    # ---- checkpointing (torch.optim.AdamW layout) ----------------------------------------------------
+    def _indexed_params(self):
+        """[(state index, parameter)] in torch's convention: positions in the concatenated group lists."""
+        out, i = [], 0
+        for group in self.param_groups:
+            for p in group["params"]:
+                out.append((i, p))
+                i += 1
+        return out
+
+    def _moment_views(self):
+        views = {}
+        for p, gi, off in self._params:
+            f = self._groups[gi]
+            views[id(p)] = (f["m"][off:off + p.numel()].view_as(p), f["v"][off:off + p.numel()].view_as(p))
+        return views
+
+    def state_dict(self):
+        """What torch.optim.AdamW(...).state_dict() would hold after the same steps (lib/solver.py:657
+        saves it, train.py:262 loads it): state[i] = {step, exp_avg, exp_avg_sq} per parameter index."""
+        views = self._moment_views()
+        step = float(self._step.item())
+        state = {}
+        for i, p in self._indexed_params():
+            if id(p) in views and step > 0:
+                m, v = views[id(p)]
+                state[i] = {"step": torch.tensor(step, dtype=torch.float32), "exp_avg": m.clone(),
+                            "exp_avg_sq": v.clone()}
+        groups, i = [], 0
+        for group in self.param_groups:
+            g = {k: v for k, v in group.items() if k != "params"}
+            g.update(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=True)
+            g["params"] = list(range(i, i + len(group["params"])))
+            i += len(group["params"])
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        """Accepts this class's and torch.optim.AdamW's / Adam's state_dict (same groups and parameter
+        order): moments are copied into the flat buffers, the step counter is the (common) per-parameter
+        `step`; parameters without an entry start from zero moments like in torch."""
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups) or any(
+                len(a["params"]) != len(b["params"]) for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        for mine, theirs in zip(self.param_groups, groups):
+            for k in ("lr", "eps", "weight_decay"):
+                if k in theirs:
+                    mine[k] = theirs[k]
+            if "betas" in theirs:
+                mine["betas"] = tuple(theirs["betas"])
+            if theirs.get("amsgrad"):
+                raise ValueError("FlatAdamW has no amsgrad state")
+        views = self._moment_views()
+        steps = set()
+        for f in self._groups:
+            if f is not None:
+                f["m"].zero_()
+                f["v"].zero_()
+        for i, p in self._indexed_params():
+            st = state_dict["state"].get(i)
+            if st is None or id(p) not in views:
+                continue
+            m, v = views[id(p)]
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            steps.add(float(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW keeps ONE step counter; the loaded per-parameter steps differ: %s"
+                             % sorted(steps))
+        self._step.fill_(steps.pop() if steps else 0.0)
+        # weight decay sits in the static chunk table; learning rate in the device scalar
+        for k, pi in enumerate(self._owners):
+            self._static["wd"][k] = self.param_groups[self._params[pi][1]]["weight_decay"]
+        self._flat_tables.clear()
+        self.sync_lr()

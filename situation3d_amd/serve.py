@@ -11,7 +11,7 @@ import torch
 
 from . import gemm_tuning
 from .geometry import GeometryPlan
-from .graph_step import _clone, _copy_into
+from .graph_step import Announced, _clone, _copy_into
 
 
 class GraphedForward:
@@ -29,7 +29,7 @@ class GraphedForward:
         self.static_next_xyz = pc[..., :3].contiguous()
         self.side = torch.cuda.Stream(pc.device)
         self.plan_cur.compute(self.static_next_xyz)
-        self._expected = None
+        self._announced = Announced()
 
         def fwd():
             batch = dict(self.static_batch)
@@ -50,14 +50,15 @@ class GraphedForward:
             self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
         torch.cuda.synchronize()
 
-    def __call__(self, batch, next_batch):
+    def __call__(self, batch, next_batch, token=None, next_token=None):
         """Outputs of `batch`; `next_batch` announces the batch of the following call (its geometry is
-        computed under this call's forward).  Breaking the announced order costs one inline geometry chain."""
-        key = batch["point_clouds"].data_ptr()
-        if self._expected != key:
+        computed under this call's forward).  Breaking the announced order costs one inline geometry chain.
+        The hand-over is keyed on explicit tokens or on tensor identity + version (graph_step.Announced),
+        never on a device address."""
+        if not self._announced.matches(batch["point_clouds"], token):
             self.plan_cur.compute(batch["point_clouds"][..., :3].contiguous())
-        self._expected = next_batch["point_clouds"].data_ptr()
         self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
+        self._announced.set(next_batch["point_clouds"], next_token)
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         return self.static_out

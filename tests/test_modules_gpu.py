@@ -404,3 +404,47 @@ def test_graphed_forward_with_prefetched_geometry_matches_inline():
             out = step(batches[i], batches[nxt])
             assert torch.equal(out["answer_scores"], refs[i]), (k, i)
     torch.cuda.synchronize()
+
+
+def test_prefetched_geometry_is_never_reused_for_a_refilled_buffer():
+    """a loader that refills ONE device buffer in place hands the same address over every step.
+    The forked geometry branch must not be trusted then (identity = tensor object + version, or explicit
+    tokens): every output equals the inline forward of the CURRENT contents, with and without tokens."""
+    import bench
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.serve import GraphedForward
+    dev = torch.device(DEV)
+    torch.manual_seed(4)
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64)
+    model = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(dev).eval()
+    scenes = []
+    for i in range(4):
+        bt = bench.synthetic_batch(2, 6000, 80 + i, dev)
+        bt["q_feat"]["input_ids"] = bt["q_feat"]["input_ids"] % 100
+        scenes.append(bt)
+    work = torch.cuda.Stream(dev)
+    with torch.cuda.stream(work), torch.no_grad():
+        refs = [model(dict(bt))["answer_scores"].clone() for bt in scenes]
+        step = GraphedForward(model, scenes[0])
+        staging = {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in scenes[0].items()}
+        for use_tokens in (False, True):
+            for i in range(4):
+                staging["point_clouds"].copy_(scenes[i]["point_clouds"])      # refill in place
+                staging["auxiliary_task"].copy_(scenes[i]["auxiliary_task"])
+                staging["q_feat"] = scenes[i]["q_feat"]
+                # the caller "announces" the same buffer as the next batch: same address every time
+                kw = dict(token=i, next_token=i + 1) if use_tokens else {}
+                out = step(staging, staging, **kw)
+                assert torch.equal(out["answer_scores"], refs[i]), (use_tokens, i)
+    torch.cuda.synchronize()
+
+
+def test_cooperative_fps_reports_no_timeouts():
+    from situation3d_amd import _lib
+    from util import scene
+    import pointnet2._ext as ext
+    _lib.fps_timeouts(reset=True)
+    idx = ext.furthest_point_sampling(scene(8, 40000, seed=3).to(DEV), 256)
+    torch.cuda.synchronize()
+    assert int(idx.min()) >= 0 and _lib.fps_timeouts() == 0
