@@ -71,19 +71,17 @@ def group_algorithmic_bytes(b, n, m, ns, c):
     return b * (4 * 3 * n + 4 * c * n + 4 * m * ns + 4 * (3 + c) * m * ns)
 
 
-def cpu_baseline(model, seed):
-    """The same step on the host cores through the ORACLE (kind "port"): CPU_SCENES scenes of the
-    B=8 workload as one batch, forward + backward (~10 s).  Checker code only -- never on the
-    product path."""
+def oracle_forward(cpu_model, batch):
+    """The composed path of `batch` on the HOST through the oracle: the nine native ops from
+    oracle/pointnet2_oracle.c (bound as `pointnet2._ext` under this build's module stack), SharedMLP on
+    torch CPU, the Q-Former through oracle/qformer_ref.py (eval-mode dropout) -> data_dict with the model's
+    output keys and the loss.  Checker code only -- never on the product path."""
     from oracle import pointnet2_ref, qformer_ref
     from situation3d_amd.pointnet2 import pointnet2_utils
-    import copy
-    cpu_model = copy.deepcopy(model).cpu().train()
-    batch = synthetic_batch(CPU_SCENES, N_POINTS, seed, "cpu")
     saved_ext = pointnet2_utils._ext
     pointnet2_utils._ext = pointnet2_ref  # CPU restatement of the nine ops
     try:
-        t0 = time.perf_counter()
+        n = batch["point_clouds"].shape[0]
         pc = batch["point_clouds"]
         xyz = pc[..., :3].contiguous()
         feats = pc[..., 3:].transpose(1, 2).contiguous()
@@ -92,7 +90,8 @@ def cpu_baseline(model, seed):
         pose = batch["auxiliary_task"]
         M = pointnet2_ref.pose_to_matrix(pose)
         sit = torch.einsum("bcr,bnc->bnr", M[:, :3, :3], tok_xyz - pose[:, None, :3])
-        tokens = tok_feat + cpu_model.pos_embed(sit)
+        tokens = tok_feat + cpu_model.pos_embed(sit if getattr(cpu_model, "pos_embed_dim", 3) == 3
+                                                else tok_xyz[..., :2])
         sd = dict(cpu_model.Qformer.bert.state_dict())
         sd.update({k: v for k, v in cpu_model.Qformer.bert.named_parameters()})
         c = cpu_model.Qformer.config
@@ -100,25 +99,61 @@ def cpu_baseline(model, seed):
                    layer_norm_eps=c.layer_norm_eps, add_cross_attention=True,
                    cross_attention_freq=c.cross_attention_freq)
         q = batch["q_feat"]
-        att = torch.cat([torch.ones(CPU_SCENES, N_QUERY, dtype=torch.long), q["attention_mask"]], 1)
-        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=cpu_model.query_tokens.expand(CPU_SCENES, -1, -1),
+        nq = cpu_model.query_tokens.shape[1]
+        att = torch.cat([torch.ones(n, nq, dtype=torch.long), q["attention_mask"]], 1)
+        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=cpu_model.query_tokens.expand(n, -1, -1),
                                         input_ids=q["input_ids"], attention_mask=att,
                                         encoder_hidden_states=tokens)
-        pooled = hidden[:, :N_QUERY].mean(1)
+        fused = hidden[:, :nq]
+        pooled = fused.mean(1)
         dd = dict(batch)
+        dd["scene_positions"], dd["att_feat_pre"], dd["att_feat_ori"] = tok_xyz, tok_feat, fused
         dd["aux_scores"] = cpu_model.aux_reg(pooled)
         dd["answer_scores"] = cpu_model.answer_cls(pooled)
-        loss, _ = get_loss(dd)
-        loss.backward()
-        dt = time.perf_counter() - t0
+        get_loss(dd)
     finally:
         pointnet2_utils._ext = saved_ext
+    return dd
+
+
+def _without_dropout(model):
+    """The oracle's Q-Former is eval-mode (dropout = identity) while BatchNorm keeps batch statistics:
+    the comparable product run is train mode with every dropout probability at zero."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model
+
+
+def cpu_baseline(model, seed):
+    """The same step on the host cores through the ORACLE (kind "port"): CPU_SCENES scenes of the
+    B=8 workload as one batch, forward + backward (~10 s) -- and, for free, an end-to-end parity check at
+    full size: the same scenes with the same (trained) weights through the HIP path give `loss_gpu`."""
+    from oracle import pointnet2_ref
+    import copy
+    cpu_model = _without_dropout(copy.deepcopy(model).cpu().train())
+    batch = synthetic_batch(CPU_SCENES, N_POINTS, seed, "cpu")
+    t0 = time.perf_counter()
+    dd = oracle_forward(cpu_model, batch)
+    dd["loss"].backward()
+    dt = time.perf_counter() - t0
+    dev = next(model.parameters()).device
+    gpu_model = _without_dropout(copy.deepcopy(model).train())
+    with torch.no_grad():
+        out = gpu_model(to_device(batch, dev))
+        loss_gpu, _ = get_loss(out)
+    loss_cpu, loss_gpu = float(dd["loss"].detach()), float(loss_gpu)
+    scores_diff = float((out["answer_scores"].cpu() - dd["answer_scores"].detach()).abs().max())
     threads = max(pointnet2_ref.num_threads(), torch.get_num_threads())
     return {"value": round(CPU_SCENES / dt, 4), "unit": "samples/s", "cores": threads,
             "kind": "port",
             "sample": "%d scenes (B=%d of the B=8 step), 40k pts, fwd+bwd, oracle C ops (OpenMP, %d threads) + "
                       "torch CPU fp32 MLP/Q-Former (%d threads), %.1f s of wall time"
-                      % (CPU_SCENES, CPU_SCENES, pointnet2_ref.num_threads(), torch.get_num_threads(), dt)}
+                      % (CPU_SCENES, CPU_SCENES, pointnet2_ref.num_threads(), torch.get_num_threads(), dt),
+            # full-size end-to-end parity of the timed model (trained weights, dropout off, same scenes)
+            "loss_cpu": round(loss_cpu, 5), "loss_gpu": round(loss_gpu, 5),
+            "loss_rel_diff": float("%.3g" % (abs(loss_cpu - loss_gpu) / max(abs(loss_cpu), 1e-12))),
+            "answer_scores_max_abs_diff": float("%.3g" % scores_diff)}
 
 
 def main():

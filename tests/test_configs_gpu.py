@@ -1,0 +1,200 @@
+"""BASELINE.json configs at their full sizes against the oracle:
+  config 2  SQA3D forward-only, 40 000 points, 32 queries + 20 question tokens, B = 4, eval mode
+            (fused-inference SharedMLP path, running BatchNorm statistics) -- every output of
+            forward(data_dict) against the same weights pushed through oracle/pointnet2_oracle.c +
+            oracle/qformer_ref.py (bench.oracle_forward);
+  config 3  the B = 8 train-mode forward + loss the bench times (dropout off), same comparison;
+  config 5  the 3D-LLM shape: Blip2PointQFormer, B = 4, d_enc 1408, Nk = 80 000 (forward; key-split
+            attention) and the reference's Nk = 5000 (forward + backward) against qformer_ref + blip2_ref;
+  full-size Q-Former: 768 wide / 12 layers / 12 heads, B = 8, 32 + 20 tokens, Nk = 256, forward + backward
+            against qformer_ref (which the reference's own Qformer.py pins: tests/test_oracle_golden.py).
+fp32 activations within 1e-4 (north star), relative to the tensor's scale; tolerances written at each assert.
+"""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _sig3d(train, batch_size, seed):
+    import bench
+    from situation3d_amd.model import SIG3DQFormer
+    torch.manual_seed(seed)
+    model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS)
+    # non-trivial BatchNorm running statistics / affine so that eval mode is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    model = model.train() if train else model.eval()
+    bench._without_dropout(model)
+    cpu_model = copy.deepcopy(model)
+    batch = bench.synthetic_batch(batch_size, bench.N_POINTS, seed + 2, "cpu")
+    return bench, model.to(DEV), cpu_model, batch
+
+
+def _compare_outputs(out, ref):
+    # indices first: the token positions are FPS picks of FPS picks -- bit-exact or everything below is noise
+    assert torch.equal(out["scene_positions"].cpu(), ref["scene_positions"]), "SA4 centres differ"
+    for key, tol in (("att_feat_pre", 1e-4), ("att_feat_ori", 1e-4), ("answer_scores", 1e-4), ("aux_scores", 1e-4)):
+        r = _rel(out[key].detach().cpu(), ref[key].detach())
+        assert r < tol, "%s: relative max error %.3g" % (key, r)     # 1e-4: north-star fp32 bar
+    r = abs(float(out["loss"]) - float(ref["loss"])) / abs(float(ref["loss"]))
+    assert r < 1e-4, "loss: relative error %.3g" % r
+
+
+def test_config2_sqa3d_forward_only_b4_40k_eval_matches_oracle():
+    bench, model, cpu_model, batch = _sig3d(train=False, batch_size=4, seed=21)
+    from situation3d_amd.trainer import get_loss
+    with torch.no_grad():
+        ref = bench.oracle_forward(cpu_model, batch)
+        out = model(bench.to_device(batch, DEV))
+        get_loss(out)
+    _compare_outputs(out, ref)
+
+
+def test_config3_sqa3d_train_forward_b8_40k_matches_oracle():
+    """Train mode (BatchNorm batch statistics over 8 scenes; compact set abstraction where the lists are
+    mostly padding), forward + loss, and the gradient of the loss w.r.t. a few parameters."""
+    bench, model, cpu_model, batch = _sig3d(train=True, batch_size=8, seed=31)
+    from situation3d_amd.trainer import get_loss
+    ref = bench.oracle_forward(cpu_model, batch)
+    ref["loss"].backward()
+    out = model(bench.to_device(batch, DEV))
+    loss, out = get_loss(out)
+    loss.backward()
+    _compare_outputs(out, ref)
+    cpu_params = dict(cpu_model.named_parameters())
+    checked = 0
+    for name, p in model.named_parameters():
+        if name in ("query_tokens", "answer_cls.3.weight", "Qformer.bert.encoder.layer.0.crossattention.self.key.weight",
+                    "Qformer.bert.encoder.layer.11.output_query.dense.weight", "pos_embed.0.weight",
+                    "encoder.sa4.mlp_module.layer2.conv.weight", "encoder.sa1.mlp_module.layer0.conv.weight",
+                    "encoder.sa2.mlp_module.layer1.bn.bn.weight"):
+            r = _rel(p.grad.cpu(), cpu_params[name].grad)
+            assert r < 2e-3, "grad %s: relative max error %.3g" % (name, r)   # float atomics + 40k-point sums
+            checked += 1
+    assert checked == 8
+
+
+def _blip2(nk, b, seed):
+    from oracle import blip2_ref, qformer_ref
+    from situation3d_amd.blip2 import Blip2PointQFormer
+    torch.manual_seed(seed)
+    model = Blip2PointQFormer().eval()       # 32 queries, d_enc 1408, bert-base Q-Former, t5_proj 768 -> 2048
+    g = torch.Generator().manual_seed(seed + 1)
+    samples = {"pc_feat": torch.randn(b, nk, 1408, generator=g),
+               "pc": torch.randint(0, 256, (b, nk, 3), generator=g).float()}
+
+    def reference(requires_grad):
+        feat = samples["pc_feat"].clone().requires_grad_(requires_grad)
+        # blip2_ref is the loop-for-loop restatement of blip2_t5.py:106-118 (it allocates a second (B,Nk,1408) tensor)
+        enc = blip2_ref.add_position_embedding(feat, samples["pc"], model.pos_embedding, 0.01)
+        sd = dict(model.Qformer.bert.state_dict())
+        sd.update(dict(model.Qformer.bert.named_parameters()))
+        c = model.Qformer.config
+        cfg = dict(num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                   layer_norm_eps=c.layer_norm_eps, add_cross_attention=True, cross_attention_freq=c.cross_attention_freq)
+        hidden = qformer_ref.bert_model(sd, cfg, query_embeds=model.query_tokens.expand(b, -1, -1),
+                                        encoder_hidden_states=enc, encoder_attention_mask=torch.ones(b, nk))
+        return feat, hidden, model.t5_proj(hidden)
+
+    return model, samples, reference
+
+
+def test_config5_blip2_shape_nk80000_forward_matches_oracle():
+    """B = 4, Nk = 80 000 point tokens of width 1408 (1.8 GB of features): key-split attention forward."""
+    model, samples, reference = _blip2(80000, 4, seed=51)
+    with torch.no_grad():
+        _, hidden, t5 = reference(False)
+        gpu = copy.deepcopy(model).to(DEV)
+        out = gpu({k: v.to(DEV) for k, v in samples.items()})
+    assert _rel(out["query_output"].cpu(), hidden) < 1e-4          # north-star fp32 bar
+    assert _rel(out["inputs_t5"].cpu(), t5) < 1e-4
+
+
+def test_config5_blip2_reference_shape_nk5000_forward_backward_matches_oracle():
+    """The reference's own token count (threedvqa_datasets.py:72-79), B = 2, forward + backward incl. the
+    gradient w.r.t. the point features and the cross-attention key / value weights of the six cross layers."""
+    model, samples, reference = _blip2(5000, 2, seed=52)
+    G = torch.randn(2, 32, 2048, generator=torch.Generator().manual_seed(5))
+    feat, hidden, t5 = reference(True)
+    (t5 * G).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    gpu = copy.deepcopy(model).to(DEV)
+    gpu.zero_grad(set_to_none=True)
+    f = samples["pc_feat"].to(DEV).requires_grad_(True)
+    out = gpu({"pc_feat": f, "pc": samples["pc"].to(DEV)})
+    (out["inputs_t5"] * G.to(DEV)).sum().backward()
+    assert _rel(out["inputs_t5"].detach().cpu(), t5.detach()) < 1e-4
+    assert _rel(f.grad.cpu(), feat.grad) < 1e-3                    # 1408-long dot products, 12 layers deep
+    n = 0
+    for name, p in gpu.named_parameters():
+        if "crossattention.self" in name or name in ("query_tokens", "t5_proj.weight"):
+            assert _rel(p.grad.cpu(), ref_grads[name]) < 1e-3, name
+            n += 1
+    assert n >= 6 * 6
+
+
+def test_full_size_qformer_forward_backward_matches_oracle():
+    """768 wide / 12 layers / 12 heads / 6 cross-attention layers, B = 8, 32 queries + 20 question tokens,
+    256 scene tokens of width 256: the Q-Former the bench times, two-segment layout, against qformer_ref --
+    last hidden state, per-parameter gradients of every layer, gradient of the scene tokens."""
+    from oracle import qformer_ref
+    from situation3d_amd.qformer import init_Qformer
+    torch.manual_seed(61)
+    qf, query_tokens = init_Qformer(32, 256)
+    qf.eval()
+    g = torch.Generator().manual_seed(62)
+    with torch.no_grad():
+        for p in qf.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    B, T = 8, 20
+    enc = torch.randn(B, 256, 256, generator=g)
+    ids = torch.randint(1000, 30000, (B, T), generator=g)
+    att = torch.ones(B, 32 + T, dtype=torch.long)
+    att[3, -5:] = 0                                            # a padded question
+    G = torch.randn(B, 32 + T, 768, generator=g)
+    c = qf.config
+    cfg = dict(num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+               layer_norm_eps=c.layer_norm_eps, add_cross_attention=True, cross_attention_freq=c.cross_attention_freq)
+    sd = dict(qf.bert.state_dict())
+    sd.update(dict(qf.bert.named_parameters()))
+    e_ref = enc.clone().requires_grad_(True)
+    q_ref = query_tokens.detach().clone().requires_grad_(True)
+    ref = qformer_ref.bert_model(sd, cfg, query_embeds=q_ref.expand(B, -1, -1), input_ids=ids, attention_mask=att,
+                                 encoder_hidden_states=e_ref)
+    (ref * G).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in qf.bert.named_parameters() if p.grad is not None}
+    gpu = copy.deepcopy(qf).to(DEV)
+    gpu.zero_grad(set_to_none=True)
+    e = enc.to(DEV).requires_grad_(True)
+    q = query_tokens.detach().to(DEV).requires_grad_(True)
+    out = gpu.bert(query_embeds=q.expand(B, -1, -1), input_ids=ids.to(DEV), attention_mask=att.to(DEV),
+                   encoder_hidden_states=e, return_dict=True).last_hidden_state
+    (out * G.to(DEV)).sum().backward()
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-4           # north-star fp32 bar
+    assert _rel(e.grad.cpu(), e_ref.grad) < 1e-3
+    assert _rel(q.grad.cpu(), q_ref.grad) < 1e-3
+    worst, n = 0.0, 0
+    for name, p in gpu.bert.named_parameters():
+        if name == "embeddings.word_embeddings.weight":
+            rows = ids.unique()
+            r = _rel(p.grad[rows.to(DEV)].cpu(), ref_grads[name][rows])
+        else:
+            r = _rel(p.grad.cpu(), ref_grads[name])
+        worst, n = max(worst, r), n + 1
+        assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
+    assert n > 250, n

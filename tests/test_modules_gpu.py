@@ -427,16 +427,35 @@ def test_prefetched_geometry_is_never_reused_for_a_refilled_buffer():
     with torch.cuda.stream(work), torch.no_grad():
         refs = [model(dict(bt))["answer_scores"].clone() for bt in scenes]
         step = GraphedForward(model, scenes[0])
-        staging = {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in scenes[0].items()}
+
+        def fresh():
+            return {k: (dict(v) if isinstance(v, dict) else v.clone()) for k, v in scenes[0].items()}
+
+        def fill(buf, i):
+            buf["point_clouds"].copy_(scenes[i]["point_clouds"])       # refill in place
+            buf["auxiliary_task"].copy_(scenes[i]["auxiliary_task"])
+            buf["q_feat"] = scenes[i]["q_feat"]
+
+        # (1) ONE staging buffer refilled in place and (having nothing else) announced as its own successor:
+        #     same object, same address, new contents -> the version check must reject the prefetched plan
+        one = fresh()
+        for i in range(4):
+            fill(one, i)
+            assert torch.equal(step(one, one)["answer_scores"], refs[i]), ("one buffer", i)
+        # (2) a double-buffered loader: two buffers, each refilled in place every other step; the next batch
+        #     is complete when it is announced -> the prefetched plan is valid and must be used, keyed on
+        #     identity + version, or on the caller's tokens
         for use_tokens in (False, True):
+            bufs = [fresh(), fresh()]
+            fill(bufs[0], 0)
             for i in range(4):
-                staging["point_clouds"].copy_(scenes[i]["point_clouds"])      # refill in place
-                staging["auxiliary_task"].copy_(scenes[i]["auxiliary_task"])
-                staging["q_feat"] = scenes[i]["q_feat"]
-                # the caller "announces" the same buffer as the next batch: same address every time
+                fill(bufs[(i + 1) % 2], (i + 1) % 4)
                 kw = dict(token=i, next_token=i + 1) if use_tokens else {}
-                out = step(staging, staging, **kw)
+                out = step(bufs[i % 2], bufs[(i + 1) % 2], **kw)
                 assert torch.equal(out["answer_scores"], refs[i]), (use_tokens, i)
+        # (3) a caller that breaks its announcement (token mismatch) pays an inline chain, never a wrong plan
+        fill(bufs[0], 2)
+        assert torch.equal(step(bufs[0], bufs[1], token=77, next_token=78)["answer_scores"], refs[2])
     torch.cuda.synchronize()
 
 
