@@ -69,11 +69,29 @@ SIGNATURES = {
     "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _I, _P],
     "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],
     "sig3d_gather_table": [_I, _P, _P],
+    "sig3d_gemm": [_I, _I, _I, _I, _I, _I, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long,
+                   _P, ctypes.c_long, _I, _P, _I, _P, ctypes.c_long, _I, _I, _P],
     "sig3d_attention_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F,
                             ctypes.c_uint, _P, _I, _P, _P],
     "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _F, ctypes.c_uint, _P, _P],
 }
+
+
+class GemmProblem(ctypes.Structure):
+    """struct sig3d_gemm_problem of include/sig3d_hip.h (field order and types must match)."""
+    _fields_ = [("amode", _I), ("bmode", _I), ("batch", _I), ("m", _I), ("n", _I), ("k", _I), ("m_last", _I), ("k_last", _I),
+                ("A", _P), ("lda", _I), ("stride_a", ctypes.c_long),
+                ("B", _P), ("ldb", _I), ("stride_b", ctypes.c_long),
+                ("C", _P), ("ldc", _I), ("stride_c", ctypes.c_long),
+                ("bias", _P), ("stride_bias", ctypes.c_long),
+                ("act", _I), ("aux", _P), ("accumulate", _I),
+                ("rowsum", _P), ("stride_rowsum", ctypes.c_long),
+                ("tile", _I), ("ksplit", _I)]
+
+
+SIGNATURES["sig3d_gemm_group"] = [_I, ctypes.POINTER(GemmProblem), _P]
+
 INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes")
 
 _lib = None

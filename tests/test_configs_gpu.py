@@ -23,6 +23,13 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
+def _is_key_bias(name):
+    """softmax(q (k + b)^T) does not depend on a key bias b (it shifts every score of a row by q.b), so
+    d loss / d key.bias is EXACTLY zero; what both implementations return is rounding noise (~1e-9) that
+    cannot be compared relatively."""
+    return name.endswith("self.key.bias")
+
+
 def _sig3d(train, batch_size, seed):
     import bench
     from situation3d_amd.model import SIG3DQFormer
@@ -141,10 +148,11 @@ def test_config5_blip2_reference_shape_nk5000_forward_backward_matches_oracle():
     assert _rel(f.grad.cpu(), feat.grad) < 1e-3                    # 1408-long dot products, 12 layers deep
     n = 0
     for name, p in gpu.named_parameters():
-        if "crossattention.self" in name or name in ("query_tokens", "t5_proj.weight"):
-            assert _rel(p.grad.cpu(), ref_grads[name]) < 1e-3, name
+        if ("crossattention.self" in name or name in ("query_tokens", "t5_proj.weight")) and not _is_key_bias(name):
+            r = _rel(p.grad.cpu(), ref_grads[name])
+            assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
             n += 1
-    assert n >= 6 * 6
+    assert n >= 6 * 5
 
 
 def test_full_size_qformer_forward_backward_matches_oracle():
@@ -190,6 +198,9 @@ def test_full_size_qformer_forward_backward_matches_oracle():
     assert _rel(q.grad.cpu(), q_ref.grad) < 1e-3
     worst, n = 0.0, 0
     for name, p in gpu.bert.named_parameters():
+        if _is_key_bias(name):
+            assert float(p.grad.abs().max()) < 1e-5 and float(ref_grads[name].abs().max()) < 1e-5
+            continue
         if name == "embeddings.word_embeddings.weight":
             rows = ids.unique()
             r = _rel(p.grad[rows.to(DEV)].cpu(), ref_grads[name][rows])
@@ -197,4 +208,4 @@ def test_full_size_qformer_forward_backward_matches_oracle():
             r = _rel(p.grad.cpu(), ref_grads[name])
         worst, n = max(worst, r), n + 1
         assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
-    assert n > 250, n
+    assert n > 230, n
