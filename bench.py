@@ -34,11 +34,15 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s sp
 SA_LEVELS = [(40000, 2048, 64, 3), (2048, 1024, 32, 128), (1024, 512, 16, 256), (512, 256, 16, 256)]
 
 
-def synthetic_batch(batch, n_points, seed, device):
+def synthetic_batch(batch, n_points, seed, device, surface=False):
     """xyz ~ U([0,8]x[0,8]x[0,3]) m, colours U(0,1), pose = U(room) +
-    z-rotation quaternion, 20 question token ids U(1000,30000), soft multi-hot answers."""
+    z-rotation quaternion, 20 question token ids U(1000,30000), soft multi-hot answers.
+    surface=True: the points lie on room surfaces instead (surface_points)."""
     g = torch.Generator().manual_seed(seed)
-    xyz = torch.rand(batch, n_points, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    if surface:
+        xyz = surface_points(batch, n_points, g)
+    else:
+        xyz = torch.rand(batch, n_points, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
     rgb = torch.rand(batch, n_points, 3, generator=g)
     t = torch.rand(batch, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
     ang = (torch.rand(batch, generator=g) * 2 - 1) * 3.14159265
@@ -53,6 +57,38 @@ def synthetic_batch(batch, n_points, seed, device):
         "answer_cat_scores": ans,
     }
     return to_device(d, device)
+
+
+def surface_points(batch, n_points, g):
+    """ScanNet-shaped SURFACE scenes: points on the floor, the four walls and the faces of a dozen furniture
+    boxes of an 8 x 8 x 3 m room (+ 5 mm sensor noise), area-proportional -- real scans are surfaces, so
+    neighbour lists are fuller than in the volume-uniform distribution SURVEY.md 8d prescribes for the
+    headline (where 89-96 % of the SA1 / SA2 list entries are padding)."""
+    out = torch.empty(batch, n_points, 3)
+    for b in range(batch):
+        faces = [((0.0, 0.0, 0.0), (8.0, 0.0, 0.0), (0.0, 8.0, 0.0))]                      # floor: origin, edge u, edge v
+        for o, u in (((0, 0, 0), (8, 0, 0)), ((0, 8, 0), (8, 0, 0)), ((0, 0, 0), (0, 8, 0)), ((8, 0, 0), (0, 8, 0))):
+            faces.append((tuple(map(float, o)), tuple(map(float, u)), (0.0, 0.0, 3.0)))    # walls
+        nbox = 12
+        lo = torch.rand(nbox, 2, generator=g) * 6.5 + 0.25
+        sz = torch.rand(nbox, 3, generator=g) * torch.tensor([1.6, 1.6, 1.4]) + 0.3
+        for i in range(nbox):
+            x0, y0 = lo[i].tolist()
+            sx, sy, sz_ = sz[i].tolist()
+            faces.append(((x0, y0, sz_), (sx, 0.0, 0.0), (0.0, sy, 0.0)))                   # top
+            faces.append(((x0, y0, 0.0), (sx, 0.0, 0.0), (0.0, 0.0, sz_)))                  # four sides
+            faces.append(((x0, y0 + sy, 0.0), (sx, 0.0, 0.0), (0.0, 0.0, sz_)))
+            faces.append(((x0, y0, 0.0), (0.0, sy, 0.0), (0.0, 0.0, sz_)))
+            faces.append(((x0 + sx, y0, 0.0), (0.0, sy, 0.0), (0.0, 0.0, sz_)))
+        o = torch.tensor([f[0] for f in faces])
+        u = torch.tensor([f[1] for f in faces])
+        v = torch.tensor([f[2] for f in faces])
+        area = torch.linalg.cross(u, v).norm(dim=1)
+        which = torch.multinomial(area / area.sum(), n_points, replacement=True, generator=g)
+        st = torch.rand(n_points, 2, generator=g)
+        pts = o[which] + st[:, :1] * u[which] + st[:, 1:] * v[which]
+        out[b] = pts + torch.randn(n_points, 3, generator=g) * 0.005
+    return out
 
 
 def to_device(d, device):
@@ -71,7 +107,7 @@ def group_algorithmic_bytes(b, n, m, ns, c):
     return b * (4 * 3 * n + 4 * c * n + 4 * m * ns + 4 * (3 + c) * m * ns)
 
 
-def oracle_forward(cpu_model, batch):
+def oracle_forward(cpu_model, batch, backward=False):
     """The composed path of `batch` on the HOST through the oracle: the nine native ops from
     oracle/pointnet2_oracle.c (bound as `pointnet2._ext` under this build's module stack), SharedMLP on
     torch CPU, the Q-Former through oracle/qformer_ref.py (eval-mode dropout) -> data_dict with the model's
@@ -111,6 +147,8 @@ def oracle_forward(cpu_model, batch):
         dd["aux_scores"] = cpu_model.aux_reg(pooled)
         dd["answer_scores"] = cpu_model.answer_cls(pooled)
         get_loss(dd)
+        if backward:   # the grouping / gather backward ops dispatch through `_ext` too: still bound to the oracle
+            dd["loss"].backward()
     finally:
         pointnet2_utils._ext = saved_ext
     return dd
@@ -134,8 +172,7 @@ def cpu_baseline(model, seed):
     cpu_model = _without_dropout(copy.deepcopy(model).cpu().train())
     batch = synthetic_batch(CPU_SCENES, N_POINTS, seed, "cpu")
     t0 = time.perf_counter()
-    dd = oracle_forward(cpu_model, batch)
-    dd["loss"].backward()
+    dd = oracle_forward(cpu_model, batch, backward=True)
     dt = time.perf_counter() - t0
     dev = next(model.parameters()).device
     gpu_model = _without_dropout(copy.deepcopy(model).train())
@@ -156,12 +193,136 @@ def cpu_baseline(model, seed):
             "answer_scores_max_abs_diff": float("%.3g" % scores_diff)}
 
 
+TIMED_ENTRY_POINTS = ["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
+                      "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query",
+                      "sig3d_ball_query_grid", "sig3d_furthest_point_sampling"]
+KSTEPS = 3   # eager steps bracketed with HIP events after the timed region
+
+
+def measure(args, rank, world, device, steps, warmup, surface=False, compact=True, kernels=True):
+    """Build model + optimizer + (graphed) step for one data / mode variant, time `steps` steps between
+    barriers + synchronize, optionally bracket the hand-written kernels of KSTEPS eager steps with HIP events.
+    -> dict(dt, final_loss, recs, model, compact_info, use_graph, n_act)."""
+    from situation3d_amd.pointnet2 import fused_mlp
+    saved_compact = fused_mlp.COMPACT
+    fused_mlp.COMPACT = bool(compact) and saved_compact
+    try:
+        torch.manual_seed(1234)  # identical initial weights on every rank (and in every variant)
+        model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
+        # clip_grad_value_(1.0) + AdamW (lr 2e-5, wd 0.05: scripts/train.sh:7) + zero_grad fused over
+        # flat storage; under data parallelism the same flat gradient buffers are all-reduced in place
+        optimizer = build_optimizer(model, name="adamw" if args.torch_adamw else "flat_adamw")
+        reducer = None
+        if world > 1 or args.force_reducer:
+            reducer = (GradBucketReducer(model.parameters()) if args.torch_adamw
+                       else GradBucketReducer.from_flat(optimizer.flat_grad_buffers()))
+        n_batches = min(4, steps + warmup)
+        batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device, surface=surface)
+                   for i in range(n_batches)]
+        # every forward/backward of this process runs on ONE non-default stream (see graph_step.py)
+        work = torch.cuda.Stream(device)
+        recs, graphed = None, None
+        with torch.cuda.stream(work):
+            use_graph = not args.no_graph
+            if use_graph:
+                graphed = GraphedTrainStep(model, optimizer, batches[0],
+                                           prefetch_geometry=not args.no_prefetch, reducer=reducer)
+
+                def step(i):
+                    return graphed(batches[i % n_batches], batches[(i + 1) % n_batches])
+            else:
+                def step(i):
+                    return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+
+            for i in range(warmup):
+                step(i)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = step(warmup + i)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            final_loss = float(loss.item())
+            if kernels:
+                # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
+                # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
+                # issued once more eagerly right after the timed region and bracketed there.
+                _lib.enable_timing(TIMED_ENTRY_POINTS)
+                if reducer is not None:
+                    reducer.hooks_enabled = True
+                for i in range(KSTEPS):
+                    train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+                torch.cuda.synchronize()
+                recs = _lib.timing_records()
+                _lib.enable_timing(None)
+        # set-abstraction levels that ran over the distinct neighbours only, with the fraction of their
+        # (centre, sample) positions that are distinct on the last batch (DESIGN.md 5d)
+        compact_info, distinct = {}, {}
+        plan = getattr(graphed, "plan_cur", None)
+        if plan is not None:
+            for li, cl in enumerate(plan.compact):
+                if cl is not None:
+                    bsz, mpt, nsm = cl.shape
+                    frac = float(cl.n_act.float().mean().item()) / (mpt * nsm)
+                    distinct["SA%d" % (li + 1)] = round(frac, 4)
+                    layer = getattr(model.encoder, "sa%d" % (li + 1))
+                    if getattr(layer, "_compact_decision", False):
+                        compact_info["SA%d" % (li + 1)] = round(frac, 4)
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return dict(dt=float(t.item()), final_loss=final_loss, recs=recs, model=model, compact_info=compact_info,
+                    distinct=distinct, use_graph=use_graph)
+    finally:
+        fused_mlp.COMPACT = saved_compact
+
+
+def ball_query_algorithmic_bytes(b, n, m, ns):
+    """B*(12N + 12M + 4*M*ns)"""
+    return b * (12 * n + 12 * m + 4 * m * ns)
+
+
+def pair_roofline(recs, distinct):
+    """The pair the north star names -- ball_query + group_points -- over ALL FOUR levels of a step, from the
+    event-bracketed eager launches: achieved = algorithmic bytes / summed duration.  Dense grouping launches
+    count SURVEY.md 8d's bytes; a compact launch (distinct neighbours only) counts its OWN algorithmic bytes:
+    the sources it gathers from once, its index list and the columns it writes (distinct fraction x dense)."""
+    t_ms, nbytes, launches = 0.0, 0, 0
+    for name in ("sig3d_ball_query", "sig3d_ball_query_grid"):
+        for s_ev, e_ev, ints in recs[name]:
+            t_ms += s_ev.elapsed_time(e_ev)
+            nbytes += ball_query_algorithmic_bytes(ints[0], ints[1], ints[2], ints[3])
+            launches += 1
+    for name, pm in (("sig3d_query_group_fused", False), ("sig3d_query_group_fused_pm", True)):
+        for s_ev, e_ev, ints in recs[name]:
+            t_ms += s_ev.elapsed_time(e_ev)
+            nbytes += group_algorithmic_bytes(ints[0], ints[1], ints[2], ints[5] if pm else ints[4], ints[3])
+            launches += 1
+    for s_ev, e_ev, ints in recs["sig3d_query_group_compact"]:
+        bb, nn, mm, cc, ns_ = ints[0], ints[1], ints[2], ints[3], ints[5]
+        level = [k for k, (ln, lm, lns, lc) in zip(("SA1", "SA2", "SA3", "SA4"), SA_LEVELS) if (ln, lm, lns) == (nn, mm, ns_)]
+        frac = distinct.get(level[0], 1.0) if level else 1.0
+        t_ms += s_ev.elapsed_time(e_ev)
+        nbytes += int(bb * (12 * nn + 4 * cc * nn) + frac * bb * mm * ns_ * (4 + 4 * (3 + cc)))
+        launches += 1
+    for s_ev, e_ev, ints in recs["sig3d_transpose_cn"]:   # point-major copies feeding the wide levels: pure overhead
+        t_ms += s_ev.elapsed_time(e_ev)
+        launches += 1
+    return t_ms, nbytes, launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the dense-mode and surface-data lines printed beside the headline (N = 1 only)")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
     ap.add_argument("--torch-adamw", action="store_true",
                     help="torch.optim.AdamW + clip_grad_value_ instead of the fused flat optimizer")
@@ -180,85 +341,24 @@ def main():
     torch.cuda.set_device(device)
     if not args.no_gemm_tuning:
         gemm_tuning.enable(tune_missing=True)  # committed winners; unseen shapes tuned in warm-up
-    torch.manual_seed(1234)  # identical initial weights on every rank
-    model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
-    # clip_grad_value_(1.0) + AdamW (lr 2e-5, wd 0.05: scripts/train.sh:7) + zero_grad fused over
-    # flat storage; under data parallelism the same flat gradient buffers are all-reduced in place
-    optimizer = build_optimizer(model, name="adamw" if args.torch_adamw else "flat_adamw")
-    reducer = None
-    if world > 1 or args.force_reducer:
-        reducer = (GradBucketReducer(model.parameters()) if args.torch_adamw
-                   else GradBucketReducer.from_flat(optimizer.flat_grad_buffers()))
 
-    n_batches = min(4, args.steps + args.warmup)
-    batches = [synthetic_batch(BATCH, N_POINTS, 1234 + 1000 * rank + i, device) for i in range(n_batches)]
-
-    # every forward/backward of this process runs on ONE non-default stream (see graph_step.py)
-    work = torch.cuda.Stream(device)
-    KSTEPS = 3
-    with torch.cuda.stream(work):
-        use_graph = not args.no_graph
-        if use_graph:
-            graphed = GraphedTrainStep(model, optimizer, batches[0],
-                                       prefetch_geometry=not args.no_prefetch, reducer=reducer)
-
-            def step(i):
-                return graphed(batches[i % n_batches], batches[(i + 1) % n_batches])
-        else:
-            def step(i):
-                return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
-
-        for i in range(args.warmup):
-            step(i)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            loss = step(args.warmup + i)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        final_loss = float(loss.item())
-
-        # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
-        # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
-        # issued once more eagerly right after the timed region and bracketed there.
-        _lib.enable_timing(["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
-                            "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query", "sig3d_ball_query_grid",
-                            "sig3d_furthest_point_sampling"])
-        if reducer is not None:
-            reducer.hooks_enabled = True
-        for i in range(KSTEPS):
-            train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
-        torch.cuda.synchronize()
-        recs = _lib.timing_records()
-        _lib.enable_timing(None)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    # ---- headline: SURVEY.md 8d distribution (volume-uniform points), compact set abstraction where it pays
+    head = measure(args, rank, world, device, args.steps, args.warmup)
+    dt, recs, model = head["dt"], head["recs"], head["model"]
 
     if rank == 0:
         def kernel_ms(name):
-            r = recs[name]
-            return [s.elapsed_time(e) for s, e, _ in r]
+            return [s.elapsed_time(e) for s, e, _ in recs[name]]
 
-        # the grouping launches of a step: the narrow SA1 level through query_group_fused_kernel, the wide
-        # levels through its point-major twin (plus the small transposes that feed it, reported apart)
-        # Levels whose neighbour lists are mostly padding run in compact mode (distinct neighbours only:
-        # DESIGN.md 5d) and never form the dense grouped tensor; the roofline is taken over the launches
-        # that do, with the algorithmic bytes of exactly those launches (shapes from the recorded arguments).
+        # dense grouping launches alone (the kernel round 1 reported)
         grp, grp_bytes = [], 0
         for name, pm in (("sig3d_query_group_fused", False), ("sig3d_query_group_fused_pm", True)):
             for s_ev, e_ev, ints in recs[name]:
-                bb, nn, mm, cc = ints[0], ints[1], ints[2], ints[3]
-                ns_ = ints[5] if pm else ints[4]
                 grp.append(s_ev.elapsed_time(e_ev))
-                grp_bytes += group_algorithmic_bytes(bb, nn, mm, ns_, cc)
+                grp_bytes += group_algorithmic_bytes(ints[0], ints[1], ints[2], ints[5] if pm else ints[4], ints[3])
         cgrp = kernel_ms("sig3d_query_group_compact")
+        pair_ms, pair_bytes, pair_launches = pair_roofline(recs, head["distinct"])
+        pair_gbs = pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else 0.0
         # the largest HBM-bound kernel of the step by time is the flat AdamW update: per parameter it reads
         # p, g, m, v and writes p, m, v (28 B: clip + update in one pass; the gradients are dropped, not zeroed)
         adam = kernel_ms("sig3d_adamw_table") + kernel_ms("sig3d_adamw_flat")
@@ -268,19 +368,15 @@ def main():
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid")
         fps = kernel_ms("sig3d_furthest_point_sampling")
-        # HBM traffic of the roofline kernel cannot be read from inside this process: it comes from
-        # the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_query_group_fused.json")
-        if os.path.exists(pmc):
-            traffic = round(json.load(open(pmc))["traffic_bytes_per_launch"])
-        compact_info = {}
-        plan = getattr(graphed, "plan_cur", None) if use_graph else None
-        if plan is not None:
-            for li, cl in enumerate(plan.compact):
-                if cl is not None:
-                    bsz, mpt, nsm = cl.shape
-                    compact_info["SA%d" % (li + 1)] = round(float(cl.n_act.float().mean().item()) / (mpt * nsm), 4)
+        # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
+        # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
+        traffic, traffic_commit = None, None
+        for cand in ("r02_pmc_group_pair.json", "r01_pmc_query_group_fused.json"):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc):
+                j = json.load(open(pmc))
+                traffic, traffic_commit = round(j["traffic_bytes_per_launch"]), j.get("commit", "round 1 (0c8aecd)")
+                break
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -294,11 +390,24 @@ def main():
                                    "(32 queries + 20 question tokens, 12 layers)",
                        "global_batch": world * BATCH, "points_per_scene": N_POINTS,
                        "parallelism": "dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "query_group_fused_kernel + query_group_fused_pm_kernel",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),
-                         "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
+            # the pair the north star names, all four levels of a step, compact launches at their own bytes;
+            # dense-equivalent = SURVEY.md 8d's 314.8 MB per step over the same time
+            "roofline": {"bound": "hbm", "kernel": "ball_query (grid + scan) + query_group (fused / point-major / compact) "
+                                                   "+ point-major transposes, SA1-4",
+                         "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_commit": traffic_commit,
+                         "algorithmic_bytes_per_step": round(pair_bytes / KSTEPS),
+                         "launches_per_step": pair_launches // KSTEPS, "ms_per_step": round(pair_ms / KSTEPS, 4),
+                         "dense_equivalent_frac": round(sum(ball_query_algorithmic_bytes(BATCH, n, m, ns)
+                                                            + group_algorithmic_bytes(BATCH, n, m, ns, c)
+                                                            for n, m, ns, c in SA_LEVELS) * KSTEPS
+                                                        / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pair_ms else None},
+            "roofline_group_dense": {"bound": "hbm", "kernel": "query_group_fused_kernel + query_group_fused_pm_kernel "
+                                                               "(levels that form the dense grouped tensor)",
+                                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                     "algorithmic_bytes_per_launch": round(grp_bytes / max(len(grp), 1)),
+                                     "launches": len(grp), "avg_launch_us": round(sum(grp) / max(len(grp), 1) * 1e3, 2)},
             "roofline_adamw": {"bound": "hbm", "kernel": "adamw_table_kernel", "achieved": round(adam_gbs, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(adam_gbs / HBM_PEAK_GBS, 4),
                                "algorithmic_bytes_per_launch": 28 * n_params,
@@ -308,14 +417,35 @@ def main():
                                     "point_major_transposes": round(sum(tr) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
                                     "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},
-            # set-abstraction levels that ran over the distinct neighbours only, with the fraction of their
-            # (centre, sample) positions that are distinct on this batch
-            "compact_levels": compact_info,
-            "launch_mode": "hipGraph replay" if use_graph else "eager",
+            "compact_levels": head["compact_info"],
+            "distinct_neighbour_fraction": head["distinct"],
+            "launch_mode": "hipGraph replay" if head["use_graph"] else "eager",
             "library_gemms": "default heuristic" if args.no_gemm_tuning else "tuned (TunableOp)",
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(head["final_loss"], 5),
+            "fps_timeouts": _lib.fps_timeouts(),
         }
+    # ---- beside the headline (N = 1): the same step with every level dense, and on surface-shaped scenes
+    if world == 1 and not args.no_variants:
+        vsteps, vwarm = min(args.steps, 10), min(args.warmup, 3)
+        variants = {}
+        for key, kw in (("dense_sa (SIG3D_COMPACT=0), 8d data", dict(surface=False, compact=False)),
+                        ("synthetic-surface data", dict(surface=True, compact=True))):
+            del head, model
+            torch.cuda.empty_cache()
+            head = model = None
+            v = measure(args, rank, world, device, vsteps, vwarm, kernels=False, **kw)
+            variants[key] = {"ms_per_step": round(v["dt"] / vsteps * 1e3, 3),
+                             "value": round(BATCH * vsteps / v["dt"], 1), "unit": "samples/s", "steps": vsteps,
+                             "compact_levels": v["compact_info"], "distinct_neighbour_fraction": v["distinct"],
+                             "final_loss": round(v["final_loss"], 5)}
+            del v
+        if rank == 0:
+            out["variants"] = variants
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            if model is None:   # the variants released the headline's model: same seed, initial weights
+                torch.manual_seed(1234)
+                model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
             out["cpu_baseline"] = cpu_baseline(model, 1234)
         line = json.dumps(out)
     if dist.is_initialized():

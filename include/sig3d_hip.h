@@ -277,8 +277,11 @@ int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x, const flo
  * Dropout bits = hash(*rng_counter, call_id, element index): advance the device counter once per
  * forward pass (sig3d_counter_increment) so that hipGraph replays draw fresh masks.
  * part_rows > 0: bias / gamma / beta are (rows/part_rows, cols) and rows [p*part_rows, (p+1)*part_rows)
- * use parameter set p (the query and text feed-forward tails of a layer in one launch); <= 0: one set. */
-int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+ * use parameter set p (the query and text feed-forward tails of a layer in one launch); <= 0: one set.
+ * live_rows in (0, rows): rows [live_rows, rows) are PADDING of the two-segment layout -- x, v (and dx in the
+ * backward) hold live_rows rows only, out rows (dres rows in the backward) beyond are written as zeros, so
+ * that the projections around the tail run on the live rows alone; <= 0: all rows are live. */
+int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
                              const unsigned *rng_counter, const float *x, const float *bias,
                              const float *res, const float *gamma, const float *beta, float eps,
                              float *out, float *v, float *mean, float *rstd, unsigned short *mask,
@@ -289,7 +292,7 @@ int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, float p_drop, un
  * fully written here).  workspace: 3*cols*ceil(rows/4) floats of scratch (per-workgroup partial
  * column sums, folded without atomics: deterministic).  part_rows as in the forward: dparams is then
  * (parts, 3, cols) and part_rows must be a multiple of 4. */
-int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, const float *dy, const float *v,
+int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, int live_rows, float p_drop, const float *dy, const float *v,
                              const float *mean, const float *rstd, const float *gamma,
                              const unsigned short *mask, float *dx, float *dres, float *dparams,
                              float *workspace, void *stream);
@@ -298,12 +301,12 @@ int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, float p_drop, co
  * a_2 * (x - mean) / (std + eps) + b_2 with the UNBIASED standard deviation and eps added to the std):
  * SA / SGA compute norm(x + dropout(sublayer(x))) (mcan_sqa_module.py:216-224, 249-261).  rstd receives
  * 1/(std + eps); the backward needs eps again. */
-int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows, float p_drop, unsigned call_id,
+int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
                                     const unsigned *rng_counter, const float *x, const float *bias,
                                     const float *res, const float *gamma, const float *beta, float eps,
                                     float *out, float *v, float *mean, float *rstd, unsigned short *mask,
                                     void *stream);
-int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, float p_drop, float eps, const float *dy,
+int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, int live_rows, float p_drop, float eps, const float *dy,
                                     const float *v, const float *mean, const float *rstd, const float *gamma,
                                     const unsigned short *mask, float *dx, float *dres, float *dparams,
                                     float *workspace, void *stream);

@@ -58,12 +58,12 @@ SIGNATURES = {
     "sig3d_pos_embed_add": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "sig3d_column_sum": [_I, _I, _I, _P, _P, _P],
     "sig3d_bias_gelu": [_I, _I, _I, _P, _P, _P, _P, _P],
-    "sig3d_dropout_add_ln_fwd": [_I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+    "sig3d_dropout_add_ln_fwd": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                  _P, _P],
-    "sig3d_dropout_add_ln_bwd": [_I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "sig3d_dropout_add_mcan_norm_fwd": [_I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+    "sig3d_dropout_add_ln_bwd": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_dropout_add_mcan_norm_fwd": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                  _P, _P],
-    "sig3d_dropout_add_mcan_norm_bwd": [_I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_dropout_add_mcan_norm_bwd": [_I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_counter_increment": [_P, _P],
     "sig3d_step_increment": [_P, _P],
     "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _I, _P],

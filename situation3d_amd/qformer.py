@@ -117,16 +117,19 @@ def advance_dropout_seed(device):
 def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, mcan=False):
     """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask.
     part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows.
-    mcan: the MCAN blocks' normalisation (unbiased std, eps on the std) instead of nn.LayerNorm's."""
+    mcan: the MCAN blocks' normalisation (unbiased std, eps on the std) instead of nn.LayerNorm's.
+    x2 may hold fewer rows than the residual r2: the rows beyond are padding of the two-segment layout, the
+    kernel writes zeros there (out has r2's row count, v has x2's)."""
     dev = x2.device
-    rows, cols = x2.shape
-    out = torch.empty_like(x2)
+    live, cols = x2.shape
+    rows = r2.shape[0]
+    out = torch.empty((rows, cols), dtype=torch.float32, device=dev)
     v = torch.empty_like(x2)
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
         _lib.call("sig3d_dropout_add_mcan_norm_fwd" if mcan else "sig3d_dropout_add_ln_fwd", rows, cols, part_rows,
-                  ctypes.c_float(p_drop),
+                  live, ctypes.c_float(p_drop),
                   ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
                   _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
                   _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
@@ -136,10 +139,12 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, m
 
 def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
-    dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0)."""
-    rows, cols = v.shape
+    dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0).
+    v may hold fewer rows than dy2 (see _ln_tail_fwd): dx has v's rows, dres has dy2's with zeros beyond."""
+    live, cols = v.shape
+    rows = dy2.shape[0]
     dx = torch.empty_like(v)
-    dres = torch.empty_like(v)
+    dres = torch.empty((rows, cols), dtype=torch.float32, device=v.device)
     shape = (rows // part_rows, 3, cols) if part_rows > 0 else (3, cols)
     dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
     work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
@@ -147,9 +152,9 @@ def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None)
             _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work), _lib.stream_ptr(v.device))
     with torch.cuda.device(v.device):
         if mcan_eps is None:
-            _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, ctypes.c_float(p_drop), *tail)
+            _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, live, ctypes.c_float(p_drop), *tail)
         else:
-            _lib.call("sig3d_dropout_add_mcan_norm_bwd", rows, cols, part_rows, ctypes.c_float(p_drop),
+            _lib.call("sig3d_dropout_add_mcan_norm_bwd", rows, cols, part_rows, live, ctypes.c_float(p_drop),
                       ctypes.c_float(mcan_eps), *tail)
     return dx, dres, dparams
 
@@ -410,7 +415,11 @@ class _AttentionBlockFn(torch.autograd.Function):
     layout = (B, N, seg, base2, rows): x has `rows` storage rows; tokens [0, seg) of every batch
     element sit in rows [0, B*seg), the others from row base2 on (sig3d_attention_fwd); rows that
     hold no token are kept finite (zeros from the attention kernels, row-wise ops elsewhere) and
-    carry zero gradients.  seg == N, rows == B*N: plain (B, N) order."""
+    carry zero gradients.  seg == N, rows == B*N: plain (B, N) order.
+    Everything between the input and the LayerNorm tail runs on the LIVE rows only -- rows [0, L),
+    L = base2 + B*(N - seg): the padding behind the shorter segment (96 of 512 rows at B = 8 with 32
+    queries + 20 question tokens) costs no GEMM work; the tail kernels write the zeros the padded output
+    rows must hold (sig3d_dropout_add_ln_fwd / _bwd, live_rows)."""
 
     @staticmethod
     def forward(ctx, x, kv_src, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask, num_heads, p_attn,
@@ -419,45 +428,48 @@ class _AttentionBlockFn(torch.autograd.Function):
         dev = x.device
         b, nq, seg, base2, rows = layout
         assert x.shape[0] == rows
+        live = min(rows, base2 + b * (nq - seg)) if nq > seg else min(rows, b * seg)
+        xl = x[:live]
         hd = wq.shape[0]
         d = hd // num_heads
         scale = 1.0 / math.sqrt(d)
         if kv_src is None:  # self-attention
             w_all = _stacked((wq, wk, wv))
-            proj = torch.addmm(_stacked((bq, bk, bv)), x, w_all.t())      # (B*N, 3*hd)
+            proj = torch.addmm(_stacked((bq, bk, bv)), xl, w_all.t())     # (L, 3*hd)
             qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
-            klay = (seg, base2, rows)
+            klay = (seg, base2, live)
             kvproj, e2 = None, None
         else:
             nk = kv_src.shape[1]
             klay = (nk, 0, 0)
             e2 = kv_src.reshape(b * nk, kv_src.shape[2])
             w_all = _stacked((wk, wv))
-            proj = torch.addmm(bq, x, wq.t())                             # (B*N, hd)
+            proj = torch.addmm(bq, xl, wq.t())                            # (L, hd)
             kvproj = torch.addmm(_stacked((bk, bv)), e2, w_all.t())       # (B*Nk, 2*hd)
             qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
-        att = torch.empty((rows, hd), dtype=torch.float32, device=dev)
+        att = torch.empty((live, hd), dtype=torch.float32, device=dev)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
         _ks, _kw = _fwd_key_splits(b, num_heads, nq, nk, dev)
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], rows, klay[2],
+            _lib.call("sig3d_attention_fwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], live, klay[2],
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
                       _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         y = att.mm(wo.t())
         out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out)
         ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)
-        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, rows, klay)
+        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep = ctx.saved_tensors
-        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, rows, klay = ctx.cfg
+        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay = ctx.cfg
         dev = x.device
         d = hd // num_heads
+        xl = x[:live]
         dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden)
         gwo = dyo.t().mm(att)
         datt = dyo.mm(wo)
@@ -473,22 +485,22 @@ class _AttentionBlockFn(torch.autograd.Function):
             dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
             ldq, ldk, ldv = hd, 2 * hd, 2 * hd
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], rows, klay[2],
+            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], live, klay[2],
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
         tail = (gwo, dparams[2], dparams[0], dparams[1]) + (None,) * 8
         if self_attn:
-            gx = dres.addmm_(dproj, w_all)             # residual + projection paths in one epilogue
-            gw = dproj.t().mm(x)                       # (3*hd, c)
+            dres[:live].addmm_(dproj, w_all)           # residual + projection paths in one epilogue
+            gw = dproj.t().mm(xl)                      # (3*hd, c)
             gb = _colsum(dproj)
-            return (gx, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:]) + tail
+            return (dres, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:]) + tail
         e2 = kv_src.reshape(b * nk, kv_src.shape[2])
-        gx = dres.addmm_(dproj, wq)
-        gwq, gbq = dproj.t().mm(x), _colsum(dproj)
+        dres[:live].addmm_(dproj, wq)
+        gwq, gbq = dproj.t().mm(xl), _colsum(dproj)
         g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
         gwkv, gbkv = dkv.t().mm(e2), _colsum(dkv)
-        return (gx, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:]) + tail
+        return (dres, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:]) + tail
 
 
 class _FFNBlockFn(torch.autograd.Function):

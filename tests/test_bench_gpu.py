@@ -32,11 +32,18 @@ def test_default_line_carries_the_contract():
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
     r = out["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "ball_query" in r["kernel"] and "query_group" in r["kernel"]          # the pair the north star names
+    assert out["fps_timeouts"] == 0
+    # beside the headline: every level dense, and surface-shaped scenes (both slower or equal, both finite)
+    v = out["variants"]
+    assert len(v) == 2 and all(x["ms_per_step"] > 0 for x in v.values())
+    dense = [x for k, x in v.items() if k.startswith("dense")][0]
+    assert dense["compact_levels"] == {} and out["compact_levels"]              # headline compact, variant dense
 
 
 def test_data_parallel_path_over_real_rccl_group_of_one():
-    out = _run(["--force-reducer"], {"SIG3D_SINGLE_RANK_PG": "1", "MASTER_PORT": "29533"})
+    out = _run(["--force-reducer", "--no-variants"], {"SIG3D_SINGLE_RANK_PG": "1", "MASTER_PORT": "29533"})
     assert out["value"] > 0 and out["n_gpus"] == 1
-    ref = _run([], {})
+    ref = _run(["--no-variants"], {})
     # same seeds, same batches, mean over one rank == identity: the loss after 6 steps must agree
     assert abs(out["final_loss"] - ref["final_loss"]) <= 2e-3 * abs(ref["final_loss"])
