@@ -73,10 +73,13 @@ class GeometryPlan:
         return self.inds[i], self.new_xyz[i], self.ball_idx[i], self.compact[i]
 
     def copy_from(self, other):
-        for a, b in zip(self.inds + self.new_xyz + self.ball_idx,
-                        other.inds + other.new_xyz + other.ball_idx):
-            a.copy_(b, non_blocking=True)
+        """Hand-over at the end of a step: every tensor of `other` into this plan, ONE launch
+        (table_copy.TableCopy) instead of one copy kernel per tensor."""
+        pairs = list(zip(self.inds + self.new_xyz + self.ball_idx, other.inds + other.new_xyz + other.ball_idx))
         for mine, theirs in zip(self.compact, other.compact):
             if mine is not None:
-                for a, b in zip(mine.tensors(), theirs.tensors()):
-                    a.copy_(b, non_blocking=True)
+                pairs += list(zip(mine.tensors(), theirs.tensors()))
+        if getattr(self, "_table_copy", None) is None:
+            from .table_copy import TableCopy
+            self._table_copy = TableCopy(self.inds[0].device)
+        self._table_copy(pairs)

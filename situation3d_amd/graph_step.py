@@ -39,12 +39,35 @@ from .geometry import GeometryPlan
 from .trainer import get_loss
 
 
-def _copy_into(dst, src):
+def _pairs(dst, src, out):
     for k, v in src.items():
         if isinstance(v, dict):
-            _copy_into(dst[k], v)
+            _pairs(dst[k], v, out)
         else:
-            dst[k].copy_(v, non_blocking=True)
+            out.append((dst[k], v))
+    return out
+
+
+_table_copies = {}
+
+
+def _copy_into(dst, src, extra=()):
+    """Refresh the static input buffers of a captured step from the caller's batch (+ `extra` (dst, src)
+    pairs): one table-driven launch when every tensor is a contiguous device tensor of matching size
+    (table_copy.TableCopy), plain copies otherwise."""
+    pairs = _pairs(dst, src, []) + list(extra)
+    ok = all(d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype
+             and d.shape == s.shape and (d.numel() * d.element_size()) % 4 == 0 for d, s in pairs)
+    if ok and pairs:
+        dev = pairs[0][0].device
+        tc = _table_copies.get(dev)
+        if tc is None:
+            from .table_copy import TableCopy
+            tc = _table_copies[dev] = TableCopy(dev)
+        tc(pairs)
+        return
+    for d, s in pairs:
+        d.copy_(s, non_blocking=True)
 
 
 def _clone(d):
@@ -111,6 +134,7 @@ class GraphedTrainStep:
             self.plan_next = GeometryPlan(b, n, levels, pc.device)
             self.static_next_xyz = pc[..., :3].contiguous()
             self.side = torch.cuda.Stream(pc.device)
+            self.plan_cur.copy_from(self.plan_next)      # builds the hand-over's copy table OUTSIDE any capture
             self.plan_cur.compute(self.static_next_xyz)  # geometry of the example batch
 
         def fwd_bwd():

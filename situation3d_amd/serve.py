@@ -28,6 +28,7 @@ class GraphedForward:
         self.plan_next = GeometryPlan(b, n, levels, pc.device)
         self.static_next_xyz = pc[..., :3].contiguous()
         self.side = torch.cuda.Stream(pc.device)
+        self.plan_cur.copy_from(self.plan_next)          # builds the hand-over's copy table OUTSIDE any capture
         self.plan_cur.compute(self.static_next_xyz)
         self._announced = Announced()
 

@@ -38,7 +38,7 @@ struct Tile {  // k-contiguous global operand -> LDS [k][m], odd row stride
   }
 };
 
-template <int WM, int WN, int GK, int PF, int SCHED, int OCC>
+template <int WM, int WN, int GK, int PF, int SCHED, int OCC, int KNOCK = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksplit, const float *__restrict__ A,
                                                     const float *__restrict__ B, float *__restrict__ C, int ntm) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
   // prologue: chunk 0 -> LDS stage 0, chunks 1..PF-1 (PF = 2) in flight
   ta[0].load(A, K, m0, c_lo * GK, tid);
   tb[0].load(B, K, n0, c_lo * GK, tid);
-  if (PF == 2 && nchunks > 1) {
-    ta[1].load(A, K, m0, (c_lo + 1) * GK, tid);
-    tb[1].load(B, K, n0, (c_lo + 1) * GK, tid);
+  if (PF == 2) {
+    ta[1].load(A, K, m0, (c_lo + min(1, nchunks - 1)) * GK, tid);
+    tb[1].load(B, K, n0, (c_lo + min(1, nchunks - 1)) * GK, tid);
   }
   ta[0].store(s_a, tid);
   tb[0].store(s_b, tid);
@@ -86,18 +86,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
   auto body = [&](int c, auto par_) {
     constexpr int par = decltype(par_)::value;   // register buffer that holds chunk c + 1 (PF = 2) / receives it (PF = 1)
     const int st = c & 1;
-    if (PF == 1) {
-      if (c + 1 < nchunks) {
-        ta[0].load(A, K, m0, (c_lo + c + 1) * GK, tid);
-        tb[0].load(B, K, n0, (c_lo + c + 1) * GK, tid);
-      }
+    if (KNOCK & 2) {
+    } else if (PF == 1) {
+      // UNCONDITIONAL (clamped) loads: a load under `if` ends its basic block, hipcc's s_waitcnt pass then
+      // merges the pending-load state conservatively and drains vmcnt(0) at the next use
+      const int cn = min(c + 1, nchunks - 1);
+      ta[0].load(A, K, m0, (c_lo + cn) * GK, tid);
+      tb[0].load(B, K, n0, (c_lo + cn) * GK, tid);
     } else {
       // chunk c+2 into the buffer chunk c was in (already in LDS)
-      if (c + 2 < nchunks) {
-        ta[par ^ 1].load(A, K, m0, (c_lo + c + 2) * GK, tid);
-        tb[par ^ 1].load(B, K, n0, (c_lo + c + 2) * GK, tid);
-      }
+      const int cn = min(c + 2, nchunks - 1);
+      ta[par ^ 1].load(A, K, m0, (c_lo + cn) * GK, tid);
+      tb[par ^ 1].load(B, K, n0, (c_lo + cn) * GK, tid);
     }
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay HERE: the scheduler otherwise sinks them to the stores
     const float *sa = s_a + st * (GK * LDA) + wm * (32 * WM) + l31 + half * LDA;
     const float *sb = s_b + st * (GK * LDB) + wn * (32 * WN) + l31 + half * LDB;
     constexpr int GS = 4, NG = GK / 2 / GS;
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
 #pragma unroll
     for (int t = 0; t < GS; ++t) {
 #pragma unroll
-      for (int a = 0; a < WM; ++a) av[0][t][a] = sa[(2 * t) * LDA + 32 * a];
+      for (int a = 0; a < WM; ++a) av[0][t][a] = (KNOCK & 1) ? (float)(lane + t) : sa[(2 * t) * LDA + 32 * a];
 #pragma unroll
-      for (int b = 0; b < WN; ++b) bv[0][t][b] = sb[(2 * t) * LDB + 32 * b];
+      for (int b = 0; b < WN; ++b) bv[0][t][b] = (KNOCK & 1) ? (float)(lane - t) : sb[(2 * t) * LDB + 32 * b];
     }
     if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, GS * (WM + WN), 0);
 #pragma unroll
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
 #pragma unroll
         for (int t = 0; t < GS; ++t) {
 #pragma unroll
-          for (int a = 0; a < WM; ++a) av[(gq + 1) & 1][t][a] = sa[(2 * ((gq + 1) * GS + t)) * LDA + 32 * a];
+          for (int a = 0; a < WM; ++a) av[(gq + 1) & 1][t][a] = (KNOCK & 1) ? (float)(lane + t + gq) : sa[(2 * ((gq + 1) * GS + t)) * LDA + 32 * a];
 #pragma unroll
-          for (int b = 0; b < WN; ++b) bv[(gq + 1) & 1][t][b] = sb[(2 * ((gq + 1) * GS + t)) * LDB + 32 * b];
+          for (int b = 0; b < WN; ++b) bv[(gq + 1) & 1][t][b] = (KNOCK & 1) ? (float)(lane - t - gq) : sb[(2 * ((gq + 1) * GS + t)) * LDB + 32 * b];
         }
       }
 #pragma unroll
@@ -134,12 +136,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
         }
       }
     }
-    if (c + 1 < nchunks) {
+    if (!(KNOCK & 2)) {   // unconditional too (the last chunk's store is never read)
       const int src = (PF == 1) ? 0 : par;
       ta[src].store(s_a + (st ^ 1) * (GK * LDA), tid);
       tb[src].store(s_b + (st ^ 1) * (GK * LDB), tid);
     }
-    __syncthreads();
+    if (!(KNOCK & 4)) __syncthreads();
   };
   for (int c = 0; c < nchunks; c += 2) {
     body(c, std::integral_constant<int, 1>());
@@ -163,12 +165,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt(int M, int N, int K, int ksp
 
 struct Shape { const char *name; int m, n, k; };
 
-template <int WM, int WN, int GK, int PF, int SCHED, int OCC>
+template <int WM, int WN, int GK, int PF, int SCHED, int OCC, int KNOCK = 0>
 void run(const Shape &s, int ksplit, const float *A, std::vector<float *> &W, float *C, const std::vector<float> &ref) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   if (s.m % TM || s.n % TN || s.k % GK || (s.k / GK) < ksplit) return;
   const size_t lds = sizeof(float) * 2 * GK * (TM + 1 + TN + 1);
-  auto kern = gemm_nt<WM, WN, GK, PF, SCHED, OCC>;
+  auto kern = gemm_nt<WM, WN, GK, PF, SCHED, OCC, KNOCK>;
   CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int ntm = s.m / TM, ntn = s.n / TN;
   dim3 grid(ntm * ntn, 1, ksplit);
@@ -193,6 +195,7 @@ void run(const Shape &s, int ksplit, const float *A, std::vector<float *> &W, fl
   double err = 0;
   for (int i = 0; i < 256; ++i) err = fmax(err, fabs(out[i] - ref[i]));
   const double us = ms * 1e3 / reps;
+  if (KNOCK) printf("  [knock-out %d: %s%s%s]", KNOCK, KNOCK & 1 ? "no LDS operand reads " : "", KNOCK & 2 ? "no global loads / LDS stores " : "", KNOCK & 4 ? "no barrier" : "");
   printf("  %dx%d gk%-2d pf%d s%d occ%d ks%-2d (%4d WGs, %5.1f KB lds): %7.1f us %6.1f TF  err %.1e\n", TM, TN, GK, PF, SCHED,
          OCC, ksplit, grid.x * ksplit, lds / 1024.0, us, 2.0 * s.m * s.n * s.k / us / 1e6, err);
 }
@@ -223,6 +226,19 @@ int main(int argc, char **argv) {
     for (auto &w : W) { CHECK(hipMalloc(&w, sizeof(float) * hW.size())); CHECK(hipMemcpy(w, hW.data(), sizeof(float) * hW.size(), hipMemcpyHostToDevice)); }
     for (int ks : {1, 2, 3, 4, 6, 8}) {
       if (only_ks >= 0 && ks != only_ks) continue;
+      if (argc > 4) {   // knock-out experiments only
+        run<1, 1, 32, 1, 1, 1>(s, ks, A, W, C, ref);
+        run<1, 1, 32, 2, 1, 1>(s, ks, A, W, C, ref);
+        run<1, 1, 64, 2, 1, 1>(s, ks, A, W, C, ref);
+        run<1, 2, 32, 2, 1, 1>(s, ks, A, W, C, ref);
+        run<2, 1, 32, 2, 1, 1>(s, ks, A, W, C, ref);
+        run<1, 1, 32, 1, 1, 1, 1>(s, ks, A, W, C, ref);
+        run<1, 1, 32, 1, 1, 1, 2>(s, ks, A, W, C, ref);
+        run<1, 1, 32, 1, 1, 1, 3>(s, ks, A, W, C, ref);
+        run<1, 1, 32, 1, 1, 1, 7>(s, ks, A, W, C, ref);
+        run<1, 2, 32, 1, 1, 1, 7>(s, ks, A, W, C, ref);
+        continue;
+      }
       run<1, 1, 32, 1, 0, 1>(s, ks, A, W, C, ref);
       run<1, 1, 32, 1, 1, 1>(s, ks, A, W, C, ref);
       run<1, 1, 32, 2, 1, 1>(s, ks, A, W, C, ref);
