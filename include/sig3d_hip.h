@@ -280,7 +280,9 @@ int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x, const flo
  * use parameter set p (the query and text feed-forward tails of a layer in one launch); <= 0: one set.
  * live_rows in (0, rows): rows [live_rows, rows) are PADDING of the two-segment layout -- x, v (and dx in the
  * backward) hold live_rows rows only, out rows (dres rows in the backward) beyond are written as zeros, so
- * that the projections around the tail run on the live rows alone; <= 0: all rows are live. */
+ * that the projections around the tail run on the live rows alone; 0: all rows are live.
+ * live_rows < 0: -live_rows rows are live and the others PASS THROUGH: out row = res row (dres row = dy row in
+ * the backward) -- the text rows under a cross-attention block (Qformer.py:375-402) without split / cat. */
 int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
                              const unsigned *rng_counter, const float *x, const float *bias,
                              const float *res, const float *gamma, const float *beta, float eps,

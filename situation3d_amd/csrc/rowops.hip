@@ -68,16 +68,20 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ res,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     float *__restrict__ out, float *__restrict__ v_out, float *__restrict__ mean_out,
-    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows, int mcan, int live_rows) {
+    float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows, int mcan, int live_rows,
+    int pad_copy) {
   const int lane = lane_id();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   if (row >= live_rows) {
-    // padding rows of the two-segment layout (no token lives there): x / v hold live_rows rows only; the
-    // output row is kept finite (zeros) for the batched feed-forward GEMMs that sweep all rows
+    // rows beyond the live ones: x / v hold live_rows rows only.  pad_copy == 0: padding rows of the
+    // two-segment layout (no token lives there), kept finite (zeros) for the batched feed-forward GEMMs that
+    // sweep all rows.  pad_copy != 0: rows the block does not touch (the text rows under a cross-attention
+    // block, Qformer.py:375-402) pass through from the residual input -- no split / cat around the block.
 #pragma unroll
     for (int i = 0; i < PER_LANE; ++i)
-      if (lane + 64 * i < cols) out[(size_t)row * cols + lane + 64 * i] = 0.f;
+      if (lane + 64 * i < cols)
+        out[(size_t)row * cols + lane + 64 * i] = pad_copy ? res[(size_t)row * cols + lane + 64 * i] : 0.f;
     if (lane == 0) { mean_out[row] = 0.f; rstd_out[row] = 0.f; }
     return;
   }
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float *__restrict__ v, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const unsigned short *__restrict__ mask,
     float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial, int part_rows,
-    int mcan, float eps, int live_rows) {
+    int mcan, float eps, int live_rows, int pad_copy) {
   // partial: (gridDim.x, 3*cols) = per-workgroup [d gamma | d beta | d bias] column sums
   __shared__ float part[3][3][64 * PER_LANE];  // waves 1..3 park their sums here
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -159,10 +163,12 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
   for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int row = wave_global * rows_per_wave + rr;
     if (row >= rows) break;
-    if (row >= live_rows) {  // padding row: zero gradient to the residual, nothing to the GEMM output (v, dx end earlier)
+    if (row >= live_rows) {  // padding row: zero gradient to the residual (pass-through row: dy itself), nothing
+                             // to the GEMM output (v, dx end earlier)
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i)
-        if (lane + 64 * i < cols) dres[(size_t)row * cols + lane + 64 * i] = 0.f;
+        if (lane + 64 * i < cols)
+          dres[(size_t)row * cols + lane + 64 * i] = pad_copy ? dy[(size_t)row * cols + lane + 64 * i] : 0.f;
       continue;
     }
     const float mu = mean[row], rs = rstd[row];
@@ -273,7 +279,7 @@ extern "C" int sig3d_counter_increment(unsigned *counter, void *stream_) {
   return 0;
 }
 
-static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
+static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, int live_rows, int pad_copy, float p_drop, unsigned call_id,
                        const unsigned *rng_counter, const float *x, const float *bias, const float *res,
                        const float *gamma, const float *beta, float eps, float *out, float *v, float *mean,
                        float *rstd, unsigned short *mask, void *stream_) {
@@ -290,11 +296,11 @@ static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, int live_row
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<12>, grid, dim3(256), 0, stream, rows, cols, p_drop,
                        call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask,
-                       part_rows, mcan, live_rows);
+                       part_rows, mcan, live_rows, pad_copy);
   else
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<LN_MAX_PER_LANE>, grid, dim3(256), 0, stream, rows, cols,
                        p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd,
-                       mask, part_rows, mcan, live_rows);
+                       mask, part_rows, mcan, live_rows, pad_copy);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_fwd_kernel");
   return 0;
 }
@@ -305,7 +311,7 @@ extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, int l
                                         const float *beta, float eps, float *out, float *v,
                                         float *mean, float *rstd, unsigned short *mask,
                                         void *stream_) {
-  return ln_tail_fwd(0, rows, cols, part_rows, live_rows, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
+  return ln_tail_fwd(0, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
                      mean, rstd, mask, stream_);
 }
 
@@ -315,11 +321,11 @@ extern "C" int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows
                                                const float *beta, float eps, float *out, float *v,
                                                float *mean, float *rstd, unsigned short *mask,
                                                void *stream_) {
-  return ln_tail_fwd(1, rows, cols, part_rows, live_rows, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
+  return ln_tail_fwd(1, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
                      mean, rstd, mask, stream_);
 }
 
-static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, int live_rows, float p_drop, const float *dy,
+static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, int live_rows, int pad_copy, float p_drop, const float *dy,
                        const float *v, const float *mean, const float *rstd, const float *gamma,
                        const unsigned short *mask, float *dx, float *dres, float *dparams, float *workspace,
                        void *stream_) {
@@ -344,11 +350,11 @@ static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, i
   const int blocks = sig3d_ceil_div(sig3d_ceil_div(rows, rpw), 4);
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<12>, dim3(blocks), dim3(256), 0, stream, rows, cols, p_drop,
-                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan, eps, live_rows);
+                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan, eps, live_rows, pad_copy);
   else
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<LN_MAX_PER_LANE>, dim3(blocks), dim3(256), 0, stream, rows,
                        cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan,
-                       eps, live_rows);
+                       eps, live_rows, pad_copy);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
   // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols)
   hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(3 * cols, 64), parts), dim3(CS_WAVES * 64), 0,
@@ -362,7 +368,7 @@ extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, int l
                                         const float *gamma, const unsigned short *mask, float *dx,
                                         float *dres, float *dparams, float *workspace,
                                         void *stream_) {
-  return ln_tail_bwd(0, 0.f, rows, cols, part_rows, live_rows, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
+  return ln_tail_bwd(0, 0.f, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
                      workspace, stream_);
 }
 
@@ -371,7 +377,7 @@ extern "C" int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows
                                                const float *rstd, const float *gamma,
                                                const unsigned short *mask, float *dx, float *dres,
                                                float *dparams, float *workspace, void *stream_) {
-  return ln_tail_bwd(1, eps, rows, cols, part_rows, live_rows, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
+  return ln_tail_bwd(1, eps, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
                      workspace, stream_);
 }
 

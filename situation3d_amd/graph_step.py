@@ -74,6 +74,15 @@ def _clone(d):
     return {k: (_clone(v) if isinstance(v, dict) else v.clone()) for k, v in d.items()}
 
 
+def _flush_deferred(model):
+    """Deferred, layer-batched weight gradients of the Q-Former (qformer._WeightGradArena): fill whatever the
+    backward pass so far has made ready (a no-op when nothing is pending or the mode is off)."""
+    qf = getattr(model, "Qformer", None)
+    enc = getattr(getattr(qf, "bert", None), "encoder", None)
+    if enc is not None and hasattr(enc, "flush_weight_grads"):
+        enc.flush_weight_grads()
+
+
 class Announced:
     """Identity of the batch whose geometry the forked branch computed during the previous replay.
     A device address is NOT an identity (the caching allocator recycles addresses; a loader that refills one
@@ -145,6 +154,7 @@ class GraphedTrainStep:
             loss, out = get_loss(out)
             self.static_out = out  # answer_scores, aux_scores, ... of the last replay
             loss.backward()
+            _flush_deferred(model)
             if reducer is not None and fused_opt:
                 optimizer.gather_grads()  # scattered grads -> the flat buffers the reducer owns
             return loss
@@ -166,6 +176,7 @@ class GraphedTrainStep:
             self.static_out = out
             leaves = [self._boundary[1]] + ([self._qf_boundary[1]] if self._qf_boundary is not None else [])
             loss.backward(inputs=self._upper_params + leaves)
+            _flush_deferred(model)   # weight gradients of the layers above the cut (qformer._WeightGradArena)
             optimizer.gather_grads(slot=0, zero=True)
             return loss
 
@@ -174,6 +185,7 @@ class GraphedTrainStep:
             gradient of the visual tokens keeps accumulating in their boundary leaf."""
             hidden, leaf = self._qf_boundary
             hidden.backward(leaf.grad, inputs=self._lower_params + [self._boundary[1]])
+            _flush_deferred(model)
             optimizer.gather_grads(slot=1, zero=False)
             self._qf_boundary = None
 

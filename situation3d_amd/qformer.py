@@ -25,6 +25,7 @@ torch's Philox (same distribution, different bits); eval mode is deterministic.
 """
 import ctypes
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -114,22 +115,25 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
-def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, mcan=False):
+def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, mcan=False, out=None,
+                 pass_through=False):
     """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask.
     part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows.
     mcan: the MCAN blocks' normalisation (unbiased std, eps on the std) instead of nn.LayerNorm's.
     x2 may hold fewer rows than the residual r2: the rows beyond are padding of the two-segment layout, the
-    kernel writes zeros there (out has r2's row count, v has x2's)."""
+    kernel writes zeros there (out has r2's row count, v has x2's) -- or, with pass_through, the residual's rows
+    (rows the block leaves alone).  `out`: a preallocated (rows, cols) destination."""
     dev = x2.device
     live, cols = x2.shape
     rows = r2.shape[0]
-    out = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=dev)
     v = torch.empty_like(x2)
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
         _lib.call("sig3d_dropout_add_mcan_norm_fwd" if mcan else "sig3d_dropout_add_ln_fwd", rows, cols, part_rows,
-                  live, ctypes.c_float(p_drop),
+                  -live if (pass_through and live < rows) else live, ctypes.c_float(p_drop),
                   ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
                   _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), _lib.ptr(out),
                   _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask),
@@ -137,14 +141,16 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, m
     return out, v, stats, mask
 
 
-def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None):
+def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None, dx_out=None, pass_through=False):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
     dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0).
     v may hold fewer rows than dy2 (see _ln_tail_fwd): dx has v's rows, dres has dy2's with zeros beyond."""
     live, cols = v.shape
     rows = dy2.shape[0]
-    dx = torch.empty_like(v)
+    dx = torch.empty_like(v) if dx_out is None else dx_out
     dres = torch.empty((rows, cols), dtype=torch.float32, device=v.device)
+    if pass_through and live < rows:
+        live = -live
     shape = (rows // part_rows, 3, cols) if part_rows > 0 else (3, cols)
     dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
     work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
@@ -159,18 +165,20 @@ def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None)
     return dx, dres, dparams
 
 
-def _colsum(t2, parts=1):
+def _colsum(t2, parts=1, out=None):
     """Column sums of a contiguous (parts*rows, cols) matrix -> (cols,) or (parts, cols)."""
     rows, cols = t2.shape[0] // parts, t2.shape[1]
-    o = torch.empty((parts, cols) if parts > 1 else (cols,), dtype=torch.float32, device=t2.device)
+    o = out if out is not None else \
+        torch.empty((parts, cols) if parts > 1 else (cols,), dtype=torch.float32, device=t2.device)
     with torch.cuda.device(t2.device):
         _lib.call("sig3d_column_sum", parts, rows, cols, _lib.ptr(t2), _lib.ptr(o), _lib.stream_ptr(t2.device))
     return o
 
 
-def _bias_gelu(x2, bias, part_rows, gy=None):
+def _bias_gelu(x2, bias, part_rows, gy=None, out=None):
     """gelu(x + bias) (gy None) or gy * gelu'(x + bias); bias (parts, cols) per block of part_rows rows."""
-    out = torch.empty_like(x2)
+    if out is None:
+        out = torch.empty_like(x2)
     with torch.cuda.device(x2.device):
         _lib.call("sig3d_bias_gelu", x2.shape[0], x2.shape[1], part_rows, _lib.ptr(x2), _lib.ptr(bias),
                   _lib.ptr(gy), _lib.ptr(out), _lib.stream_ptr(x2.device))
@@ -405,6 +413,129 @@ class _ProjAttentionFn(torch.autograd.Function):
                 None, None)
 
 
+class _WeightGradArena:
+    """Per-forward storage that lets the weight-gradient products of ALL Q-Former layers run as a handful of
+    strided-batched GEMMs at the end of the backward pass instead of ~90 small ones inside it.
+
+    A weight gradient (dW = dY^T X, db = column sums of dY) is off the dependency chain of the backward pass:
+    nothing needs it before the optimizer.  At the Q-Former's row counts (416 live rows) every GEMM launch pays
+    ~6-8 us of ramp and drain around ~10-20 us of work, so the twelve layers' products of one kind as ONE
+    batched launch run at 110-116 TFLOP/s instead of 37-84 (tools/batched_dw_probe.py: -0.37 ms per step),
+    and the 58 bias-gradient column sums shrink to six launches.  Mechanics:
+      * the block functions write the operands of those products -- layer inputs, attention outputs, GELU
+        activations in the forward pass; dY of every dense layer in the backward pass -- into slices of the
+        buffers below (same bytes as before, only their addresses are planned);
+      * their backward returns, as the gradients of the weights, VIEWS of the result buffers, which autograd
+        adopts as `.grad` (parameters must have no gradient yet: checked when the arena is built);
+      * `flush()` fills the result buffers: automatically when the last block of the stack has run its
+        backward, or explicitly between the pieces of a split backward pass (graph_step.GraphedTrainStep).
+    The key / value projections of all cross-attention layers read the same scene tokens (Qformer.py:116-118,
+    164-170), so they are ONE GEMM in the forward pass (tokens x [Wk0;Wv0;Wk2;Wv2;...]^T) and their weight /
+    input gradients two GEMMs in flush() / the lowest cross-attention block instead of twelve."""
+
+    def __init__(self, layers, batch, tq, tt, part_rows, enc2, num_heads, return_enc_at):
+        first = layers[0].attention
+        wq = first.self.query.weight
+        dev, H, I = wq.device, wq.shape[0], layers[0].intermediate_query.dense.weight.shape[0]
+        NL = len(layers)
+        P, rows, L, rq = part_rows, 2 * part_rows, part_rows + batch * tt, batch * tq
+        self.nl, self.P, self.rows, self.L, self.rq, self.H, self.I = NL, P, rows, L, rq, H, I
+        self.cross = [i for i, l in enumerate(layers) if l.has_cross_attention]
+        self.cross_ord = {l: j for j, l in enumerate(self.cross)}
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)   # noqa: E731
+        # operands written by the forward pass
+        self.x_attn, self.att, self.x_ffn, self.act = e(NL, rows, H), e(NL, L, H), e(NL, rows, H), e(NL, rows, I)
+        # operands written by the backward pass
+        self.dyo_attn, self.dproj, self.dyo_ffn, self.gpre = e(NL, L, H), e(NL, L, 3 * H), e(NL, rows, H), e(NL, rows, I)
+        # results
+        self.gwqkv, self.gbqkv, self.gwo = e(NL, 3 * H, H), e(NL, 3 * H), e(NL, H, H)
+        self.gw1, self.gb1, self.gw2 = e(NL, 2, I, H), e(NL, 2, I), e(NL, 2, H, I)
+        nc = len(self.cross)
+        self.enc2 = enc2
+        if nc:
+            nrow_e, cenc = enc2.shape
+            self.sa_out, self.att_x = e(nc, rows, H), e(nc, rq, H)
+            self.dyo_x, self.dq_x = e(nc, rq, H), e(nc, rq, H)
+            self.kv, self.dkv = e(nrow_e, nc * 2 * H), e(nrow_e, nc * 2 * H)
+            self.gwq_x, self.gbq_x, self.gwo_x = e(nc, H, H), e(nc, H), e(nc, H, H)
+            self.gwkv, self.gbkv = e(nc * 2 * H, cenc), e(nc * 2 * H)
+            with torch.no_grad():   # [Wk;Wv] of every cross layer stacked: one projection GEMM for all of them
+                ws, bs = [], []
+                for i in self.cross:
+                    sa = layers[i].crossattention.self
+                    ws += [sa.key.weight, sa.value.weight]
+                    bs += [sa.key.bias, sa.value.bias]
+                self.wkv_all = _stacked(ws)
+                torch.addmm(_stacked(bs), enc2, self.wkv_all.t(), out=self.kv)
+        # cross layers whose backward returns the gradient of the scene tokens, accumulated over the cross layers
+        # above them (the lowest one; with a split backward pass also the lowest one of the upper piece)
+        self.return_enc_at = sorted(set(return_enc_at) & set(self.cross), reverse=True) if nc else []
+        self._enc_done_hi = nc          # cross ordinals >= this have had their dkv folded into a returned g_enc
+        self._marks = set()
+        self._expected = 2 * NL + nc
+        self._flushed_hi = NL           # layers >= this are flushed
+
+    # ---- bookkeeping -----------------------------------------------------------------------------------
+    def mark(self, kind, layer):
+        key = (kind, layer)
+        if key in self._marks:
+            raise RuntimeError("deferred weight gradients: a Q-Former block ran its backward twice "
+                               "(retain_graph is not supported; set encoder.defer_weight_grads = False)")
+        self._marks.add(key)
+        if len(self._marks) == self._expected:
+            self.flush()
+
+    def _layer_done(self, l):
+        return ("attn", l) in self._marks and ("ffn", l) in self._marks and \
+            (l not in self.cross_ord or ("cross", l) in self._marks)
+
+    def g_enc(self, layer):
+        """Gradient of the scene tokens over the cross layers [layer's ordinal, those already returned)."""
+        j0, j1 = self.cross_ord[layer], self._enc_done_hi
+        self._enc_done_hi = j0
+        H2 = 2 * self.H
+        return self.dkv[:, j0 * H2:j1 * H2].mm(self.wkv_all[j0 * H2:j1 * H2])
+
+    # ---- the deferred products -------------------------------------------------------------------------
+    @torch.no_grad()
+    def flush(self):
+        """Weight / bias gradients of every layer whose blocks have all run their backward and that is not
+        flushed yet (a contiguous range below the last flush), batched over that range."""
+        hi = self._flushed_hi
+        lo = hi
+        while lo > 0 and self._layer_done(lo - 1):
+            lo -= 1
+        n = hi - lo
+        if n <= 0:
+            return
+        self._flushed_hi = lo
+        P, H, I, L, rq = self.P, self.H, self.I, self.L, self.rq
+        # feed-forward pair: (query branch, text branch) x n layers
+        torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
+                  out=self.gw2[lo:hi].view(2 * n, H, I))
+        torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
+                  out=self.gw1[lo:hi].view(2 * n, I, H))
+        _colsum(self.gpre[lo:hi].view(2 * n * P, I), parts=2 * n, out=self.gb1[lo:hi])
+        # self-attention
+        torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
+        torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
+        _colsum(self.dproj[lo:hi].view(n * L, 3 * H), parts=n, out=self.gbqkv[lo:hi])
+        # cross-attention layers inside the range
+        js = [j for j, l in enumerate(self.cross) if lo <= l < hi]
+        if js:
+            j0, j1 = js[0], js[-1] + 1
+            m = j1 - j0
+            torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
+            torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
+            _colsum(self.dq_x[j0:j1].view(m * rq, H), parts=m, out=self.gbq_x[j0:j1])
+            cols = slice(j0 * 2 * H, j1 * 2 * H)
+            torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
+            if m == len(self.cross):
+                _colsum(self.dkv, out=self.gbkv)
+            else:
+                torch.sum(self.dkv[:, cols], dim=0, out=self.gbkv[cols])
+
+
 class _AttentionBlockFn(torch.autograd.Function):
     """BertAttention as ONE autograd node on 2-D row matrices (Qformer.py:249-299):
         LayerNorm(dropout(dense(attention(x, kv))) + x)
@@ -419,21 +550,33 @@ class _AttentionBlockFn(torch.autograd.Function):
     Everything between the input and the LayerNorm tail runs on the LIVE rows only -- rows [0, L),
     L = base2 + B*(N - seg): the padding behind the shorter segment (96 of 512 rows at B = 8 with 32
     queries + 20 question tokens) costs no GEMM work; the tail kernels write the zeros the padded output
-    rows must hold (sig3d_dropout_add_ln_fwd / _bwd, live_rows)."""
+    rows must hold (sig3d_dropout_add_ln_fwd / _bwd, live_rows).
+    pass_rows: cross-attention on the leading B*N rows of a LONGER matrix (the text rows behind them
+    pass through the block untouched: Qformer.py:375-402 without split / cat).
+    arena (a _WeightGradArena) + layer index: operands of the weight-gradient products go to the arena and
+    the products themselves are deferred to arena.flush()."""
 
     @staticmethod
     def forward(ctx, x, kv_src, wq, bq, wk, bk, wv, bv, wo, bo, gamma, beta, mask, num_heads, p_attn,
-                p_hidden, eps, id_attn, id_out, layout):
+                p_hidden, eps, id_attn, id_out, layout, arena=None, li=-1):
         x = x.contiguous()
         dev = x.device
         b, nq, seg, base2, rows = layout
-        assert x.shape[0] == rows
+        total = x.shape[0]
+        assert total >= rows
         live = min(rows, base2 + b * (nq - seg)) if nq > seg else min(rows, b * seg)
+        cross = kv_src is not None
+        j = arena.cross_ord[li] if (arena is not None and cross) else -1
+        if arena is not None:   # flush() reads this block's input from the arena: a producer that did not write in place
+            home = arena.sa_out[j] if cross else arena.x_attn[li]
+            if x.data_ptr() != home.data_ptr():
+                home.copy_(x)
+                x = home
         xl = x[:live]
         hd = wq.shape[0]
         d = hd // num_heads
         scale = 1.0 / math.sqrt(d)
-        if kv_src is None:  # self-attention
+        if not cross:  # self-attention
             w_all = _stacked((wq, wk, wv))
             proj = torch.addmm(_stacked((bq, bk, bv)), xl, w_all.t())     # (L, 3*hd)
             qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
@@ -442,12 +585,21 @@ class _AttentionBlockFn(torch.autograd.Function):
         else:
             nk = kv_src.shape[1]
             klay = (nk, 0, 0)
-            e2 = kv_src.reshape(b * nk, kv_src.shape[2])
-            w_all = _stacked((wk, wv))
             proj = torch.addmm(bq, xl, wq.t())                            # (L, hd)
-            kvproj = torch.addmm(_stacked((bk, bv)), e2, w_all.t())       # (B*Nk, 2*hd)
-            qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
-        att = torch.empty((live, hd), dtype=torch.float32, device=dev)
+            if arena is None:
+                e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+                w_all = _stacked((wk, wv))
+                kvproj = torch.addmm(_stacked((bk, bv)), e2, w_all.t())   # (B*Nk, 2*hd)
+                kp, vp, ldk, ldv = _off(kvproj, 0), _off(kvproj, hd), 2 * hd, 2 * hd
+            else:   # projected for all cross layers at once when the arena was built
+                w_all, kvproj = None, None
+                ldk = ldv = arena.kv.shape[1]
+                kp, vp = _off(arena.kv, j * 2 * hd), _off(arena.kv, j * 2 * hd + hd)
+            qp, ldq = _off(proj, 0), hd
+        if arena is None:
+            att = torch.empty((live, hd), dtype=torch.float32, device=dev)
+        else:
+            att = arena.att_x[j] if cross else arena.att[li]
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
         if mask is not None:
             mask = mask.contiguous()
@@ -458,49 +610,85 @@ class _AttentionBlockFn(torch.autograd.Function):
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
                       _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         y = att.mm(wo.t())
-        out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out)
+        out_buf = None
+        if arena is not None:   # the block's output is the next block's input: written where flush() will read it
+            out_buf = arena.x_ffn[li] if (cross or li not in arena.cross_ord) else arena.sa_out[arena.cross_ord[li]]
+        out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out, out=out_buf,
+                                           pass_through=total > rows)
         ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)
-        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay)
+        ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay, total > rows)
+        ctx.arena, ctx.li = arena, li
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep = ctx.saved_tensors
-        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay = ctx.cfg
+        num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay, passing = ctx.cfg
+        arena, li = ctx.arena, ctx.li
         dev = x.device
         d = hd // num_heads
         xl = x[:live]
-        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden)
-        gwo = dyo.t().mm(att)
-        datt = dyo.mm(wo)
         self_attn = kv_src is None
-        dproj = torch.empty_like(proj)
+        j = arena.cross_ord[li] if (arena is not None and not self_attn) else -1
+        dyo_buf = None
+        if arena is not None:
+            dyo_buf = arena.dyo_attn[li] if self_attn else arena.dyo_x[j]
+        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden, dx_out=dyo_buf,
+                                          pass_through=passing)
+        datt = dyo.mm(wo)
+        if arena is None:
+            dproj = torch.empty_like(proj)
+        else:
+            dproj = arena.dproj[li] if self_attn else arena.dq_x[j]
         if self_attn:
             qp, kp, vp = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd)
             dqp, dkp, dvp = _off(dproj, 0), _off(dproj, hd), _off(dproj, 2 * hd)
             ldq = ldk = ldv = 3 * hd
-        else:
+        elif arena is None:
             dkv = torch.empty_like(kvproj)
             qp, kp, vp = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd)
             dqp, dkp, dvp = _off(dproj, 0), _off(dkv, 0), _off(dkv, hd)
             ldq, ldk, ldv = hd, 2 * hd, 2 * hd
+        else:
+            ldq, ldk = hd, arena.kv.shape[1]
+            ldv = ldk
+            qp, kp, vp = _off(proj, 0), _off(arena.kv, j * 2 * hd), _off(arena.kv, j * 2 * hd + hd)
+            dqp, dkp, dvp = _off(dproj, 0), _off(arena.dkv, j * 2 * hd), _off(arena.dkv, j * 2 * hd + hd)
         with torch.cuda.device(dev):
             _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], live, klay[2],
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
-        tail = (gwo, dparams[2], dparams[0], dparams[1]) + (None,) * 8
+        nones = (None,) * 10
         if self_attn:
             dres[:live].addmm_(dproj, w_all)           # residual + projection paths in one epilogue
-            gw = dproj.t().mm(xl)                      # (3*hd, c)
-            gb = _colsum(dproj)
-            return (dres, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:]) + tail
-        e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+            if arena is None:
+                gwo = dyo.t().mm(att)
+                gw = dproj.t().mm(xl)                  # (3*hd, c)
+                gb = _colsum(dproj)
+            else:
+                gwo, gw, gb = arena.gwo[li], arena.gwqkv[li], arena.gbqkv[li]
+                arena.mark("attn", li)
+            return (dres, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:],
+                    gwo, dparams[2], dparams[0], dparams[1]) + nones
         dres[:live].addmm_(dproj, wq)
-        gwq, gbq = dproj.t().mm(xl), _colsum(dproj)
-        g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
-        gwkv, gbkv = dkv.t().mm(e2), _colsum(dkv)
-        return (dres, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:]) + tail
+        if arena is None:
+            e2 = kv_src.reshape(b * nk, kv_src.shape[2])
+            gwo = dyo.t().mm(att)
+            gwq, gbq = dproj.t().mm(xl), _colsum(dproj)
+            g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
+            gwkv, gbkv = dkv.t().mm(e2), _colsum(dkv)
+            gwk, gbk, gwv, gbv = gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:]
+        else:
+            gwo, gwq, gbq = arena.gwo_x[j], arena.gwq_x[j], arena.gbq_x[j]
+            r0 = j * 2 * hd
+            gwk, gwv = arena.gwkv[r0:r0 + hd], arena.gwkv[r0 + hd:r0 + 2 * hd]
+            gbk, gbv = arena.gbkv[r0:r0 + hd], arena.gbkv[r0 + hd:r0 + 2 * hd]
+            g_enc = None
+            if ctx.needs_input_grad[1] and li in arena.return_enc_at:
+                g_enc = arena.g_enc(li).view(kv_src.shape)
+            arena.mark("cross", li)
+        return (dres, g_enc, gwq, gbq, gwk, gbk, gwv, gbv, gwo, dparams[2], dparams[0], dparams[1]) + nones
 
 
 class _FFNBlockFn(torch.autograd.Function):
@@ -544,39 +732,53 @@ class _FFNPairBlockFn(torch.autograd.Function):
     shapes, so every GEMM is one strided-batched GEMM over the (2, ...) parameter pairs, bias + GELU,
     the LayerNorm tail and the bias-gradient column sums take a `part_rows` argument.
     Rows without a token (padding of the shorter part) only ever see finite values and zero
-    gradients, so they add exact zeros to the weight gradients."""
+    gradients, so they add exact zeros to the weight gradients.
+    arena + layer index: see _WeightGradArena (weight-gradient products deferred and batched over layers)."""
 
     @staticmethod
-    def forward(ctx, x, w1q, b1q, w1t, b1t, w2q, b2q, w2t, b2t, gq, bq, gt, bt, p_drop, eps, call_id):
+    def forward(ctx, x, w1q, b1q, w1t, b1t, w2q, b2q, w2t, b2t, gq, bq, gt, bt, p_drop, eps, call_id,
+                arena=None, li=-1):
         x = x.contiguous()
         P = x.shape[0] // 2
+        if arena is not None and x.data_ptr() != arena.x_ffn[li].data_ptr():
+            arena.x_ffn[li].copy_(x)    # a producer that did not write in place
+            x = arena.x_ffn[li]
         w1, b1, w2, b2 = _pair(w1q, w1t), _pair(b1q, b1t), _pair(w2q, w2t), _pair(b2q, b2t)
         gamma, beta = _pair(gq, gt), _pair(bq, bt)
         x3 = x.view(2, P, -1)
         pre = torch.bmm(x3, w1.transpose(1, 2))                       # (2, P, I), bias added below
-        act = _bias_gelu(pre.view(2 * P, -1), b1, P)                  # (2P, I)
+        act = _bias_gelu(pre.view(2 * P, -1), b1, P, out=None if arena is None else arena.act[li])   # (2P, I)
         y = torch.bmm(act.view(2, P, -1), w2.transpose(1, 2))         # (2, P, C)
-        out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P)
+        out_buf = arena.x_attn[li + 1] if (arena is not None and li + 1 < arena.nl) else None
+        out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P, out=out_buf)
         ctx.save_for_backward(x, w1, b1, w2, pre, act, v, stats, gamma, keep)
         ctx.p_drop = p_drop
+        ctx.arena, ctx.li = arena, li
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, w1, b1, w2, pre, act, v, stats, gamma, keep = ctx.saved_tensors
+        arena, li = ctx.arena, ctx.li
         P = x.shape[0] // 2
-        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop, P)
+        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop, P,
+                                          dx_out=None if arena is None else arena.dyo_ffn[li])
         dyo3 = dyo.view(2, P, -1)
-        gw2 = torch.bmm(dyo3.transpose(1, 2), act.view(2, P, -1))      # (2, C, I)
         gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
-        gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1))
-        gb1 = _colsum(gpre, parts=2)                                   # (2, I)
+        gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
+                          out=None if arena is None else arena.gpre[li])
         gpre3 = gpre.view(2, P, -1)
-        gw1 = torch.bmm(gpre3.transpose(1, 2), x.view(2, P, -1))       # (2, I, C)
         gx = dres.view(2, P, -1).baddbmm_(gpre3, w1).view(2 * P, -1)   # residual + dense1 input grads
+        if arena is None:
+            gw2 = torch.bmm(dyo3.transpose(1, 2), act.view(2, P, -1))  # (2, C, I)
+            gb1 = _colsum(gpre, parts=2)                               # (2, I)
+            gw1 = torch.bmm(gpre3.transpose(1, 2), x.view(2, P, -1))   # (2, I, C)
+        else:
+            gw2, gb1, gw1 = arena.gw2[li], arena.gb1[li], arena.gw1[li]
+            arena.mark("ffn", li)
         # dparams (2, 3, C): [d gamma | d beta | d bias2] per part
         return (gx, gw1[0], gb1[0], gw1[1], gb1[1], gw2[0], dparams[0, 2], gw2[1], dparams[1, 2],
-                dparams[0, 0], dparams[0, 1], dparams[1, 0], dparams[1, 1], None, None, None)
+                dparams[0, 0], dparams[0, 1], dparams[1, 0], dparams[1, 1], None, None, None, None, None)
 
 
 def fused_attention(q, k, v, additive_mask, num_heads, p_drop=0.0, call_id=0):
@@ -738,9 +940,10 @@ class BertAttention(nn.Module):
         return (self.output(self_outputs[0], hidden_states),) + self_outputs[1:]
 
     def forward_rows(self, rows, attention_mask, layout, encoder_hidden_states=None,
-                     encoder_attention_mask=None):
-        """rows (R, C) in the token order `layout` = (B, N, seg, base2, R) of _AttentionBlockFn ->
-        same shape and order."""
+                     encoder_attention_mask=None, arena=None, li=-1):
+        """rows (R, C) in the token order `layout` = (B, N, seg, base2, R') of _AttentionBlockFn ->
+        same shape and order.  R > R' (cross-attention on the leading rows of the two-segment matrix): the
+        rows beyond R' pass through.  arena / li: deferred weight gradients (_WeightGradArena)."""
         att, outp = self.self, self.output
         batch, n_tokens = layout[0], layout[1]
         if encoder_hidden_states is not None:
@@ -753,7 +956,7 @@ class BertAttention(nn.Module):
             rows, encoder_hidden_states, att.query.weight, att.query.bias, att.key.weight, att.key.bias,
             att.value.weight, att.value.bias, outp.dense.weight, outp.dense.bias, outp.LayerNorm.weight,
             outp.LayerNorm.bias, mask, att.num_attention_heads, float(p_attn), float(p_hidden),
-            float(outp.LayerNorm.eps), att._call_id, outp._call_id, layout)
+            float(outp.LayerNorm.eps), att._call_id, outp._call_id, layout, arena, li)
 
 
 class BertIntermediate(nn.Module):
@@ -835,33 +1038,33 @@ class BertLayer(nn.Module):
         return (layer_output, present_key_value)
 
     def forward_segmented(self, rows, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                          batch, query_length, text_length, part_rows):
+                          batch, query_length, text_length, part_rows, arena=None, li=-1):
         """Same computation as forward() on the padded two-segment row matrix (2P, C), P = part_rows:
             rows [0, B*Tq)      query tokens        rows [B*Tq, P)       padding
             rows [P, P + B*Tt)  text tokens         rows [P + B*Tt, 2P)  padding
         The query / text split (Qformer.py:375,396) and the final cat (:402) disappear: self-attention
-        maps tokens to rows inside the kernel, cross-attention works on the leading B*Tq rows, and the
-        two feed-forward branches -- same shapes, different weights -- run as ONE strided-batched GEMM
-        chain over the two P-row halves (_FFNPairBlockFn).  The (B, N, C) layout pays a strided copy
-        per slice, per residual and per gradient, and twice the GEMM launches."""
+        maps tokens to rows inside the kernel, cross-attention works on the leading B*Tq rows and lets the
+        others pass through its LayerNorm tail, and the two feed-forward branches -- same shapes, different
+        weights -- run as ONE strided-batched GEMM chain over the two P-row halves (_FFNPairBlockFn).  The
+        (B, N, C) layout pays a strided copy per slice, per residual and per gradient, and twice the GEMM
+        launches.  arena / li: deferred, layer-batched weight gradients (_WeightGradArena)."""
         rq = batch * query_length
         attention_output = self.attention.forward_rows(
-            rows, attention_mask, (batch, query_length + text_length, query_length, part_rows, 2 * part_rows))
+            rows, attention_mask, (batch, query_length + text_length, query_length, part_rows, 2 * part_rows),
+            arena=arena, li=li)
         if self.has_cross_attention:
             assert encoder_hidden_states is not None, \
                 "encoder_hidden_states must be given for cross-attention layers"
-            query_rows, rest = torch.split(attention_output, [rq, 2 * part_rows - rq], dim=0)
-            query_rows = self.crossattention.forward_rows(
-                query_rows, None, (batch, query_length, query_length, 0, rq), encoder_hidden_states,
-                encoder_attention_mask)
-            attention_output = torch.cat([query_rows, rest], dim=0)
+            attention_output = self.crossattention.forward_rows(
+                attention_output, None, (batch, query_length, query_length, 0, rq), encoder_hidden_states,
+                encoder_attention_mask, arena=arena, li=li)
         iq, oq, it, ot = self.intermediate_query, self.output_query, self.intermediate, self.output
         p = oq.dropout.p if oq.training else 0.0
         return _FFNPairBlockFn.apply(
             attention_output, iq.dense.weight, iq.dense.bias, it.dense.weight, it.dense.bias,
             oq.dense.weight, oq.dense.bias, ot.dense.weight, ot.dense.bias, oq.LayerNorm.weight,
             oq.LayerNorm.bias, ot.LayerNorm.weight, ot.LayerNorm.bias, float(p), float(oq.LayerNorm.eps),
-            oq._call_id)
+            oq._call_id, arena, li)
 
     def feed_forward_chunk(self, attention_output):
         return self.output(self.intermediate(attention_output), attention_output)
@@ -905,6 +1108,40 @@ class BertEncoder(nn.Module):
         self.layer = nn.ModuleList([BertLayer(config, i) for i in range(config.num_hidden_layers)])
         self.cut_after = None   # set for ONE forward: detach after this many layers, (output, leaf) left in .cut
         self.cut = None
+        # weight-gradient products of all layers deferred to the end of the backward pass and batched over the
+        # layers (_WeightGradArena).  Needs: gradients enabled, every parameter trainable and WITHOUT a gradient
+        # at forward time (autograd must adopt, not accumulate into, the views it is handed), no per-parameter
+        # gradient hooks that would fire before flush().  trainer.train_step / graph_step switch it per mode.
+        self.defer_weight_grads = os.environ.get("SIG3D_QF_DEFER", "1") != "0"
+        self._arena = None
+
+    def _make_arena(self, hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut):
+        if not (self.defer_weight_grads and torch.is_grad_enabled() and hidden_states.is_cuda):
+            return None
+        if encoder_hidden_states is not None and encoder_hidden_states.dim() != 3:
+            return None
+        for p in self.parameters():
+            if not p.requires_grad or p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None):
+                return None
+        for layer in self.layer:   # stripped text branch (Blip2T5) or no scene tokens for a cross layer
+            if layer.intermediate is None or (layer.has_cross_attention and encoder_hidden_states is None):
+                return None
+        cross = [i for i, l in enumerate(self.layer) if l.has_cross_attention]
+        ret = [cross[0]] if cross else []
+        if cut is not None and cross:
+            upper = [i for i in cross if i >= cut]
+            ret += upper[:1]
+        enc2 = None
+        if encoder_hidden_states is not None:
+            enc2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[2])
+        return _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
+                                self.layer[0].attention.self.num_attention_heads, ret)
+
+    def flush_weight_grads(self):
+        """Fill the deferred weight gradients of every layer whose backward has run (see _WeightGradArena;
+        automatic at the end of a whole backward pass, explicit between the pieces of a split one)."""
+        if self._arena is not None:
+            self._arena.flush()
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
@@ -914,10 +1151,12 @@ class BertEncoder(nn.Module):
             # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
             batch, tq, tt, part_rows = segments
             cut, self.cut_after, self.cut = self.cut_after, None, None
+            arena = self._make_arena(hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut)
+            self._arena = arena
             for i, layer_module in enumerate(self.layer):
                 hidden_states = layer_module.forward_segmented(
                     hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
-                    batch, tq, tt, part_rows)
+                    batch, tq, tt, part_rows, arena=arena, li=i)
                 if cut is not None and i + 1 == cut:
                     # data-parallel step (graph_step.py): the backward pass is cut here so that the gradient
                     # all-reduce of the layers above overlaps the backward of the layers below

@@ -106,6 +106,9 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     data_dict = model(data_dict)
     loss, data_dict = get_loss(data_dict)
     loss.backward()
+    enc = getattr(getattr(getattr(model, "Qformer", None), "bert", None), "encoder", None)
+    if enc is not None and hasattr(enc, "flush_weight_grads"):
+        enc.flush_weight_grads()   # deferred, layer-batched weight gradients (qformer._WeightGradArena)
     if reducer is not None:
         if fused:
             optimizer.gather_grads()  # scattered grads -> flat buffers (reducer.from_flat slices)

@@ -467,3 +467,52 @@ def test_cooperative_fps_reports_no_timeouts():
     idx = ext.furthest_point_sampling(scene(8, 40000, seed=3).to(DEV), 256)
     torch.cuda.synchronize()
     assert int(idx.min()) >= 0 and _lib.fps_timeouts() == 0
+
+
+@pytest.mark.parametrize("b,tq,tt,cut", [(8, 32, 20, None), (3, 5, 9, None), (2, 8, 3, 2)])
+def test_deferred_layer_batched_weight_gradients_equal_immediate_ones(b, tq, tt, cut):
+    """qformer._WeightGradArena: the weight / bias gradients of all layers computed as a few strided-batched
+    GEMMs at the end of backward (one fused K/V projection for all cross layers, pass-through text rows under
+    cross-attention) against the per-layer products inside backward: same outputs, same gradients for every
+    parameter and input, with and without a split backward pass."""
+    from situation3d_amd.qformer import QFormer, QFormerConfig
+    torch.manual_seed(b * 10 + tq)
+    cfg = QFormerConfig(vocab_size=200, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=64, encoder_width=96,
+                        cross_attention_freq=2, query_length=tq, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    model = QFormer(cfg).to(DEV).train()
+    ids = torch.randint(1, 200, (b, tt), device=DEV)
+    att = torch.ones(b, tq + tt, dtype=torch.long, device=DEV)
+    att[0, -1] = 0
+    enc = torch.randn(b, 13, 96, device=DEV)
+    G = torch.randn(b, tq, 128, device=DEV)
+    results = []
+    for defer in (False, True):
+        model.bert.encoder.defer_weight_grads = defer
+        model.zero_grad(set_to_none=True)
+        q = (torch.randn(b, tq, 128, generator=torch.Generator().manual_seed(1)) * 0.1).to(DEV).requires_grad_(True)
+        e = enc.clone().requires_grad_(True)
+        model.bert.encoder.cut_after = cut
+        out = model.bert(input_ids=ids, attention_mask=att, query_embeds=q, encoder_hidden_states=e, return_dict=True)
+        assert (model.bert.encoder._arena is not None) == defer
+        hidden = out.query_hidden_state
+        if cut is None:
+            (hidden * G).sum().backward()
+        else:   # split backward pass: layers above the cut first (flush), then the ones below
+            top, leaf = model.bert.encoder.cut
+            (hidden * G).sum().backward(inputs=[leaf] + [p for l in model.bert.encoder.layer[cut:] for p in l.parameters()] + [e])
+            model.bert.encoder.flush_weight_grads()
+            lower = [p for l in model.bert.encoder.layer[:cut] for p in l.parameters()] + list(model.bert.embeddings.parameters())
+            top.backward(leaf.grad, inputs=lower + [q, e])
+        model.bert.encoder.flush_weight_grads()
+        results.append((hidden.detach().clone(), q.grad.clone(), e.grad.clone(),
+                        {n: p.grad.clone() for n, p in model.bert.named_parameters() if p.grad is not None}))
+    (o0, q0, e0, g0), (o1, q1, e1, g1) = results
+    torch.testing.assert_close(o1, o0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(q1, q0, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(e1, e0, rtol=1e-4, atol=1e-5)
+    assert g0.keys() == g1.keys() and len(g0) > 60
+    for n in g0:
+        scale = max(1.0, g0[n].abs().max().item())
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-4, atol=1e-5 * scale, msg=lambda m: n + ": " + m)
