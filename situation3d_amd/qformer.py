@@ -474,6 +474,7 @@ class _WeightGradArena:
         self._marks = set()
         self._expected = 2 * NL + nc
         self._flushed_hi = NL           # layers >= this are flushed
+        self.side_stream, self._forked = None, False
 
     # ---- bookkeeping -----------------------------------------------------------------------------------
     def mark(self, kind, layer):
@@ -497,18 +498,38 @@ class _WeightGradArena:
         return self.dkv[:, j0 * H2:j1 * H2].mm(self.wkv_all[j0 * H2:j1 * H2])
 
     # ---- the deferred products -------------------------------------------------------------------------
-    @torch.no_grad()
     def flush(self):
         """Weight / bias gradients of every layer whose blocks have all run their backward and that is not
-        flushed yet (a contiguous range below the last flush), batched over that range."""
+        flushed yet (a contiguous range below the last flush), batched over that range.
+        The products are MFMA-bound and nothing before the optimizer needs them, while what the backward pass
+        still has to do after the Q-Former -- the point encoder's BatchNorm / gather / scatter kernels -- is
+        HBM-bound: with `side_stream` set they are issued on that stream (forked from the current one), and
+        join() makes the current stream wait for them (trainer.train_step / graph_step call it before the
+        gradients are consumed).  Inside a hipGraph capture this is a forked branch of the graph."""
         hi = self._flushed_hi
         lo = hi
         while lo > 0 and self._layer_done(lo - 1):
             lo -= 1
-        n = hi - lo
-        if n <= 0:
+        if hi - lo <= 0:
             return
         self._flushed_hi = lo
+        side = self.side_stream
+        if side is None:
+            self._products(lo, hi)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._products(lo, hi)
+        self._forked = True
+
+    def join(self):
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            self._forked = False
+
+    @torch.no_grad()
+    def _products(self, lo, hi):
+        n = hi - lo
         P, H, I, L, rq = self.P, self.H, self.I, self.L, self.rq
         # feed-forward pair: (query branch, text branch) x n layers
         torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
@@ -1113,7 +1134,10 @@ class BertEncoder(nn.Module):
         # at forward time (autograd must adopt, not accumulate into, the views it is handed), no per-parameter
         # gradient hooks that would fire before flush().  trainer.train_step / graph_step switch it per mode.
         self.defer_weight_grads = os.environ.get("SIG3D_QF_DEFER", "1") != "0"
-        self._arena = None
+        # opt-in: measured SLOWER on MI355X (9.27 vs 8.99 ms per step): the batched GEMMs fill every CU, the point
+        # encoder's backward kernels beside them (and the FPS branch) only get in each other's way
+        self.flush_on_side_stream = os.environ.get("SIG3D_QF_FLUSH_STREAM", "0") != "0"
+        self._arena, self._side = None, None
 
     def _make_arena(self, hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut):
         if not (self.defer_weight_grads and torch.is_grad_enabled() and hidden_states.is_cuda):
@@ -1134,14 +1158,22 @@ class BertEncoder(nn.Module):
         enc2 = None
         if encoder_hidden_states is not None:
             enc2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[2])
-        return _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
-                                self.layer[0].attention.self.num_attention_heads, ret)
+        arena = _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
+                                 self.layer[0].attention.self.num_attention_heads, ret)
+        if self.flush_on_side_stream:
+            dev = hidden_states.device
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(dev)
+            arena.side_stream = self._side
+        return arena
 
     def flush_weight_grads(self):
         """Fill the deferred weight gradients of every layer whose backward has run (see _WeightGradArena;
-        automatic at the end of a whole backward pass, explicit between the pieces of a split one)."""
+        automatic at the end of a whole backward pass, explicit between the pieces of a split one) and make
+        the current stream wait for them."""
         if self._arena is not None:
             self._arena.flush()
+            self._arena.join()
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
