@@ -333,7 +333,7 @@ static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, i
   SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
   SIG3D_REQUIRE(p_drop == 0.f || mask != nullptr, "the forward's mask buffer is required when p_drop > 0");
   if (rows == 0) {
-    SIG3D_HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * 3 * cols, stream));
+    if (dparams) SIG3D_HIP_TRY(hipMemsetAsync(dparams, 0, sizeof(float) * 3 * cols, stream));
     return 0;
   }
   SIG3D_REQUIRE(workspace != nullptr, "workspace of 3*cols*ceil(rows/4) floats is required");
@@ -356,7 +356,10 @@ static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, i
                        cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan,
                        eps, live_rows, pad_copy);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
-  // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols)
+  // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols).  dparams == NULL: the
+  // caller folds the partial rows itself later (several tails in one sig3d_column_sum launch): the workspace
+  // holds (blocks, 3*cols) rows, blocks = ceil(ceil(rows / rpw) / 4), blocks / parts consecutive rows per part
+  if (dparams == nullptr) return 0;
   hipLaunchKernelGGL(column_sum_kernel, dim3(sig3d_ceil_div(3 * cols, 64), parts), dim3(CS_WAVES * 64), 0,
                      stream, blocks / parts, 3 * cols, workspace, dparams);
   SIG3D_LAUNCH_CHECK("column_sum_kernel");

@@ -141,7 +141,17 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, m
     return out, v, stats, mask
 
 
-def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None, dx_out=None, pass_through=False):
+def _ln_bwd_blocks(rows, part_rows=0):
+    """Partial rows sig3d_dropout_add_ln_bwd leaves in its workspace (see include/sig3d_hip.h)."""
+    rpw = 8 if rows >= 4096 else (2 if rows >= 256 else 1)
+    if 0 < part_rows < rows:
+        while part_rows % (4 * rpw) != 0:
+            rpw >>= 1
+    return (-(-rows // rpw) + 3) // 4
+
+
+def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None, dx_out=None, pass_through=False,
+                 work_out=None):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
     dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0).
     v may hold fewer rows than dy2 (see _ln_tail_fwd): dx has v's rows, dres has dy2's with zeros beyond."""
@@ -152,8 +162,11 @@ def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None,
     if pass_through and live < rows:
         live = -live
     shape = (rows // part_rows, 3, cols) if part_rows > 0 else (3, cols)
-    dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
-    work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
+    if work_out is None:
+        dparams = torch.empty(shape, dtype=torch.float32, device=v.device)
+        work = torch.empty(((rows + 3) // 4, 3 * cols), dtype=torch.float32, device=v.device)
+    else:   # the caller folds the per-workgroup partial sums later (many tails in one launch)
+        dparams, work = None, work_out
     tail = (_lib.ptr(dy2), _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma), _lib.ptr(mask),
             _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work), _lib.stream_ptr(v.device))
     with torch.cuda.device(v.device):
@@ -450,6 +463,11 @@ class _WeightGradArena:
         # results
         self.gwqkv, self.gbqkv, self.gwo = e(NL, 3 * H, H), e(NL, 3 * H), e(NL, H, H)
         self.gw1, self.gb1, self.gw2 = e(NL, 2, I, H), e(NL, 2, I), e(NL, 2, H, I)
+        # LayerNorm-tail parameter gradients [d gamma | d beta | d bias]: per-workgroup partial rows of every
+        # tail's backward kernel, folded over all layers at once
+        self.ln_blocks_ffn, self.ln_blocks_attn = _ln_bwd_blocks(rows, P), _ln_bwd_blocks(rows)
+        self.ln_work_ffn, self.ln_ffn = e(NL, self.ln_blocks_ffn, 3 * H), e(NL, 2, 3, H)
+        self.ln_work_attn, self.ln_attn = e(NL, self.ln_blocks_attn, 3 * H), e(NL, 3, H)
         nc = len(self.cross)
         self.enc2 = enc2
         if nc:
@@ -459,6 +477,7 @@ class _WeightGradArena:
             self.kv, self.dkv = e(nrow_e, nc * 2 * H), e(nrow_e, nc * 2 * H)
             self.gwq_x, self.gbq_x, self.gwo_x = e(nc, H, H), e(nc, H), e(nc, H, H)
             self.gwkv, self.gbkv = e(nc * 2 * H, cenc), e(nc * 2 * H)
+            self.ln_work_x, self.ln_x = e(nc, self.ln_blocks_attn, 3 * H), e(nc, 3, H)
             with torch.no_grad():   # [Wk;Wv] of every cross layer stacked: one projection GEMM for all of them
                 ws, bs = [], []
                 for i in self.cross:
@@ -541,6 +560,10 @@ class _WeightGradArena:
         torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
         torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
         _colsum(self.dproj[lo:hi].view(n * L, 3 * H), parts=n, out=self.gbqkv[lo:hi])
+        # LayerNorm tails: (layer, part) x blocks-per-part partial rows -> [d gamma | d beta | d bias]
+        bf, ba = self.ln_blocks_ffn, self.ln_blocks_attn
+        _colsum(self.ln_work_ffn[lo:hi].view(n * bf, 3 * H), parts=2 * n, out=self.ln_ffn[lo:hi].view(2 * n, 3 * H))
+        _colsum(self.ln_work_attn[lo:hi].view(n * ba, 3 * H), parts=n, out=self.ln_attn[lo:hi].view(n, 3 * H))
         # cross-attention layers inside the range
         js = [j for j, l in enumerate(self.cross) if lo <= l < hi]
         if js:
@@ -549,6 +572,7 @@ class _WeightGradArena:
             torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
             torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
             _colsum(self.dq_x[j0:j1].view(m * rq, H), parts=m, out=self.gbq_x[j0:j1])
+            _colsum(self.ln_work_x[j0:j1].view(m * ba, 3 * H), parts=m, out=self.ln_x[j0:j1].view(m, 3 * H))
             cols = slice(j0 * 2 * H, j1 * 2 * H)
             torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
             if m == len(self.cross):
@@ -654,8 +678,13 @@ class _AttentionBlockFn(torch.autograd.Function):
         dyo_buf = None
         if arena is not None:
             dyo_buf = arena.dyo_attn[li] if self_attn else arena.dyo_x[j]
+        work = None
+        if arena is not None:
+            work = arena.ln_work_attn[li] if self_attn else arena.ln_work_x[j]
         dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden, dx_out=dyo_buf,
-                                          pass_through=passing)
+                                          pass_through=passing, work_out=work)
+        if arena is not None:
+            dparams = arena.ln_attn[li] if self_attn else arena.ln_x[j]
         datt = dyo.mm(wo)
         if arena is None:
             dproj = torch.empty_like(proj)
@@ -783,7 +812,10 @@ class _FFNPairBlockFn(torch.autograd.Function):
         arena, li = ctx.arena, ctx.li
         P = x.shape[0] // 2
         dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop, P,
-                                          dx_out=None if arena is None else arena.dyo_ffn[li])
+                                          dx_out=None if arena is None else arena.dyo_ffn[li],
+                                          work_out=None if arena is None else arena.ln_work_ffn[li])
+        if arena is not None:
+            dparams = arena.ln_ffn[li]
         dyo3 = dyo.view(2, P, -1)
         gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
         gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
