@@ -169,6 +169,7 @@ def cpu_baseline(model, seed):
     full size: the same scenes with the same (trained) weights through the HIP path give `loss_gpu`."""
     from oracle import pointnet2_ref
     import copy
+    model.Qformer.bert.encoder._arena = None   # per-forward scratch of the last step (non-leaf tensors): not part of the model
     cpu_model = _without_dropout(copy.deepcopy(model).cpu().train())
     batch = synthetic_batch(CPU_SCENES, N_POINTS, seed, "cpu")
     t0 = time.perf_counter()

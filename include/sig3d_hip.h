@@ -320,6 +320,28 @@ int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, int live_
 /* *counter += 1 (uint32) on the stream: the per-forward seed of the dropout hash. */
 int sig3d_counter_increment(unsigned *counter, void *stream);
 
+/* ---- training loss and localisation target -------------------------------------------------- */
+
+/* The SQA3D loss of lib/loss_helper.py:195-227, 286-300 in one launch:
+ *   answer = BCE-with-logits(answer_scores, answer_targets, 'sum') / b          (soft multi-hot targets)
+ *   pos / rot = MSE (l1 == 0) or L1 (l1 != 0) of aux_scores vs aux_targets on columns [0,3) / [3,aux_dim), 'mean'
+ *   loss = amplify * (situation_w * (pos_w * pos + rot_w * rot) + qa_w * answer)     (amplify = 10, :300)
+ * losses[5] = {loss, answer, pos, rot, aux}; d_answer (b, num_answers) and d_aux (b, aux_dim) receive
+ * d loss / d scores.  sig3d_sqa_loss_scale multiplies them by the incoming gradient (*upstream) -- the whole
+ * backward of the loss. */
+int sig3d_sqa_loss(int b, int num_answers, int aux_dim, int l1, const float *answer_scores,
+                   const float *answer_targets, const float *aux_scores, const float *aux_targets, float qa_w,
+                   float situation_w, float pos_w, float rot_w, float amplify, float *losses, float *d_answer,
+                   float *d_aux, void *stream);
+int sig3d_sqa_loss_scale(int n_answer, int n_aux, const float *upstream, const float *d_answer, const float *d_aux,
+                         float *g_answer, float *g_aux, void *stream);
+
+/* Gaussian localisation target of SIG3D.forward (situation3d/models/sqa_module.py:328-338):
+ *   out[b][i] = exp(-|positions[b][i][:2] - pose[b][:2]|^2 / (2 sigma^2)) / sum_i(...)
+ * positions (b, t, pdim >= 2), pose (b, pose_dim >= 2), out (b, t). */
+int sig3d_gaussian_target(int b, int t, int pdim, float sigma, const float *positions, const float *pose,
+                          int pose_dim, float *out, void *stream);
+
 /* ---- optimizer step ---------------------------------------------------------------------- */
 
 /* clip_grad_value_ + AdamW.step() (+ the next zero_grad) of lib/solver.py:618-627 /

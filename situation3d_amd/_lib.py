@@ -64,6 +64,9 @@ SIGNATURES = {
     "sig3d_dropout_add_mcan_norm_fwd": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                  _P, _P],
     "sig3d_dropout_add_mcan_norm_bwd": [_I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_sqa_loss": [_I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P],
+    "sig3d_sqa_loss_scale": [_I, _I, _P, _P, _P, _P, _P, _P],
+    "sig3d_gaussian_target": [_I, _I, _I, _F, _P, _P, _I, _P, _P],
     "sig3d_counter_increment": [_P, _P],
     "sig3d_step_increment": [_P, _P],
     "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _I, _P],

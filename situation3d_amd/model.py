@@ -104,7 +104,7 @@ class SIG3DQFormer(nn.Module):
         pose = data_dict["auxiliary_task"]
         sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
         data_dict["situational_positions"] = sit_xyz
-        data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose[:, :3])
+        data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose)   # reads pose[:, :2]
         tokens = tok_feat + self.pos_embed(sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2])
         if data_dict.get("_split_backward"):
             # data-parallel step (graph_step.py): the backward pass is cut at the visual tokens (and, with

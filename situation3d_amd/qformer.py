@@ -1206,6 +1206,8 @@ class BertEncoder(nn.Module):
         if self._arena is not None:
             self._arena.flush()
             self._arena.join()
+            if self._arena._flushed_hi == 0:
+                self._arena = None   # every gradient is in place (the views keep their storage alive)
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,

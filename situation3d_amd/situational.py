@@ -49,7 +49,17 @@ def situational_transform(pose, points, inverse=False):
 
 
 def gaussian_localisation_target(scene_positions, gt_translation, sigma=0.16):
-    """sqa_module.py:328-338: weights ~ exp(-|p_xy - t_xy|^2 / (2 sigma^2)), normalised per scene."""
+    """sqa_module.py:328-338: weights ~ exp(-|p_xy - t_xy|^2 / (2 sigma^2)), normalised per scene.
+    On the GPU (no gradient wanted: it is a target) one launch of csrc/sqa_loss.hip instead of seven torch kernels."""
+    if (scene_positions.is_cuda and scene_positions.dtype == torch.float32 and gt_translation.dtype == torch.float32
+            and not (torch.is_grad_enabled() and (scene_positions.requires_grad or gt_translation.requires_grad))):
+        import ctypes
+        p, t = scene_positions.contiguous(), gt_translation.contiguous()
+        out = torch.empty(p.shape[:2], dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.call("sig3d_gaussian_target", p.shape[0], p.shape[1], p.shape[2], ctypes.c_float(sigma), _lib.ptr(p),
+                      _lib.ptr(t), t.shape[1], _lib.ptr(out), _lib.stream_ptr(p.device))
+        return out
     d = torch.norm(scene_positions[..., :2] - gt_translation[:, None, :2], dim=2)
     w = torch.exp(-d ** 2 / (2 * sigma ** 2))
     return w / w.sum(dim=1, keepdim=True)

@@ -31,7 +31,52 @@ def compute_aux_situation_loss(data_dict, tag="__l2__quat__"):
     return LOSS_W["SITUATION_POS_W"] * pos + LOSS_W["SITUATION_ROT_W"] * rot, pos, rot
 
 
+class _FusedSQALossFn(torch.autograd.Function):
+    """loss_helper.py:195-227, 286-300 as one HIP launch (csrc/sqa_loss.hip); backward = one scaling launch."""
+
+    @staticmethod
+    def forward(ctx, answer_scores, aux_scores, answer_targets, aux_targets, l1):
+        import ctypes
+        from . import _lib
+        a, x = answer_scores.contiguous(), aux_scores.contiguous()
+        dev = a.device
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        d_a, d_x = torch.empty_like(a), torch.empty_like(x)
+        f = ctypes.c_float
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_sqa_loss", a.shape[0], a.shape[1], x.shape[1], int(l1), _lib.ptr(a),
+                      _lib.ptr(answer_targets.contiguous()), _lib.ptr(x), _lib.ptr(aux_targets.contiguous()),
+                      f(LOSS_W["QA_W"]), f(LOSS_W["SITUATION_W"]), f(LOSS_W["SITUATION_POS_W"]),
+                      f(LOSS_W["SITUATION_ROT_W"]), f(10.0), _lib.ptr(losses), _lib.ptr(d_a), _lib.ptr(d_x),
+                      _lib.stream_ptr(dev))
+        ctx.save_for_backward(d_a, d_x)
+        ctx.mark_non_differentiable(losses)
+        return losses[0], losses
+
+    @staticmethod
+    def backward(ctx, g, _):
+        from . import _lib
+        d_a, d_x = ctx.saved_tensors
+        g_a, g_x = torch.empty_like(d_a), torch.empty_like(d_x)
+        with torch.cuda.device(d_a.device):
+            _lib.call("sig3d_sqa_loss_scale", d_a.numel(), d_x.numel(), _lib.ptr(g.contiguous()), _lib.ptr(d_a),
+                      _lib.ptr(d_x), _lib.ptr(g_a), _lib.ptr(g_x), _lib.stream_ptr(d_a.device))
+        return g_a, g_x, None, None, None
+
+
 def get_loss(data_dict, situation_loss_tag="__l2__quat__", use_aux_situation=True, use_answer=True):
+    a, x = data_dict.get("answer_scores"), data_dict.get("aux_scores")
+    if (use_aux_situation and use_answer and a is not None and a.is_cuda and a.dtype == torch.float32
+            and "answer_cat_scores" in data_dict and x is not None and x.dim() == 2 and x.shape[1] >= 4
+            and ("__l2__" in situation_loss_tag or "__l1__" in situation_loss_tag)):
+        # the GPU hot path: every term of the loss and its gradient in one launch
+        loss, parts = _FusedSQALossFn.apply(a, x, data_dict["answer_cat_scores"].to(torch.float32),
+                                            data_dict["auxiliary_task"].to(torch.float32),
+                                            "__l2__" not in situation_loss_tag)
+        data_dict["answer_loss"], data_dict["pos_loss"], data_dict["rot_loss"], data_dict["aux_loss"] = \
+            parts[1], parts[2], parts[3], parts[4]
+        data_dict["loss"] = loss
+        return loss, data_dict
     zero = data_dict["answer_scores"].new_zeros(())
     data_dict["answer_loss"] = compute_answer_classification_loss(data_dict) if use_answer else zero
     if use_aux_situation:

@@ -82,3 +82,39 @@ def test_two_d_pos_embed_matches_reference():
     pe = build_pos_embed(2, 256)
     pe.load_state_dict({k[len("pos_embed."):]: v for k, v in g.items() if k.startswith("pos_embed.")}, strict=True)
     torch.testing.assert_close(pe(g["scene_positions"]), g["pos_embed_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["__l2__quat__", "__l1__quat__"])
+def test_fused_loss_kernel_matches_torch_formulation(tag):
+    """csrc/sqa_loss.hip (one launch for every term of loss_helper.py:195-227, 286-300 and its gradient) against
+    the torch formulation the CPU path keeps, at the bench's sizes: loss terms and d loss / d scores."""
+    from situation3d_amd import trainer
+    g = torch.Generator().manual_seed(3)
+    B, A = 8, 706
+    scores = (torch.randn(B, A, generator=g) * 3).cuda().requires_grad_(True)
+    aux = torch.randn(B, 7, generator=g).cuda().requires_grad_(True)
+    targets = (torch.rand(B, A, generator=g) > 0.99).float().cuda()
+    pose = (torch.randn(B, 7, generator=g) * 2).cuda()
+    dd = {"answer_scores": scores, "aux_scores": aux, "answer_cat_scores": targets, "auxiliary_task": pose}
+    loss, dd = trainer.get_loss(dd, situation_loss_tag=tag)
+    (loss * 0.7).backward()
+    s2, a2 = scores.detach().cpu().double().requires_grad_(True), aux.detach().cpu().double().requires_grad_(True)
+    ref = {"answer_scores": s2, "aux_scores": a2, "answer_cat_scores": targets.cpu().double(), "auxiliary_task": pose.cpu().double()}
+    rl, ref = trainer.get_loss(ref, situation_loss_tag=tag)     # host tensors: the torch formulation
+    (rl * 0.7).backward()
+    for k in ("loss", "answer_loss", "pos_loss", "rot_loss", "aux_loss"):
+        torch.testing.assert_close(dd[k].detach().cpu().double(), ref[k].detach(), rtol=1e-5, atol=1e-6, msg=k)
+    torch.testing.assert_close(scores.grad.cpu().double(), s2.grad, rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(aux.grad.cpu().double(), a2.grad, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_gaussian_target_kernel_matches_reference():
+    from situation3d_amd.situational import gaussian_localisation_target
+    g = _load("situational_live.npz")
+    w = gaussian_localisation_target(g["scene_positions"].cuda(), g["auxiliary_task"].cuda())
+    torch.testing.assert_close(w.cpu(), g["auxiliary_task_loc_gt"], rtol=1e-5, atol=1e-7)
+    p3 = torch.cat([g["scene_positions"], torch.rand(3, 256, 1)], -1).cuda()
+    torch.testing.assert_close(gaussian_localisation_target(p3, g["auxiliary_task"].cuda()).cpu(),
+                               g["auxiliary_task_loc_gt"], rtol=1e-5, atol=1e-7)
