@@ -372,12 +372,10 @@ def main():
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
         traffic, traffic_commit = None, None
-        for cand in ("r02_pmc_group_pair.json", "r01_pmc_query_group_fused.json"):
-            pmc = os.path.join(ROOT, "profiles", cand)
-            if os.path.exists(pmc):
-                j = json.load(open(pmc))
-                traffic, traffic_commit = round(j["traffic_bytes_per_launch"]), j.get("commit", "round 1 (0c8aecd)")
-                break
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_group_pair.json")
+        if os.path.exists(pmc):
+            j = json.load(open(pmc))
+            traffic, traffic_commit = round(j["traffic_bytes_per_step"]), j.get("commit")
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -396,7 +394,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ball_query (grid + scan) + query_group (fused / point-major / compact) "
                                                    "+ point-major transposes, SA1-4",
                          "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(pair_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_commit": traffic_commit,
+                         "frac": round(pair_gbs / HBM_PEAK_GBS, 4),
+                         # HBM bytes of the same kernels per step (PMC, FETCH_SIZE x 2 + WRITE_SIZE) and the commit
+                         # they were measured at; per step like algorithmic_bytes_per_step
+                         "traffic": traffic, "traffic_commit": traffic_commit,
                          "algorithmic_bytes_per_step": round(pair_bytes / KSTEPS),
                          "launches_per_step": pair_launches // KSTEPS, "ms_per_step": round(pair_ms / KSTEPS, 4),
                          "dense_equivalent_frac": round(sum(ball_query_algorithmic_bytes(BATCH, n, m, ns)
