@@ -29,6 +29,12 @@ extern "C" {
 const char *sig3d_version(void);          /* "sig3d-hip <semver> gfx950" */
 const char *sig3d_last_error(void);       /* thread-local message of the last failing call */
 
+/* Diagnostic: store the GPU wall clock into *slot from `stream` (a graph node when captured) --
+ * the concurrent timeline of a replayed hipGraph, which per-node events and profilers cannot give.
+ * sig3d_timestamp_rate: ticks per second of that clock. */
+int sig3d_timestamp(unsigned long long *slot, void *stream);
+int sig3d_timestamp_rate(int device, long long *hz);
+
 /* ---- PointNet++ ops: lib/pointnet2/_ext_src ------------------------------------------ */
 
 /* replaces furthest_point_sampling_kernel_wrapper(b,n,m,dataset,temp,idxs)
@@ -38,6 +44,15 @@ const char *sig3d_last_error(void);       /* thread-local message of the last fa
  * including the reference's tie-break order and its `mag <= 1e-3` skip rule. */
 int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                   int *idxs, void *stream);
+
+/* Same wrapper, same results for ANY input, for the call sites whose `dataset` is itself the
+ * output of an earlier FPS stored in pick order (SA level l+1 sampling the centres of level l,
+ * pointnet2_modules.py:233-240 stacked four times in models/.../pointnet2 backbone).  FPS over
+ * an FPS-ordered cloud picks 0,1,..,m-1 unless candidates tie exactly; two parallel kernels
+ * PROVE that per scene with the reference's own arithmetic and tie order, and only the scenes
+ * that fail the proof run the m dependent rounds.  flags: b ints, 1 = proven, 0 = computed. */
+int sig3d_furthest_point_sampling_nested(int b, int n, int m, const float *dataset, float *temp,
+                                         int *idxs, int *flags, void *stream);
 
 /* replaces gather_points_kernel_wrapper(b,c,n,npoints,points,idx,out)
  *   sampling.cpp:4-6, sampling_gpu.cu:8-31.   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

@@ -19,7 +19,10 @@ _F = ctypes.c_float
 # name -> argtypes (restype is int status everywhere); order == include/sig3d_hip.h
 SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "sig3d_furthest_point_sampling_nested": [_I, _I, _I, _P, _P, _P, _P, _P],
     "sig3d_fps_timeout_count": [_P, _I],
+    "sig3d_timestamp": [_P, _P],
+    "sig3d_timestamp_rate": [_I, _P],
     "sig3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_gather_xyz": [_I, _I, _I, _P, _P, _P, _P],

@@ -20,8 +20,6 @@
 // as (bitrev << 22) | (k >> L).  Points with x^2+y^2+z^2 <= 1e-3 (double compare, :100-101)
 // never take part: their running distance is pinned to -1, which also makes the all-skipped
 // case return index 0 as the reference does (best = -1, besti = 0).
-#include <cstdlib>
-
 #include "sig3d_common.h"
 
 namespace {
@@ -42,12 +40,19 @@ template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int L,
                                                  const float *__restrict__ dataset_all,
                                                  float *__restrict__ temp_all,
-                                                 int *__restrict__ idxs_all) {
+                                                 int *__restrict__ idxs_all,
+                                                 const int *__restrict__ prefix_ok) {
   constexpr int NW = NT / 64;
   __shared__ int s_val[2][NW];
   __shared__ unsigned s_key[2][NW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (prefix_ok != nullptr && prefix_ok[blockIdx.x] != 0) {
+    // fps_prefix_check_kernel proved that every round of this scene picks the next point in
+    // storage order: the result is 0..m-1 and the m dependent rounds need not run
+    for (int j = tid; j < m; j += NT) idxs_all[(size_t)blockIdx.x * m + j] = j;
+    return;
+  }
   const float *dataset = dataset_all + (size_t)blockIdx.x * n * 3;
   float *temp = temp_all + (size_t)blockIdx.x * n;
   int *idxs = idxs_all + (size_t)blockIdx.x * m;
@@ -124,11 +129,76 @@ __global__ __launch_bounds__(NT) void fps_kernel(int n, int m, int L,
 
 template <int NT, int PPT>
 int launch_fps(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
-               hipStream_t stream) {
+               hipStream_t stream, const int *prefix_ok = nullptr) {
   hipLaunchKernelGGL((fps_kernel<NT, PPT>), dim3(b), dim3(NT), 0, stream, n, m, L, dataset, temp,
-                     idxs);
+                     idxs, prefix_ok);
   SIG3D_LAUNCH_CHECK("fps_kernel");
   return 0;
+}
+
+// ---- FPS over an FPS-ordered cloud: prove the answer instead of computing it ------------------
+// The input of SA level l+1 is the output of the FPS of level l, stored in pick order.  FPS is
+// greedy, so FPS over the first n' picks of an FPS run reproduces that run: unless two candidates
+// tie exactly, round j picks point j and the result is 0,1,...,m-1.  Running the m strictly
+// dependent rounds (0.6 us each, one workgroup per scene) to find that out costs 1.1 ms per step
+// at B = 8; CHECKING it is embarrassingly parallel:
+//   r[j]   = running distance of point j when round j is decided
+//          = min(1e10, min_{i<j} d(x_j, x_i))            (-1 when x_j is a skipped point)
+//   round j picks j  <=>  for every k != j:  t_j(k) < r[j],  or  t_j(k) == r[j] and key(k) > key(j)
+// with t_j(k) the same running minimum for point k and key() the reference's tie order
+// (fps_key).  Same sq_dist3, same fminf chain (min is exact, so its order is free), same skip
+// rule as fps_kernel: the check decides exactly what fps_kernel would have computed, and any
+// scene that fails it (ties, duplicates, zero padding, an input that is not FPS-ordered at all)
+// runs the ordinary kernel.  Bit-exact either way.
+__global__ __launch_bounds__(256) void fps_prefix_radius_kernel(int n, int m,
+                                                                const float *__restrict__ dataset_all,
+                                                                float *__restrict__ r_all,
+                                                                int *__restrict__ ok_all) {
+  const float *dataset = dataset_all + (size_t)blockIdx.y * n * 3;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per round
+  if (blockIdx.x == 0 && threadIdx.x == 0) ok_all[blockIdx.y] = 1;
+  if (j >= m) return;
+  const float x = dataset[3 * j + 0], y = dataset[3 * j + 1], z = dataset[3 * j + 2];
+  const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  float t = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+  for (int i = lane; i < j; i += 64)
+    t = fminf(sq_dist3(x, y, z, dataset[3 * i + 0], dataset[3 * i + 1], dataset[3 * i + 2]), t);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t = fminf(t, __shfl_xor(t, off, 64));
+  if (lane == 0) r_all[(size_t)blockIdx.y * n + j] = t;
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int L,
+                                                               const float *__restrict__ dataset_all,
+                                                               const float *__restrict__ r_all,
+                                                               int *__restrict__ ok_all) {
+  extern __shared__ float s_prefix[];  // x,y,z,r of the first m points
+  const float *dataset = dataset_all + (size_t)blockIdx.y * n * 3;
+  const float *r = r_all + (size_t)blockIdx.y * n;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    s_prefix[4 * i + 0] = dataset[3 * i + 0];
+    s_prefix[4 * i + 1] = dataset[3 * i + 1];
+    s_prefix[4 * i + 2] = dataset[3 * i + 2];
+    s_prefix[4 * i + 3] = r[i];
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const unsigned bsmask = (1u << L) - 1u;
+  const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+  const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  float t = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+  const unsigned mykey = fps_key((unsigned)k, L, bsmask);
+  bool bad = false;
+  for (int i = 0; i + 1 < m; ++i) {
+    const float4 p = *reinterpret_cast<const float4 *>(&s_prefix[4 * i]);
+    t = fminf(sq_dist3(x, y, z, p.x, p.y, p.z), t);
+    const float rj = s_prefix[4 * (i + 1) + 3];  // round j = i + 1 must pick point j
+    const bool beats = (t > rj) || (t == rj && mykey < fps_key((unsigned)(i + 1), L, bsmask));
+    bad |= beats && (k != i + 1);
+  }
+  if (bad) ok_all[blockIdx.y] = 0;
 }
 
 // ---- cooperative FPS: one scene spread over W workgroups ------------------------------------
@@ -376,6 +446,36 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
     return 0;
   }
   return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
+}
+
+// FPS of a cloud that is (expected to be) the FPS-ordered output of an earlier FPS: identical
+// results to sig3d_furthest_point_sampling for ANY input, the dependent rounds only run for the
+// scenes where the prefix property fails.  `flags`: b ints of scratch (1 = proven, 0 = computed).
+extern "C" int sig3d_furthest_point_sampling_nested(int b, int n, int m, const float *dataset,
+                                                    float *temp, int *idxs, int *flags,
+                                                    void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+  if (b == 0 || m <= 0) return 0;
+  SIG3D_REQUIRE(n >= 1, "furthest_point_sampling needs n >= 1");
+  SIG3D_REQUIRE(flags != nullptr, "flags must not be null");
+  // the check holds the first m points in LDS and pays off against the single-workgroup kernels
+  if (m > n || m > 4096 || n > 8192)
+    return sig3d_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream_);
+  const int L = ref_opt_n_threads_log2(n);
+  hipLaunchKernelGGL(fps_prefix_radius_kernel, dim3(sig3d_ceil_div(m, 4), b), dim3(256), 0, stream,
+                     n, m, dataset, temp, flags);
+  SIG3D_LAUNCH_CHECK("fps_prefix_radius_kernel");
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n, 256), b), dim3(256),
+                     sizeof(float) * 4 * (size_t)m, stream, n, m, L, dataset, temp, flags);
+  SIG3D_LAUNCH_CHECK("fps_prefix_check_kernel");
+  if (n <= 256) return launch_fps<256, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n < 512) return launch_fps<256, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 512) return launch_fps<512, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 1024) return launch_fps<512, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
 }
 
 extern "C" int sig3d_fps_timeout_count(unsigned *count, int reset) {

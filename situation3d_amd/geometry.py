@@ -13,11 +13,16 @@ the reference gives its DataLoader workers for the CPU-side voxelisation (lib/se
 The numbers produced are bit-identical to calling the ops inline.
 """
 import ctypes
+import os
 
 import torch
 
-from . import _lib
+from . import _lib, timeline
 from .pointnet2 import _ext, fused_mlp
+
+
+# SIG3D_NESTED_FPS=0 runs the dependent rounds on every level (A/B timing; results are identical)
+NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
 
 
 class GeometryPlan:
@@ -27,6 +32,7 @@ class GeometryPlan:
         self.levels = list(levels)
         self.batch, self.n_points = batch, n_points
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
+        self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
         self._bq_work = None  # scratch of the grid ball query (allocated once: static under hipGraph)
         n = n_points
         for npoint, radius, nsample in self.levels:
@@ -34,6 +40,7 @@ class GeometryPlan:
             self.new_xyz.append(torch.zeros(batch, npoint, 3, dtype=torch.float32, device=device))
             self.ball_idx.append(torch.zeros(batch, npoint, nsample, dtype=torch.int32, device=device))
             self._temp.append(torch.zeros(batch, max(n, 128), dtype=torch.float32, device=device))
+            self.fps_proven.append(torch.zeros(batch, dtype=torch.int32, device=device))
             # distinct neighbours of the padded lists (csrc/compact.hip), for the levels that run the MFMA path
             big = fused_mlp.COMPACT and batch * npoint * nsample >= fused_mlp.COMPACT_MIN_POSITIONS
             self.compact.append(fused_mlp.CompactLists(batch, npoint, nsample, device) if big else None)
@@ -49,9 +56,18 @@ class GeometryPlan:
         s = _lib.stream_ptr(dev)
         cur = xyz
         with torch.cuda.device(dev):
+            timeline.mark("geo:start")
             for lvl, (npoint, radius, nsample) in enumerate(self.levels):
-                _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
-                          _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
+                if lvl == 0 or not NESTED_FPS:
+                    _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
+                              _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
+                else:
+                    # `cur` is the FPS-ordered output of the level above: prove inds == 0..m-1 instead
+                    # of running the dependent rounds (csrc/sampling.hip, same results for any input)
+                    _lib.call("sig3d_furthest_point_sampling_nested", b, n, npoint, _lib.ptr(cur),
+                              _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]),
+                              _lib.ptr(self.fps_proven[lvl]), s)
+                timeline.mark("geo:L%d fps" % (lvl + 1))
                 _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
                           _lib.ptr(self.new_xyz[lvl]), s)
                 if n >= _ext.GRID_MIN_POINTS:
@@ -66,6 +82,7 @@ class GeometryPlan:
                               _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
                 if self.compact[lvl] is not None:
                     self.compact[lvl].compute(self.ball_idx[lvl])
+                timeline.mark("geo:L%d lists" % (lvl + 1))
                 cur, n = self.new_xyz[lvl], npoint
         return self
 

@@ -34,7 +34,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import gemm_tuning
+from . import gemm_tuning, timeline
 from .geometry import GeometryPlan
 from .trainer import get_loss
 
@@ -268,13 +268,17 @@ class GraphedTrainStep:
                     self.plan_next.compute(self.static_next_xyz)
             if reducer is not None:
                 reducer.zero_grad()
+            timeline.mark("main:start")
             self.static_loss = fwd_bwd_head() if self._split else fwd_bwd()
+            timeline.mark("main:backward done")
             if reducer is None:
                 update()
+            timeline.mark("main:update done")
             if self.prefetch:
                 stream.wait_stream(self.side)                    # join
                 if not self._split:
                     self.plan_cur.copy_from(self.plan_next)      # hand over for the next replay
+            timeline.mark("main:end")
         if self._split:
             if self.graph_low is not None:
                 with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_low, stream=stream, pool=self.graph.pool(),

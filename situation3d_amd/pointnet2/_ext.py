@@ -71,6 +71,23 @@ def furthest_point_sampling(points, nsamples):
     return out
 
 
+def furthest_point_sampling_nested(points, nsamples, return_proven=False):
+    """furthest_point_sampling for a cloud that is itself FPS output in pick order (the centres of the
+    SA level above): identical indices for ANY input; scenes whose result is provably 0..m-1 skip the
+    dependent rounds (csrc/sampling.hip: fps_prefix_check_kernel).  `return_proven` also returns the
+    (B,) int32 flags, 1 where the proof held."""
+    _check_contiguous(points, "points"); _check_float(points, "points")
+    dev = _lib.require_device(points)
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    out = torch.zeros((b, nsamples), dtype=torch.int32, device=dev)
+    tmp = torch.empty((b, max(n, 1)), dtype=torch.float32, device=dev)
+    flags = torch.zeros((max(b, 1),), dtype=torch.int32, device=dev)
+    _run("sig3d_furthest_point_sampling_nested", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
+         _lib.ptr(out), _lib.ptr(flags))
+    return (out, flags[:b]) if return_proven else out
+
+
 def three_nn(unknowns, knows):
     """interpolate.cpp:14-40: -> [dist2 (B,n,3) f32, idx (B,n,3) i32]."""
     _check_contiguous(unknowns, "unknowns"); _check_contiguous(knows, "knows")

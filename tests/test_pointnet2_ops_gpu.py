@@ -64,6 +64,67 @@ def test_fps_scene_40k(hip_ext, oracle):
     _fps_case(hip_ext, oracle, 1, 40000, 2048, seed=11, dup=500, zero_tail=100)
 
 
+def _nested(points, m, **kw):
+    # an addition of this library, not one of the nine reference bindings the `pointnet2._ext` shim exports
+    from situation3d_amd.pointnet2 import _ext as amd_ext
+    return amd_ext.furthest_point_sampling_nested(points, m, **kw)
+
+
+def _fps_ordered(hip_ext, xyz, m):
+    idx = hip_ext.furthest_point_sampling(xyz.to(DEV), m).long()
+    return torch.gather(xyz.to(DEV), 1, idx[..., None].expand(-1, -1, 3)).contiguous()
+
+
+@pytest.mark.parametrize("n0,n,m", [(40000, 2048, 1024), (5000, 1024, 512), (3000, 512, 256), (900, 300, 300),
+                                    (20000, 4096, 1000), (20000, 8192, 700), (600, 257, 100)])
+def test_nested_fps_proves_the_prefix_on_fps_ordered_clouds(hip_ext, oracle, n0, n, m):
+    """SA level l+1 samples the FPS-ordered centres of level l: the nested entry point must return what
+    the plain one returns (== the oracle), and on tie-free scenes it must have PROVEN it (flag 1, no
+    dependent rounds)."""
+    cloud = _fps_ordered(hip_ext, scene(3, n0, seed=n0 + m), n)
+    got, proven = _nested(cloud, m, return_proven=True)
+    assert torch.equal(got.cpu(), oracle.furthest_point_sampling(cloud.cpu(), m))
+    assert torch.equal(got, hip_ext.furthest_point_sampling(cloud, m))
+    assert proven.tolist() == [1, 1, 1]
+    assert torch.equal(got.cpu(), torch.arange(m, dtype=torch.int32).expand(3, m))
+
+
+def test_nested_fps_falls_back_per_scene_on_ties_skips_and_unordered_input(hip_ext, oracle):
+    # scene 0: FPS-ordered (provable); scene 1: random order; scene 2: FPS-ordered with duplicated points
+    # and a zero tail (ties + skipped points inside the prefix) -> those two run the ordinary rounds
+    a = _fps_ordered(hip_ext, scene(1, 6000, seed=1), 2048)
+    b = scene(1, 2048, seed=2).to(DEV)
+    c = _fps_ordered(hip_ext, scene(1, 6000, seed=3, dup=2500, zero_tail=800), 2048)
+    cloud = torch.cat([a, b, c]).contiguous()
+    got, proven = _nested(cloud, 1024, return_proven=True)
+    ref = oracle.furthest_point_sampling(cloud.cpu(), 1024)
+    assert torch.equal(got.cpu(), ref)
+    assert proven[0].item() == 1 and proven[1].item() == 0
+    assert (proven[2].item() == 1) == torch.equal(ref[2], torch.arange(1024, dtype=torch.int32))
+    # lattice: every round ties; all-zero cloud: every point skipped; m > n and n > 8192: plain kernel
+    g = torch.stack(torch.meshgrid(torch.arange(16.), torch.arange(16.), torch.arange(8.), indexing="ij"), -1)
+    lattice = (g.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()
+    for cloud, m in ((lattice, 512), (_fps_ordered(hip_ext, lattice, 1024).cpu(), 512), (torch.zeros(2, 300, 3), 8),
+                     (scene(1, 40, seed=3), 60), (scene(2, 9000, seed=4), 100), (scene(1, 1, seed=5), 1)):
+        got = _nested(cloud.to(DEV), m).cpu()
+        assert torch.equal(got, oracle.furthest_point_sampling(cloud, m)), (tuple(cloud.shape), m)
+
+
+def test_nested_fps_rejects_a_prefix_that_is_one_swap_away(hip_ext, oracle):
+    """Adversarial: swap two late points of an FPS-ordered cloud -- a single round is wrong, every other
+    condition holds -- and perturb one point by one ulp-scale step so it wins its round early."""
+    base = _fps_ordered(hip_ext, scene(1, 9000, seed=8), 1024)
+    for i, j in ((1, 2), (500, 501), (1022, 1023), (3, 900)):
+        cloud = base.clone()
+        cloud[0, [i, j]] = cloud[0, [j, i]]
+        got, proven = _nested(cloud, 1024, return_proven=True)
+        assert torch.equal(got.cpu(), oracle.furthest_point_sampling(cloud.cpu(), 1024)), (i, j)
+        assert proven.item() == 0
+    cloud = base.clone()
+    got, proven = _nested(cloud[:, :700].contiguous(), 512, return_proven=True)
+    assert proven.item() == 1 and torch.equal(got.cpu()[0], torch.arange(512, dtype=torch.int32))
+
+
 @pytest.mark.parametrize("n,m,r,ns", [(9, 2, 5.0, 6), (9, 2, 10.0, 3), (4096, 512, 0.2, 64),
                                       (4096, 512, 0.8, 16), (1000, 77, 0.5, 7), (100, 100, 0.3, 1),
                                       (63, 5, 1.0, 130), (20000, 256, 0.4, 32)])
