@@ -293,27 +293,32 @@ def pair_roofline(recs, distinct):
     count SURVEY.md 8d's bytes; a compact launch (distinct neighbours only) counts its OWN algorithmic bytes:
     the sources it gathers from once, its index list and the columns it writes (distinct fraction x dense)."""
     t_ms, nbytes, launches = 0.0, 0, 0
+    parts = {}
+
+    def add(name, ms, nb):
+        nonlocal t_ms, nbytes, launches
+        t_ms, nbytes, launches = t_ms + ms, nbytes + nb, launches + 1
+        p = parts.setdefault(name, {"launches": 0, "ms": 0.0, "algorithmic_bytes": 0})
+        p["launches"] += 1
+        p["ms"] += ms
+        p["algorithmic_bytes"] += nb
+
     for name in ("sig3d_ball_query", "sig3d_ball_query_grid"):
         for s_ev, e_ev, ints in recs[name]:
-            t_ms += s_ev.elapsed_time(e_ev)
-            nbytes += ball_query_algorithmic_bytes(ints[0], ints[1], ints[2], ints[3])
-            launches += 1
+            add(name, s_ev.elapsed_time(e_ev), ball_query_algorithmic_bytes(ints[0], ints[1], ints[2], ints[3]))
     for name, pm in (("sig3d_query_group_fused", False), ("sig3d_query_group_fused_pm", True)):
         for s_ev, e_ev, ints in recs[name]:
-            t_ms += s_ev.elapsed_time(e_ev)
-            nbytes += group_algorithmic_bytes(ints[0], ints[1], ints[2], ints[5] if pm else ints[4], ints[3])
-            launches += 1
+            add(name, s_ev.elapsed_time(e_ev),
+                group_algorithmic_bytes(ints[0], ints[1], ints[2], ints[5] if pm else ints[4], ints[3]))
     for s_ev, e_ev, ints in recs["sig3d_query_group_compact"]:
         bb, nn, mm, cc, ns_ = ints[0], ints[1], ints[2], ints[3], ints[5]
         level = [k for k, (ln, lm, lns, lc) in zip(("SA1", "SA2", "SA3", "SA4"), SA_LEVELS) if (ln, lm, lns) == (nn, mm, ns_)]
         frac = distinct.get(level[0], 1.0) if level else 1.0
-        t_ms += s_ev.elapsed_time(e_ev)
-        nbytes += int(bb * (12 * nn + 4 * cc * nn) + frac * bb * mm * ns_ * (4 + 4 * (3 + cc)))
-        launches += 1
+        add("sig3d_query_group_compact", s_ev.elapsed_time(e_ev),
+            int(bb * (12 * nn + 4 * cc * nn) + frac * bb * mm * ns_ * (4 + 4 * (3 + cc))))
     for s_ev, e_ev, ints in recs["sig3d_transpose_cn"]:   # point-major copies feeding the wide levels: pure overhead
-        t_ms += s_ev.elapsed_time(e_ev)
-        launches += 1
-    return t_ms, nbytes, launches
+        add("sig3d_transpose_cn", s_ev.elapsed_time(e_ev), 0)
+    return t_ms, nbytes, launches, parts
 
 
 def main():
@@ -358,7 +363,7 @@ def main():
                 grp.append(s_ev.elapsed_time(e_ev))
                 grp_bytes += group_algorithmic_bytes(ints[0], ints[1], ints[2], ints[5] if pm else ints[4], ints[3])
         cgrp = kernel_ms("sig3d_query_group_compact")
-        pair_ms, pair_bytes, pair_launches = pair_roofline(recs, head["distinct"])
+        pair_ms, pair_bytes, pair_launches, pair_parts = pair_roofline(recs, head["distinct"])
         pair_gbs = pair_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms else 0.0
         # the largest HBM-bound kernel of the step by time is the flat AdamW update: per parameter it reads
         # p, g, m, v and writes p, m, v (28 B: clip + update in one pass; the gradients are dropped, not zeroed)
@@ -400,6 +405,10 @@ def main():
                          "traffic": traffic, "traffic_commit": traffic_commit,
                          "algorithmic_bytes_per_step": round(pair_bytes / KSTEPS),
                          "launches_per_step": pair_launches // KSTEPS, "ms_per_step": round(pair_ms / KSTEPS, 4),
+                         # per C-ABI entry point and step: launches, event-bracketed ms, algorithmic bytes
+                         "parts": {k: {"launches": v["launches"] // KSTEPS, "ms": round(v["ms"] / KSTEPS, 4),
+                                       "algorithmic_bytes": v["algorithmic_bytes"] // KSTEPS}
+                                   for k, v in pair_parts.items()},
                          "dense_equivalent_frac": round(sum(ball_query_algorithmic_bytes(BATCH, n, m, ns)
                                                             + group_algorithmic_bytes(BATCH, n, m, ns, c)
                                                             for n, m, ns, c in SA_LEVELS) * KSTEPS

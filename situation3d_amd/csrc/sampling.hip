@@ -191,12 +191,30 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
   float t = ((double)mag <= 1e-3) ? -1.f : 1e10f;
   const unsigned mykey = fps_key((unsigned)k, L, bsmask);
   bool bad = false;
-  for (int i = 0; i + 1 < m; ++i) {
+  // one wave per SIMD (n * b threads in all): latency is hidden by unrolling, not by occupancy -- eight
+  // broadcast LDS reads in flight per trip; the tie order is only evaluated on an exact tie (rare branch)
+  constexpr int U = 8;
+  int i = 0;
+  for (; i + U < m; i += U) {
+    float4 p[U];
+    float rj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      p[u] = *reinterpret_cast<const float4 *>(&s_prefix[4 * (i + u)]);
+      rj[u] = s_prefix[4 * (i + u + 1) + 3];  // round j = i + u + 1 must pick point j
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t = fminf(sq_dist3(x, y, z, p[u].x, p[u].y, p[u].z), t);
+      if (t >= rj[u] && k != i + u + 1)
+        bad |= (t > rj[u]) || mykey < fps_key((unsigned)(i + u + 1), L, bsmask);
+    }
+  }
+  for (; i + 1 < m; ++i) {
     const float4 p = *reinterpret_cast<const float4 *>(&s_prefix[4 * i]);
     t = fminf(sq_dist3(x, y, z, p.x, p.y, p.z), t);
-    const float rj = s_prefix[4 * (i + 1) + 3];  // round j = i + 1 must pick point j
-    const bool beats = (t > rj) || (t == rj && mykey < fps_key((unsigned)(i + 1), L, bsmask));
-    bad |= beats && (k != i + 1);
+    const float rj = s_prefix[4 * (i + 1) + 3];
+    if (t >= rj && k != i + 1) bad |= (t > rj) || mykey < fps_key((unsigned)(i + 1), L, bsmask);
   }
   if (bad) ok_all[blockIdx.y] = 0;
 }

@@ -262,7 +262,9 @@ class GraphedTrainStep:
         import torch.distributed as dist
         cap_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
-            if self.prefetch:
+            # split mode: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
+            # encoder's backward and the update -- it gets its own graph on the side stream instead (below)
+            if self.prefetch and not self._split:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
                     self.plan_next.compute(self.static_next_xyz)
@@ -274,10 +276,9 @@ class GraphedTrainStep:
             if reducer is None:
                 update()
             timeline.mark("main:update done")
-            if self.prefetch:
+            if self.prefetch and not self._split:
                 stream.wait_stream(self.side)                    # join
-                if not self._split:
-                    self.plan_cur.copy_from(self.plan_next)      # hand over for the next replay
+                self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
             timeline.mark("main:end")
         if self._split:
             if self.graph_low is not None:
@@ -286,8 +287,17 @@ class GraphedTrainStep:
                     bwd_lower()
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(), capture_error_mode=cap_mode):
                 bwd_encoder()
-                if self.prefetch:  # the encoder's backward still reads plan_cur: hand over after it
-                    self.plan_cur.copy_from(self.plan_next)
+            if self.prefetch:
+                # The geometry of batch i+1 as a graph of its own, replayed on the side stream under ALL the
+                # graphs and collectives of step i (a branch captured inside the first graph had to finish with
+                # it: measured +1.1 ms per step at world size 1, the chain runs ~7 ms beside the main branch).
+                # The hand-over is an eager table copy after the encoder's backward, which still reads plan_cur.
+                self.graph_geo = torch.cuda.CUDAGraph()
+                self.side.wait_stream(stream)
+                with torch.cuda.graph(self.graph_geo, stream=self.side, pool=self.graph.pool(),
+                                      capture_error_mode=cap_mode):
+                    self.plan_next.compute(self.static_next_xyz)
+                stream.wait_stream(self.side)
         if reducer is not None:
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
                                                            pool=self.graph.pool(),
@@ -325,6 +335,10 @@ class GraphedTrainStep:
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
             self._announced.set(next_batch["point_clouds"], next_token)
         _copy_into(self.static_batch, batch)
+        if self.prefetch and self._split:
+            self.side.wait_stream(self.stream)   # next coordinates staged; last step's hand-over done
+            with torch.cuda.stream(self.side):
+                self.graph_geo.replay()          # geometry of batch i+1 under everything below
         self.graph.replay()
         if self.reducer is not None:
             if self._split:
@@ -333,6 +347,9 @@ class GraphedTrainStep:
                     self.graph_low.replay()      # ... while the lower layers' backward runs,
                     self._red_low.launch_all()   # whose gradients then travel ...
                 self.graph_enc.replay()          # ... under the point encoder's backward
+                if self.prefetch:
+                    self.stream.wait_stream(self.side)
+                    self.plan_cur.copy_from(self.plan_next)   # hand over for the next step
                 self._red_enc.launch_all()
                 self.optimizer.mark_gathered()
                 self.optimizer.begin_bucketed_step()
