@@ -173,6 +173,63 @@ class GradBucketReducer:
         return len(self.buckets)
 
 
+class SparseRowExchange:
+    """Data-parallel exchange of an embedding table's gradient by ROWS instead of as a dense matrix.
+
+    The Q-Former's word embeddings are 30 522 x 768 (94 MB of gradient, 13 % of a step's all-reduce bytes)
+    and a step touches at most B x T = 160 rows of them per rank.  Each rank contributes its token ids and
+    the per-position gradient rows (what embedding_dense_backward would scatter); two all-gathers
+    (world x n ids, world x n x C floats: 3.9 MB at world size 8) replace the 94 MB all-reduce, and every
+    rank scatter-adds ALL ranks' rows / world into its (zeroed) dense gradient slot -- the same mean of the
+    per-rank dense gradients the all-reduce would have produced (duplicate ids add up, on a rank or across
+    ranks).  VERDICT r01 item 8b; the reference (DDP, runner_base.py:88-95) reduces the dense matrix."""
+
+    def __init__(self, n_rows, width, device, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.ids = torch.zeros(n_rows, dtype=torch.int64, device=device)
+        self.rows = torch.zeros(n_rows, width, dtype=torch.float32, device=device)
+        self._wire = self.world > 1 or _single_rank_rehearsal()
+        if self._wire:
+            self.ids_all = torch.zeros(self.world * n_rows, dtype=torch.int64, device=device)
+            self.rows_all = torch.zeros(self.world * n_rows, width, dtype=torch.float32, device=device)
+        self._handles = ()
+
+    def launch(self):
+        """Asynchronous all-gathers of this rank's (ids, rows), stream-ordered after the current stream."""
+        if self._wire:
+            self._handles = (dist.all_gather_into_tensor(self.ids_all, self.ids, group=self.group, async_op=True),
+                             dist.all_gather_into_tensor(self.rows_all, self.rows, group=self.group, async_op=True))
+
+    def finish_into(self, dense):
+        """dense (V, C): the zeroed gradient slot of the table; += mean over ranks of the scattered rows."""
+        for h in self._handles:
+            h.wait()
+        self._handles = ()
+        ids, rows = (self.ids_all, self.rows_all) if self._wire else (self.ids, self.rows)
+        dense.index_add_(0, ids, rows, alpha=1.0 / self.world)
+
+
+class _EmbeddingRowsFn(torch.autograd.Function):
+    """F.embedding whose backward hands the per-position gradient rows to a SparseRowExchange instead of
+    scattering them into a dense (V, C) gradient; the table itself gets no .grad from autograd."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, sink):
+        ctx.sink = sink
+        sink.ids.copy_(ids.reshape(-1))
+        return torch.nn.functional.embedding(ids, weight)
+
+    @staticmethod
+    def backward(ctx, grad):
+        ctx.sink.rows.copy_(grad.reshape(ctx.sink.rows.shape))
+        return None, None, None
+
+
+def embedding_rows(weight, ids, sink):
+    return _EmbeddingRowsFn.apply(weight, ids, sink)
+
+
 def init_distributed(backend=None):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run
     contract) and bind this process to its GPU.  Returns (rank, local_rank, world_size)."""

@@ -204,17 +204,21 @@ class GraphedTrainStep:
         # (a third of the step) is still computing.  Two graphs + two bucket sets; no collective captured.
         self._split = False
         self._qf_cut = None
+        self._emb_sink = None
         if (self._bucketed_update and split_backward and os.environ.get("SIG3D_NO_SPLIT") is None
                 and hasattr(model, "encoder") and hasattr(model, "Qformer")):
             from .ddp import GradBucketReducer
             layers = list(model.Qformer.bert.encoder.layer)
-            # SIG3D_QF_CUT=k (default 0 = off): also cut the backward after Q-Former layer k, so that the upper
-            # layers' gradients travel under the lower layers' backward.  Measured on one GPU the third graph and
-            # gather cost ~1.2 ms of host-side launch time per step, about what the extra overlap can hide on
-            # xGMI, so it stays opt-in until it can be measured on the 8-GPU node.
+            # SIG3D_QF_CUT=k: also cut the backward after Q-Former layer k (third graph / gather / bucket set), so
+            # that the upper layers' gradients travel under the lower layers' backward.  Costs ~0.3 ms per step
+            # (measured at world size 1: 9.04 -> 9.33 ms) and moves the start of the exchange 1.4 ms forward --
+            # worth it whenever the wire is the longer chain, which it is by far at 2 GPUs (ONE xGMI link between
+            # the pair: ~8 ms for 614 MB) and within the model's error at 4 and 8.
+            # Default: the middle layer when there are peers, no cut alone.
             cut = 0
             if getattr(model.Qformer.bert, "segmented_layout", False) and len(layers) >= 2:
-                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", "0")), len(layers) - 1))
+                default_cut = len(layers) // 2 if getattr(reducer, "world", 1) > 1 else 0
+                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", str(default_cut))), len(layers) - 1))
             up_mods = layers[cut:] + [model.position_head, model.rotation_head, model.aux_reg, model.answer_cls]
             upper = [p for mod in up_mods for p in mod.parameters() if p.requires_grad]
             up_ids = {id(p) for p in upper}
@@ -222,8 +226,22 @@ class GraphedTrainStep:
             lower += [model.query_tokens] if model.query_tokens.requires_grad else []
             if cut == 0:           # no cut inside the Q-Former: everything downstream of the tokens is one part
                 upper, lower = upper + lower, []
-            parts = optimizer.flat_grad_parts([upper, lower])
+            # the word-embedding table's gradient (94 MB dense, <= B x T live rows) travels as rows
+            # (ddp.SparseRowExchange) unless SIG3D_DENSE_EMBED_GRAD is set
+            emb = getattr(model.Qformer.bert, "embeddings", None)
+            q = self.static_batch.get("q_feat")
+            table = emb.word_embeddings.weight if emb is not None and q is not None else None
+            if table is not None and (not table.requires_grad or os.environ.get("SIG3D_DENSE_EMBED_GRAD")):
+                table = None
+            parts = optimizer.flat_grad_parts([upper, lower], exclude=[table] if table is not None else ())
             if parts[0] and parts[2]:
+                if table is not None:
+                    from .ddp import SparseRowExchange
+                    self._emb_sink = SparseRowExchange(q["input_ids"].numel(), table.shape[1], table.device,
+                                                       process_group=reducer.group)
+                    emb.row_grad_sink = self._emb_sink
+                    gi, lo, hi, self._emb_grad = optimizer.mark_externally_reduced(table)
+                    self._emb_range = (gi, lo, hi)
                 self._qf_cut = cut or None
                 self._upper_params, self._lower_params = upper, lower
                 self._red_head = GradBucketReducer.from_flat(parts[0], process_group=reducer.group)
@@ -253,6 +271,9 @@ class GraphedTrainStep:
             fwd_bwd()
             if reducer is not None:
                 reducer.reduce_all()
+            if self._emb_sink is not None:
+                self._emb_sink.launch()
+                self._emb_sink.finish_into(self._emb_grad)
             update()
         torch.cuda.synchronize()
         if reducer is None:
@@ -346,6 +367,8 @@ class GraphedTrainStep:
                 if self.graph_low is not None:
                     self.graph_low.replay()      # ... while the lower layers' backward runs,
                     self._red_low.launch_all()   # whose gradients then travel ...
+                if self._emb_sink is not None:
+                    self._emb_sink.launch()      # word-embedding rows (the embeddings' backward has just run)
                 self.graph_enc.replay()          # ... under the point encoder's backward
                 if self.prefetch:
                     self.stream.wait_stream(self.side)
@@ -356,6 +379,9 @@ class GraphedTrainStep:
                 self.optimizer.update_buckets(self._red_head)
                 if self._red_low is not None:
                     self.optimizer.update_buckets(self._red_low)
+                if self._emb_sink is not None:
+                    self._emb_sink.finish_into(self._emb_grad)     # all ranks' rows -> the table's dense slot
+                    self.optimizer.update_range(*self._emb_range)
                 self.optimizer.update_buckets(self._red_enc)
                 self.optimizer.end_bucketed_step()
             elif self._bucketed_update:

@@ -80,6 +80,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._lr_host = float(self.param_groups[0]["lr"])
         self._lr_dev = torch.full((1,), self._lr_host, dtype=torch.float32, device=dev)
         self._live = np.zeros(len(self._params), dtype=bool)   # which parameters the last gather saw a gradient for
+        self._external = []   # parameters whose flat gradient slot is filled by someone else (see below)
         self._flat_tables = {}
         self._static = np.array(recs, dtype=_REC)          # 'g' holds the byte offset inside the grad
         self._owners = np.array(owners, dtype=np.int64)
@@ -114,6 +115,7 @@ class FlatAdamW(torch.optim.Optimizer):
             live[i] = True
         if dst_field_from_flat_g:
             self._live |= live
+            self._live[self._external] = True
         host, t, table = self._tables(slot)
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]
@@ -154,6 +156,18 @@ class FlatAdamW(torch.optim.Optimizer):
         for p, _, _ in self._params:
             p.grad = None
 
+    def mark_externally_reduced(self, param):
+        """`param` gets no .grad from autograd: its slot of the flat gradient buffer is filled from outside
+        between gather_grads() and the update (ddp.SparseRowExchange for an embedding table).  It stays live
+        for the bucketed update.  -> (group index, lo, hi, view of the slot shaped like the parameter)."""
+        self.flat_grad_buffers()
+        for i, (p, gi, off) in enumerate(self._params):
+            if p is param:
+                if i not in self._external:
+                    self._external.append(i)
+                return gi, off, off + p.numel(), self._groups[gi]["g"][off:off + p.numel()].view_as(p)
+        raise KeyError("not a parameter of this optimizer")
+
     def mark_gathered(self):
         """A replayed hipGraph ran gather_grads(): the flat gradient buffers are current."""
         self._gathered = True
@@ -186,14 +200,17 @@ class FlatAdamW(torch.optim.Optimizer):
                 rest.append(f["g"][hi:])
         return part, rest
 
-    def flat_grad_parts(self, parts):
+    def flat_grad_parts(self, parts, exclude=()):
         """parts: list of parameter lists.  -> one list of flat-gradient slices per part (every maximal run of
-        the part's parameters in storage order is a slice) plus a last list for all other parameters."""
+        the part's parameters in storage order is a slice) plus a last list for all other parameters.
+        Parameters in `exclude` belong to no list (their slot is exchanged some other way)."""
         self.flat_grad_buffers()
         owner = {}
         for k, ps in enumerate(parts):
             for p in ps:
                 owner[id(p)] = k
+        for p in exclude:
+            owner[id(p)] = -1
         out = [[] for _ in range(len(parts) + 1)]
         for gi, f in enumerate(self._groups):
             if f is None:
@@ -207,7 +224,8 @@ class FlatAdamW(torch.optim.Optimizer):
                     j += 1
                 lo = mine[i][1]
                 hi = mine[j][1] if j < len(mine) else f["total"]
-                out[k].append(f["g"][lo:hi])
+                if k >= 0:
+                    out[k].append(f["g"][lo:hi])
                 i = j
         return out
 
@@ -299,6 +317,12 @@ class FlatAdamW(torch.optim.Optimizer):
                         break
                 assert gi is not None, "bucket is not a slice of this optimizer's flat gradients"
                 self._adamw_ranges([(gi, off, off + flat.numel())], stream)
+
+    @torch.no_grad()
+    def update_range(self, gi, lo, hi):
+        """AdamW on flat elements [lo, hi) of group `gi` (inside a bucketed step, like one bucket)."""
+        with torch.cuda.device(self._dev):
+            self._adamw_ranges([(gi, lo, hi)], _lib.stream_ptr(self._dev))
 
     def zero_grad(self, set_to_none=True):
         for p, _, _ in self._params:

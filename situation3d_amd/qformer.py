@@ -878,7 +878,13 @@ class BertEmbeddings(nn.Module):
             position_ids = self.position_ids[
                 :, past_key_values_length: seq_length + past_key_values_length].clone()
         if input_ids is not None:
-            embeddings = self.word_embeddings(input_ids)
+            sink = getattr(self, "row_grad_sink", None)
+            if sink is not None and torch.is_grad_enabled() and sink.ids.numel() == input_ids.numel():
+                # data parallel: the table's gradient travels as rows (ddp.SparseRowExchange)
+                from .ddp import embedding_rows
+                embeddings = embedding_rows(self.word_embeddings.weight, input_ids, sink)
+            else:
+                embeddings = self.word_embeddings(input_ids)
             if self.position_embedding_type == "absolute":
                 embeddings = embeddings + self.position_embeddings(position_ids)
             if query_embeds is not None:

@@ -153,3 +153,57 @@ def test_flat_bucket_launch_all_then_wait_world2(tmp_path):
         torch.testing.assert_close(got0, e, rtol=1e-6, atol=1e-6)
     # every bucket was already reduced at the moment it was consumed
     torch.testing.assert_close(torch.cat(r0["consumed"]), torch.cat(exp), rtol=1e-6, atol=1e-6)
+
+
+def _rows_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from situation3d_amd.ddp import SparseRowExchange, embedding_rows, init_distributed
+    init_distributed(backend="gloo")
+    torch.manual_seed(0)
+    table = nn.Parameter(torch.randn(50, 8))
+    g = torch.Generator().manual_seed(7 + rank)
+    ids = torch.randint(0, 50, (3, 5), generator=g)
+    ids[0, :3] = 4                      # duplicates on a rank; id 4 is also hit on the other rank
+    target = torch.randn(3, 5, 8, generator=g)
+    sink = SparseRowExchange(ids.numel(), 8, "cpu")
+    out = embedding_rows(table, ids, sink)
+    ((out - target) ** 2).sum().backward()
+    assert table.grad is None           # no dense gradient from autograd
+    sink.launch()
+    dense = torch.zeros(50, 8)
+    sink.finish_into(dense)
+    torch.save({"dense": dense, "ids": ids, "target": target}, os.path.join(out_dir, "rows%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_embedding_rows_exchange_equals_mean_of_dense_gradients_world2(tmp_path):
+    """ddp.SparseRowExchange: ids + per-position rows all-gathered, scatter-added / world == what an all-reduce
+    (mean) of the dense embedding gradients gives -- duplicates within and across ranks included."""
+    world, port = 2, _free_port()
+    mp.spawn(_rows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / ("rows%d.pt" % k)) for k in range(world)]
+    assert torch.equal(r[0]["dense"], r[1]["dense"])
+    torch.manual_seed(0)
+    table = nn.Parameter(torch.randn(50, 8))
+    for k in range(world):
+        out = torch.nn.functional.embedding(r[k]["ids"], table)
+        (((out - r[k]["target"]) ** 2).sum() / world).backward()
+    torch.testing.assert_close(r[0]["dense"], table.grad, rtol=1e-5, atol=1e-6)
+    assert (table.grad[4] != 0).any()
+
+
+def test_embedding_rows_single_process():
+    from situation3d_amd.ddp import SparseRowExchange, embedding_rows
+    torch.manual_seed(1)
+    table = nn.Parameter(torch.randn(20, 4))
+    ids = torch.tensor([[1, 1, 3], [19, 0, 1]])
+    sink = SparseRowExchange(6, 4, "cpu")
+    embedding_rows(table, ids, sink).pow(2).sum().backward()
+    dense = torch.zeros(20, 4)
+    sink.launch()
+    sink.finish_into(dense)
+    ref = nn.Parameter(table.detach().clone())
+    torch.nn.functional.embedding(ids, ref).pow(2).sum().backward()
+    torch.testing.assert_close(dense, ref.grad)

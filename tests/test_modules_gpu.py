@@ -372,9 +372,19 @@ def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split, mo
                               split_backward=bool(split))
         assert gs._bucketed_update and gs._split == bool(split)
         assert (gs._qf_cut == 1) == (split == "qf")
+        # split form: the word-embedding table's gradient travels as rows (ddp.SparseRowExchange), not in a bucket
+        assert (gs._emb_sink is not None) == bool(split)
         graph = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(5)]
     torch.cuda.synchronize()
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
+    # ... and the table itself ends where the eager (dense-gradient) run puts it: rows that were hit moved by
+    # ~8 x lr, the others only decayed
+    w1 = m1.Qformer.bert.embeddings.word_embeddings.weight
+    w2 = m2.Qformer.bert.embeddings.word_embeddings.weight
+    torch.manual_seed(5)
+    w0 = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).Qformer.bert.embeddings.word_embeddings.weight.to(DEV)
+    assert (w1 - w0).abs().max() > 3e-3
+    assert (w2 - w1).abs().max() < 2e-4, (w2 - w1).abs().max()
 
 
 def test_graphed_forward_with_prefetched_geometry_matches_inline():
