@@ -230,6 +230,19 @@ def embedding_rows(weight, ids, sink):
     return _EmbeddingRowsFn.apply(weight, ids, sink)
 
 
+def _pg_options(backend):
+    """RCCL's internal stream on a HIGH-PRIORITY queue.  HIP multiplexes streams onto four hardware queues per
+    priority level; when RCCL's stream lands on the queue of the geometry-prefetch stream (7 ms of dependent
+    FPS rounds per step), every bucket's wait() queues behind that chain: measured 13.4 ms per step instead
+    of 9.7 with a real RCCL group of one.  A high-priority stream lives in a different set of queues, and
+    the exchange is the work that should be scheduled first anyway."""
+    if backend != "nccl" or not hasattr(dist, "ProcessGroupNCCL"):
+        return None
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts
+
+
 def init_distributed(backend=None):
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run
     contract) and bind this process to its GPU.  Returns (rank, local_rank, world_size)."""
@@ -247,10 +260,11 @@ def init_distributed(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, pg_options=_pg_options(backend))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
         if os.environ.get("SIG3D_SINGLE_RANK_PG") and not dist.is_initialized():
             dist.init_process_group(backend=backend or "nccl", rank=0, world_size=1,
-                                    init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29517"))
+                                    init_method="tcp://127.0.0.1:%s" % os.environ.get("MASTER_PORT", "29517"),
+                                    pg_options=_pg_options(backend or "nccl"))
     return rank, local, world

@@ -283,9 +283,9 @@ class GraphedTrainStep:
         import torch.distributed as dist
         cap_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
         with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
-            # split mode: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
-            # encoder's backward and the update -- it gets its own graph on the side stream instead (below)
-            if self.prefetch and not self._split:
+            # data parallel: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
+            # encoder's backward / the exchange / the update -- it gets its own graph on the side stream (below)
+            if self.prefetch and reducer is None:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
                     self.plan_next.compute(self.static_next_xyz)
@@ -297,7 +297,7 @@ class GraphedTrainStep:
             if reducer is None:
                 update()
             timeline.mark("main:update done")
-            if self.prefetch and not self._split:
+            if self.prefetch and reducer is None:
                 stream.wait_stream(self.side)                    # join
                 self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
             timeline.mark("main:end")
@@ -308,17 +308,19 @@ class GraphedTrainStep:
                     bwd_lower()
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(), capture_error_mode=cap_mode):
                 bwd_encoder()
-            if self.prefetch:
-                # The geometry of batch i+1 as a graph of its own, replayed on the side stream under ALL the
-                # graphs and collectives of step i (a branch captured inside the first graph had to finish with
-                # it: measured +1.1 ms per step at world size 1, the chain runs ~7 ms beside the main branch).
-                # The hand-over is an eager table copy after the encoder's backward, which still reads plan_cur.
-                self.graph_geo = torch.cuda.CUDAGraph()
-                self.side.wait_stream(stream)
-                with torch.cuda.graph(self.graph_geo, stream=self.side, pool=self.graph.pool(),
-                                      capture_error_mode=cap_mode):
-                    self.plan_next.compute(self.static_next_xyz)
-                stream.wait_stream(self.side)
+        if self.prefetch and reducer is not None:
+            # The geometry of batch i+1 as a graph of its own, replayed on the side stream under ALL the graphs
+            # and collectives of step i.  A branch forked inside the first graph has to finish with that graph:
+            # +1.1 ms per step in the split form (the chain runs ~7 ms beside the main branch), and with RCCL's
+            # stream on a high-priority queue (ddp._pg_options) a graph with an internal fork replays
+            # pathologically slowly (26 ms per step measured with a process group of one).  The hand-over is an
+            # eager table copy after the last graph that reads plan_cur.
+            self.graph_geo = torch.cuda.CUDAGraph()
+            self.side.wait_stream(stream)
+            with torch.cuda.graph(self.graph_geo, stream=self.side, pool=self.graph.pool(),
+                                  capture_error_mode=cap_mode):
+                self.plan_next.compute(self.static_next_xyz)
+            stream.wait_stream(self.side)
         if reducer is not None:
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
                                                            pool=self.graph.pool(),
@@ -330,6 +332,13 @@ class GraphedTrainStep:
         # and, for optimizers other than FlatAdamW with fused kernels, nothing else.  The learning rate is a
         # device scalar (optim.FlatAdamW.sync_lr) and follows a scheduler across replays.
         self._captured_bn_momenta = _bn_momenta(model)
+
+    def _hand_over(self):
+        """Data-parallel forms: join the geometry graph of batch i+1 and make its plan the current one (eager
+        table copy; the last graph that reads plan_cur has been enqueued)."""
+        if self.prefetch:
+            self.stream.wait_stream(self.side)
+            self.plan_cur.copy_from(self.plan_next)
 
     def prime(self, batch):
         """Prefetch mode: compute the geometry of the FIRST batch (pipeline prologue)."""
@@ -356,7 +365,7 @@ class GraphedTrainStep:
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
             self._announced.set(next_batch["point_clouds"], next_token)
         _copy_into(self.static_batch, batch)
-        if self.prefetch and self._split:
+        if self.prefetch and self.reducer is not None:
             self.side.wait_stream(self.stream)   # next coordinates staged; last step's hand-over done
             with torch.cuda.stream(self.side):
                 self.graph_geo.replay()          # geometry of batch i+1 under everything below
@@ -370,9 +379,7 @@ class GraphedTrainStep:
                 if self._emb_sink is not None:
                     self._emb_sink.launch()      # word-embedding rows (the embeddings' backward has just run)
                 self.graph_enc.replay()          # ... under the point encoder's backward
-                if self.prefetch:
-                    self.stream.wait_stream(self.side)
-                    self.plan_cur.copy_from(self.plan_next)   # hand over for the next step
+                self._hand_over()
                 self._red_enc.launch_all()
                 self.optimizer.mark_gathered()
                 self.optimizer.begin_bucketed_step()
@@ -385,10 +392,12 @@ class GraphedTrainStep:
                 self.optimizer.update_buckets(self._red_enc)
                 self.optimizer.end_bucketed_step()
             elif self._bucketed_update:
+                self._hand_over()
                 # all-reduce per bucket, AdamW per bucket right behind it (eager launches, ~12 per step)
                 self.optimizer.mark_gathered()   # the replayed graph filled the flat gradient buffers
                 self.optimizer.step_after(self.reducer)
             else:
+                self._hand_over()
                 self.reducer.reduce_all()
                 self.graph_opt.replay()
         return self.static_loss
