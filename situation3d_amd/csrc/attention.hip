@@ -110,7 +110,7 @@ __device__ __forceinline__ void zero_pad_rows(float *base, unsigned ld, int hi, 
 // is masked; in the backward pass dP is masked the same way and D = rowsum(dO*O) is unchanged.
 struct AttnDropout {
   unsigned seed;
-  unsigned thresh;   // keep iff hash >= thresh
+  unsigned thresh;   // keep iff the element's 16 hash bits >= thresh (p in units of 2^-16)
   float inv_keep;    // 1 / (1 - p)
   int on;
 };
@@ -125,20 +125,27 @@ __device__ __forceinline__ AttnDropout make_dropout(float p_drop, unsigned call_
   AttnDropout d;
   d.on = p_drop > 0.f;
   d.seed = at_mix((rng_counter ? *rng_counter : 0u) * 0x9E3779B9u + call_id);
-  d.thresh = (unsigned)((double)p_drop * 4294967296.0);
+  d.thresh = (unsigned)((double)p_drop * 65536.0 + 0.5);
   d.inv_keep = 1.f / (1.f - p_drop);
   return d;
 }
 
+// One 32-bit hash serves the TWO keys 2i, 2i+1 of a query row (16 bits each: the drop probability is
+// quantised to 2^-16, a relative error of the keep rate below 2e-5): the forward kernel, where a lane owns
+// consecutive keys of one query, pays half the integer multiplies (quarter-rate on the VALU) per element.
+__device__ __forceinline__ unsigned at_pair_hash(const AttnDropout &d, unsigned row_base, int key) {
+  // row_base = ((b*h + head)*nq + query) * ceil(nk / 2)  (wraps mod 2^32 for huge shapes: still a fixed map)
+  return at_mix(d.seed + (row_base + ((unsigned)key >> 1)) * 0x9E3779B9u);
+}
 __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base, int key) {
-  // row_base = ((b*h + head)*nq + query) * nk  (wraps mod 2^32 for huge shapes: still a fixed map)
-  return at_mix(d.seed + (row_base + (unsigned)key) * 0x9E3779B9u) >= d.thresh;
+  const unsigned hsh = at_pair_hash(d, row_base, key);
+  return ((key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu)) >= d.thresh;
 }
 
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
 template <int D>
-__global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
+__global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_fwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int ldq, int ldk,
     int ldv, float scale, float p_drop,
     unsigned call_id, const unsigned *__restrict__ rng_counter, const float *__restrict__ q,
@@ -151,12 +158,14 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // blockIdx.x = query tile * key_splits + key split: with few queries and many keys (3D-LLM: 32 x
+  // blockIdx.y = query tile * key_splits + key split: with few queries and many keys (3D-LLM: 32 x
   // 5000..80000) the key range is cut into key_splits pieces so that the grid covers the chip; the
   // pieces leave (max, sum, un-normalised O) partials that attention_combine_kernel folds.
-  const int q0 = (blockIdx.x / key_splits) * 32, split = blockIdx.x % key_splits;
-  const int hi = blockIdx.y, bi = blockIdx.z;
-  if (blockIdx.x == 0 && bi == 0) zero_pad_rows<D>(out, (unsigned)(h * D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
+  // heads are the FASTEST grid dimension: the h workgroups that read the h 256-byte slices of the same K / V
+  // rows are dispatched together, so a 3 KB row is fetched from HBM while its DRAM page is open
+  const int q0 = (blockIdx.y / key_splits) * 32, split = blockIdx.y % key_splits;
+  const int hi = blockIdx.x, bi = blockIdx.z;
+  if (blockIdx.y == 0 && bi == 0) zero_pad_rows<D>(out, (unsigned)(h * D), hi, gridDim.z, nq, q_seg, q_base2, q_rows);
   // token-major operands: storage row r of head hi starts at base + r*ld + hi*D, where ld is the
   // row stride in floats (h*D for a dense (b, n, h*d) tensor, 3*h*D for a slice of a fused QKV
   // projection output) and r = tok_row(token, batch)
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   float qf[DH];
   load_half_row<DH>(qf, Q, tok_row(min(q0 + l31, nq - 1), bi, nq, q_seg, q_base2), ldq, half, q0 + l31 < nq);
   const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
-  const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)nk;
+  const unsigned row_base = ((unsigned)((bi * h + hi) * nq + q0 + l31)) * (unsigned)((nk + 1) >> 1);
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 o[NB];
@@ -181,13 +190,17 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
   const int ntiles = (nk + 31) / 32;
   const int tps = (ntiles + key_splits - 1) / key_splits;
   const int t_begin = split * tps, t_end = min(ntiles, t_begin + tps);
-  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+  // Every global operand of a key tile -- K rows, the 16 additive mask values and the 32 V^T operands of
+  // the PV product -- is requested in one batch before the first MFMA, and the scheduler is fenced so that
+  // it cannot sink the loads down to their uses (it did: 8 + 16 + 16 dependent round trips per tile).
+  // The kernel fits TWO waves per SIMD (177 + 32 registers) and that is what hides the load latency and
+  // the softmax VALU work behind the other wave's MFMAs: a one-tile register lookahead (second operand
+  // set, 327 registers, one wave per SIMD) was measured SLOWER at every size (Nk = 80 000: 46.5 vs 52.2
+  // TFLOP/s; 5000: 31.8 vs 37.5; 256: 13.1 vs 11.7 us); a K-only lookahead that keeps two waves per SIMD
+  // changes nothing at full occupancy (53.8 vs 52.1 / 36.9 vs 38.4), and neither does giving every (batch,
+  // head) contiguous 256-byte rows (tools/attn_bench.py --fold: 54.5) -- so DRAM locality is not the limit.
+  auto load_tile = [&](float (&kf)[DH], float (&mk)[16], float (&va)[NB][16], int t) {
     const int key0 = t * 32;
-    // every global operand of this key tile is requested up front -- K rows, the 16 additive mask
-    // values and the 32 V^T operands of the PV product -- and the scheduler is fenced so that it
-    // cannot sink the loads down to their uses again (it did: 8 + 16 + 16 dependent round trips
-    // per tile, the whole kernel was load latency)
-    float kf[DH], mk[16], va[NB][16];
     load_half_row<DH>(kf, K, tok_row(min(key0 + l31, nk - 1), bi, nk, k_seg, k_base2), ldk, half, true);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -197,7 +210,9 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 #pragma unroll
       for (int j = 0; j < NB; ++j) va[j][r] = V[voff + 32 * j];
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute_tile = [&](const float (&kf)[DH], const float (&mk)[16], const float (&va)[NB][16], int t) {
+    const int key0 = t * 32;
     f32x16 st = {0};
 #pragma unroll
     for (int s = 0; s < DH; ++s) st = mfma32(kf[s], qf[s], st);  // S^T[key][q]
@@ -220,8 +235,14 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
     for (int r = 0; r < 16; ++r) {
       p[r] = __expf(p[r] - m_new);
       rs += p[r];  // the normaliser sees every key
-      if (drop.on)  // ... the PV numerator only the kept ones
-        p[r] = at_keep(drop, row_base, key0 + mfma_row(r, half)) ? p[r] * drop.inv_keep : 0.f;
+    }
+    if (drop.on) {  // ... the PV numerator only the kept ones; registers 2i, 2i+1 are keys 2k, 2k+1: one hash
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const unsigned hsh = at_pair_hash(drop, row_base, key0 + mfma_row(r, half));
+        p[r] = (hsh & 0xFFFFu) >= drop.thresh ? p[r] * drop.inv_keep : 0.f;
+        p[r + 1] = (hsh >> 16) >= drop.thresh ? p[r + 1] * drop.inv_keep : 0.f;
+      }
     }
     rs += __shfl_xor(rs, 32);
     l_run = l_run * alpha + rs;
@@ -229,12 +250,18 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_fwd_kernel(
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;   // (skipping this under a uniform "no row raised its maximum" branch was slower: it splits the block)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
 #pragma unroll
       for (int j = 0; j < NB; ++j) o[j] = mfma32(va[j][s], p[s], o[j]);
     }
+  };
+  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+    float kf[DH], mk[16], va[NB][16];
+    load_tile(kf, mk, va, t);
+    __builtin_amdgcn_sched_barrier(0);
+    compute_tile(kf, mk, va, t);
   }
 
   // combine the AT_WAVES partial (m, l, O^T) triples
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(int h, int nq, i
 // dQ: every wave accumulates into its OWN LDS image (plain read-modify-write around the dQ MFMAs,
 // no zero fill: first visit starts from 0) and the images are summed once at the end --
 // ds_add_f32 from four waves onto one image cost 9 us of a 27 us launch (tools/attn_timing.py).
-template <int D>
+template <int D, bool ONEQT>
 __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int k_rows,
     int ldq, int ldk, int ldv, float scale, int tiles_per_split, int nsplits, int qchunk, int atomic_dq,
@@ -361,10 +388,10 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int hi = blockIdx.y, bi = blockIdx.z;
-  const int ksplit = blockIdx.x % nsplits, chunk = blockIdx.x / nsplits;
+  const int hi = blockIdx.x, bi = blockIdx.z;   // heads fastest, see the forward kernel
+  const int ksplit = blockIdx.y % nsplits, chunk = blockIdx.y / nsplits;
   const int qc0 = chunk * qchunk, q_end = min(nq, qc0 + qchunk), nql = q_end - qc0;  // this chunk's queries
-  if (blockIdx.x == 0 && bi == 0) {
+  if (blockIdx.y == 0 && bi == 0) {
     zero_pad_rows<D>(dq, (unsigned)ldq, hi, gridDim.z, nq, q_seg, q_base2, q_rows);
     zero_pad_rows<D>(dk, (unsigned)ldk, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
     zero_pad_rows<D>(dv, (unsigned)ldv, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
@@ -421,6 +448,171 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) dvt[j][r] = dkt[j][r] = 0.f;
 
+  if constexpr (ONEQT) {
+    // ---- one query tile (nq <= 32: the 32 learned queries against any number of scene tokens) ----------
+    // Everything that depends on the queries only -- Q and dO rows for S and dP, their transposed operands
+    // for dK and dV -- is loaded ONCE and stays in registers (the generic loop re-fetches 96 values per
+    // lane per key tile), dQ accumulates in registers across the key tiles (no LDS read-modify-write per
+    // tile), and the K / V rows of the next tile are in flight while the 160 MFMAs of the current one
+    // issue.  One wave per SIMD, ~400 of its 512 registers.  At Nk = 80 000 the generic loop ran at
+    // 40 TFLOP/s with the matrix pipe waiting on two dependent load round trips per tile.
+    const int q0 = qc0;
+    // dO / Q rows of the tile as the transposed operands of dV / dK: one LDS copy for the four waves (row
+    // stride 72 floats: the two half-waves read rows r and r + 4, 4 * 72 = 32 banks apart); in registers
+    // they cost 64 VGPRs and the kernel spilled
+    constexpr int GX_LD = 72;
+    __shared__ float s_g[32][GX_LD], s_x[32][GX_LD];
+    {
+      const int row = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+      const unsigned rr = qrow(min(q0 + row, nq - 1));
+      const bool ok = q0 + row < q_end;
+      static_assert(D == 64, "the one-query-tile path is built for head size 64");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(dO + rr * ostride + c8 + 4 * i);
+        const float4 c = *reinterpret_cast<const float4 *>(Q + rr * (unsigned)ldq + c8 + 4 * i);
+        *reinterpret_cast<float4 *>(&s_g[row][c8 + 4 * i]) = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&s_x[row][c8 + 4 * i]) = ok ? c : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float fr[DH], fdo[DH];
+    {
+      const unsigned my_qrow = qrow(min(q0 + l31, nq - 1));
+      load_half_row<DH>(fr, Q, my_qrow, ldq, half, q0 + l31 < q_end);
+      load_half_row<DH>(fdo, dO, my_qrow, ostride, half, q0 + l31 < q_end);
+    }
+    __syncthreads();
+    f32x16 dqt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqt[j][r] = 0.f;
+    const float *Mz = M ? M : K;  // no mask: the unconditional load reads any valid address and is dropped
+    auto load_kv = [&](float (&kf)[DH], float (&vf)[DH], float &mk, int t) {
+      const unsigned kr = krow_of(min(t * 32 + l31, nk - 1));
+      load_half_row<DH>(kf, K, kr, ldk, half, true);
+      load_half_row<DH>(vf, V, kr, ldv, half, true);
+      mk = Mz[min(t * 32 + l31, nk - 1)];
+    };
+    auto load_kop = [&](float (&kop)[NB][16], int t) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {  // K^T operands of the dQ product
+        const unsigned koff = krow_of(min(t * 32 + mfma_row(s, half), nk - 1)) * (unsigned)ldk + l31;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) kop[j][s] = K[koff + 32 * j];
+      }
+    };
+    auto tile = [&](const float (&kf)[DH], const float (&vf)[DH], float mk_in, const float (&kop)[NB][16], int t) {
+      const int key0 = t * 32;
+      const bool key_ok = key0 + l31 < nk;
+      const float mk = M ? mk_in : 0.f;
+      f32x16 sacc = {0};
+#pragma unroll
+      for (int s = 0; s < DH; ++s) sacc = mfma32(fr[s], kf[s], sacc);  // S[q][key]
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + mfma_row(r, half);
+        const float row_lse = s_lse[min(qq - qc0, AT_NQ_MAX - 1)];   // fully fill-masked rows: see the generic loop
+        const float e = row_lse < -1e8f ? 1.f / (float)nk : __expf(sacc[r] * scale + mk - row_lse);
+        p[r] = (key_ok && qq < q_end) ? e : 0.f;
+      }
+      f32x16 dpacc = {0};
+#pragma unroll
+      for (int s = 0; s < DH; ++s) dpacc = mfma32(fdo[s], vf[s], dpacc);  // dP[q][key]
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = q0 + mfma_row(r, half);
+        float dp = dpacc[r];
+        if (drop.on) {
+          const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)((nk + 1) >> 1);
+          const bool keep = at_keep(drop, row_base, key0 + l31);
+          dp = keep ? dp * drop.inv_keep : 0.f;
+          ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
+          p[r] = keep ? p[r] * drop.inv_keep : 0.f;
+        } else {
+          ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
+        }
+        if (s_lse[min(qq - qc0, AT_NQ_MAX - 1)] < -1e8f) ds[r] = 0.f;
+      }
+      f32x16 dvt1[NB], dkt1[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dvt1[j][r] = dkt1[j][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          dvt1[j] = mfma32(s_g[mfma_row(s, half)][l31 + 32 * j], p[s], dvt1[j]);
+          dkt1[j] = mfma32(s_x[mfma_row(s, half)][l31 + 32 * j], ds[s], dkt1[j]);
+        }
+      }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: the dS tile is transposed through wave-private LDS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_T[wave][l31][mfma_row(r, half)] = ds[r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float bq = s_T[wave][mfma_row(s, half)][l31];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dqt[j] = mfma32(kop[j][s], bq, dqt[j]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (key_ok) {
+        float *dvp = dv + krow_of(key0 + l31) * (unsigned)ldv + hi * D;  // grads mirror the inputs
+        float *dkp = dk + krow_of(key0 + l31) * (unsigned)ldk + hi * D;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = 32 * j + 8 * g4 + 4 * half;
+            const float a4[4] = {dvt1[j][4 * g4], dvt1[j][4 * g4 + 1], dvt1[j][4 * g4 + 2], dvt1[j][4 * g4 + 3]};
+            const float c4[4] = {dkt1[j][4 * g4] * scale, dkt1[j][4 * g4 + 1] * scale, dkt1[j][4 * g4 + 2] * scale,
+                                 dkt1[j][4 * g4 + 3] * scale};
+            if (atomic_dkv) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                unsafeAtomicAdd(dvp + d + i, a4[i]);
+                unsafeAtomicAdd(dkp + d + i, c4[i]);
+              }
+            } else {
+              *reinterpret_cast<float4 *>(dvp + d) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+              *reinterpret_cast<float4 *>(dkp + d) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+            }
+          }
+      }
+    };
+    {
+      float kfA[DH], vfA[DH], mkA, kfB[DH], vfB[DH], mkB, kop[NB][16];
+      // one query tile: qsplit == 1, so a workgroup with fewer than AT_WAVES key tiles leaves waves idle
+      int t = active ? t_begin + slot : t_end;
+      if (t < t_end) load_kv(kfA, vfA, mkA, t);
+      for (; t < t_end; t += 2 * nslots) {
+        const int t1 = t + nslots, t2 = t + 2 * nslots;
+        load_kop(kop, t);
+        load_kv(kfB, vfB, mkB, min(t1, t_end - 1));   // unconditional lookahead (clamped at the tail)
+        __builtin_amdgcn_sched_barrier(0);
+        tile(kfA, vfA, mkA, kop, t);
+        if (t1 < t_end) {
+          load_kop(kop, t1);
+          load_kv(kfA, vfA, mkA, min(t2, t_end - 1));
+          __builtin_amdgcn_sched_barrier(0);
+          tile(kfB, vfB, mkB, kop, t1);
+        }
+      }
+    }
+    // the wave's dQ goes to its LDS image once; the common tail below sums the four images
+    if (active && t_begin + slot < t_end) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_img(wave, l31, 32 * j + mfma_row(r, half)) = dqt[j][r];
+    }
+  } else {
   for (int t = t_begin + slot; active && t < t_end; t += nslots) {
     const int key0 = t * 32;
     const int krow = min(key0 + l31, nk - 1);
@@ -487,7 +679,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
         const int qq = q0 + mfma_row(r, half);
         float dp = dpacc[r];
         if (drop.on) {  // same keep bit as the forward pass: element (b, head, qq, key0 + l31)
-          const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)nk;
+          const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)((nk + 1) >> 1);
           const bool keep = at_keep(drop, row_base, key0 + l31);
           dp = keep ? dp * drop.inv_keep : 0.f;          // d(P_dropped)/dP
           ds[r] = p[r] * (dp - s_D[min(qq - qc0, AT_NQ_MAX - 1)]);
@@ -564,6 +756,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
           }
         }
     }
+  }
   }
   AT_MARK(1, 9);
   if (qsplit > 1) {
@@ -669,24 +862,25 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   if (key_splits > ntiles_fwd) key_splits = ntiles_fwd;
   SIG3D_REQUIRE(key_splits == 1 || workspace != nullptr,
                 "key_splits > 1 needs a workspace of b*h*roundup32(nq)*key_splits*(d+2) floats");
-  dim3 grid(((nq + 31) / 32) * key_splits, h, b);
+  dim3 grid(h, ((nq + 31) / 32) * key_splits, b);
   (void)k_rows;
   const long rows = (long)b * h * nq;
+#define SIG3D_ATT_FWD(DD)                                                                                         \
+  hipLaunchKernelGGL((attention_fwd_kernel<DD>), grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,    \
+                     q_base2, k_base2, q_rows, ldq, ldk, ldv, scale, p_drop, call_id, rng_counter, q, k, v, mask,  \
+                     out, lse, key_splits, workspace)
   if (d == 64) {
-    hipLaunchKernelGGL(attention_fwd_kernel<64>, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
-                       q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
-                       p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
+    SIG3D_ATT_FWD(64);
     if (key_splits > 1)
       hipLaunchKernelGGL(attention_combine_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
                          q_seg, q_base2, key_splits, b, workspace, out, lse);
   } else {
-    hipLaunchKernelGGL(attention_fwd_kernel<96>, grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,
-                       q_base2, k_base2, q_rows, ldq, ldk, ldv, scale,
-                       p_drop, call_id, rng_counter, q, k, v, mask, out, lse, key_splits, workspace);
+    SIG3D_ATT_FWD(96);
     if (key_splits > 1)
       hipLaunchKernelGGL(attention_combine_kernel<96>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, h, nq,
                          q_seg, q_base2, key_splits, b, workspace, out, lse);
   }
+#undef SIG3D_ATT_FWD
   SIG3D_LAUNCH_CHECK("attention_fwd_kernel");
   return 0;
 }
@@ -741,7 +935,7 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
     SIG3D_HIP_TRY(hipMemset2DAsync(dk, sizeof(float) * ldk, 0, sizeof(float) * h * d, krows, stream));
     SIG3D_HIP_TRY(hipMemset2DAsync(dv, sizeof(float) * ldv, 0, sizeof(float) * h * d, krows, stream));
   }
-  dim3 grid(splits * nchunks, h, b);
+  dim3 grid(h, splits * nchunks, b);
   const size_t img = sizeof(float) * AT_WAVES * (size_t)qchunk * (d + 1);
   const size_t red_bytes = sizeof(float) * 2 * (2 * (d / 32) * 16) * 64;  // dK/dV partials of the q-split mode
   const int qsplit_max = (qchunk <= 64 && img + red_bytes <= 136 * 1024) ? 2 : 1;
@@ -749,22 +943,25 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   SIG3D_REQUIRE(lds <= 136 * 1024, "attention backward: LDS budget exceeded");
   static bool attr_done = false;
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<96>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64, true>,   // + 36 KB of static LDS
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<96, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     attr_done = true;
   }
-  if (d == 64)
-    hipLaunchKernelGGL(attention_bwd_kernel<64>, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
-                       q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, tiles_per_split, splits, qchunk,
-                       splits > 1 ? 1 : 0, nchunks > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
-                       out, lse, grad_out, dq, dk, dv);
-  else
-    hipLaunchKernelGGL(attention_bwd_kernel<96>, grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg, k_seg,
-                       q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, tiles_per_split, splits, qchunk,
-                       splits > 1 ? 1 : 0, nchunks > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, k, v, mask,
-                       out, lse, grad_out, dq, dk, dv);
+  // one query tile and whole key tiles per wave: the register-resident path (see the kernel)
+  const bool oneqt = d == 64 && nq <= 32;
+#define SIG3D_ATT_BWD(DD, ONE)                                                                                    \
+  hipLaunchKernelGGL((attention_bwd_kernel<DD, ONE>), grid, dim3(AT_WAVES * 64), lds, stream, h, nq, nk, q_seg,    \
+                     k_seg, q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, tiles_per_split, splits,      \
+                     qchunk, splits > 1 ? 1 : 0, nchunks > 1 ? 1 : 0, qsplit_max, p_drop, call_id, rng_counter, q, \
+                     k, v, mask, out, lse, grad_out, dq, dk, dv)
+  if (d == 64 && oneqt) SIG3D_ATT_BWD(64, true);
+  else if (d == 64) SIG3D_ATT_BWD(64, false);
+  else SIG3D_ATT_BWD(96, false);
+#undef SIG3D_ATT_BWD
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
   return 0;
 }

@@ -17,9 +17,10 @@ def _tm(t):  # (b,h,n,d) -> token-major (b,n,h*d)
     return t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], -1).contiguous()
 
 
-def test_attention_dropout_matches_torch_with_recovered_mask():
+@pytest.mark.parametrize("nq", [40, 32, 20])   # <= 32 queries: the register-resident backward path
+def test_attention_dropout_matches_torch_with_recovered_mask(nq):
     from situation3d_amd.qformer import fused_attention
-    b, h, nq, nk, p = 2, 3, 40, 64, 0.25
+    b, h, nk, p = 2, 3, 64, 0.25
     g = torch.Generator().manual_seed(0)
     q = torch.randn(b, h, nq, 64, generator=g).to(DEV)
     k = torch.randn(b, h, nk, 64, generator=g).to(DEV)

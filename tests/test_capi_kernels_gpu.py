@@ -84,7 +84,8 @@ def _attn_ref(q, k, v, mask, scale):
 @pytest.mark.parametrize("b,h,nq,nk,use_mask", [(2, 12, 32, 256, True), (1, 3, 52, 52, True),
                                                 (2, 2, 32, 5000, False), (1, 1, 5, 33, True),
                                                 (1, 2, 32, 1, False), (1, 2, 100, 77, True),
-                                                (2, 2, 256, 256, True), (1, 2, 300, 48, False), (1, 1, 129, 129, True)])
+                                                (2, 2, 256, 256, True), (1, 2, 300, 48, False), (1, 1, 129, 129, True),
+                                                (1, 2, 20, 700, True), (3, 1, 32, 1000, True), (1, 1, 7, 97, False)])
 @pytest.mark.parametrize("D", [64, 96])
 def test_attention_fwd_bwd(b, h, nq, nk, use_mask, D):
     """Head sizes 64 (Q-Former) and 96 (MCAN blocks); more than 128 query rows run the backward in query

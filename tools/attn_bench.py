@@ -15,6 +15,8 @@ def timeit(fn, iters=10, warm=2):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
 b, h, nq = 4, 12, 32
+if "--fold" in sys.argv:   # heads folded into the batch: every (batch, head) streams CONTIGUOUS 256-byte K / V rows
+    sys.argv.remove("--fold"); b, h = 48, 1
 for nk in [int(a) for a in sys.argv[1:]] or [256, 5000, 20000, 80000]:
     hd = h * 64
     q, go = torch.randn(b, nq, hd, device=dev), torch.randn(b, nq, hd, device=dev)
