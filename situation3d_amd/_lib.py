@@ -98,6 +98,29 @@ class GemmProblem(ctypes.Structure):
 
 SIGNATURES["sig3d_gemm_group"] = [_I, ctypes.POINTER(GemmProblem), _P]
 
+
+def gemm_problem(**kw):
+    """A GemmProblem with tensors given as tensors; m_last / k_last default to m / k."""
+    p = GemmProblem()
+    vals = dict(amode=0, bmode=0, batch=1, m=0, n=0, k=0, m_last=None, k_last=None, A=None, lda=0, stride_a=0,
+                B=None, ldb=0, stride_b=0, C=None, ldc=0, stride_c=0, bias=None, stride_bias=0, act=0, aux=None,
+                accumulate=0, rowsum=None, stride_rowsum=0, tile=0, ksplit=0)
+    vals.update(kw)
+    if vals["m_last"] is None:
+        vals["m_last"] = vals["m"]
+    if vals["k_last"] is None:
+        vals["k_last"] = vals["k"]
+    for name, v in vals.items():
+        setattr(p, name, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    return p
+
+
+def gemm_group(device, *problems):
+    """One launch for up to four independent products (sig3d_gemm_group)."""
+    arr = (GemmProblem * len(problems))(*problems)
+    with torch.cuda.device(device):
+        call("sig3d_gemm_group", len(problems), arr, stream_ptr(device))
+
 INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes")
 
 _lib = None

@@ -37,6 +37,51 @@ def sinusoid_table(n_pos=256, channels=1408 // 3):
     return emb[:, :channels].contiguous()
 
 
+class _LinearRowsFn(torch.autograd.Function):
+    """`t5_proj` (blip2_t5.py:91,128) on the hand-written f32-MFMA GEMM family (csrc/gemm.hip): the forward is ONE
+    launch with the bias in the epilogue, reading the Q-Former's query rows where its last LayerNorm tail left
+    them; the backward is ONE grouped launch for dX = dY W, dW = dY^T X and db (column sums taken from the dY
+    operand while it is staged) -- the library path is an addmm plus two mm, a sum and their transposes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        rows = x.reshape(-1, x.shape[-1])
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        m, k = rows.shape
+        n = weight.shape[0]
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+        _lib.gemm_group(x.device, _lib.gemm_problem(m=m, n=n, k=k, A=rows, lda=k, B=weight, ldb=k, C=out, ldc=n,
+                                                    bias=bias))
+        ctx.save_for_backward(rows, weight)
+        ctx.shape = x.shape
+        return out.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, grad):
+        rows, weight = ctx.saved_tensors
+        m, k = rows.shape
+        n = weight.shape[0]
+        dy = grad.reshape(m, n)
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        dx = torch.empty_like(rows)
+        dw = torch.empty_like(weight)
+        db = torch.empty(n, dtype=torch.float32, device=rows.device)
+        _lib.gemm_group(
+            rows.device,
+            _lib.gemm_problem(amode=0, bmode=1, m=m, n=k, k=n, A=dy, lda=n, B=weight, ldb=k, C=dx, ldc=k),
+            _lib.gemm_problem(amode=1, bmode=1, m=n, n=k, k=m, A=dy, lda=n, B=rows, ldb=k, C=dw, ldc=k, rowsum=db))
+        return dx.view(ctx.shape), dw, db
+
+
+def linear_rows(x, linear):
+    """nn.Linear through _LinearRowsFn when it can run there (CUDA, float32), else the module itself."""
+    if x.is_cuda and x.dtype == torch.float32 and linear.bias is not None:
+        return _LinearRowsFn.apply(x, linear.weight, linear.bias)
+    return linear(x)
+
+
 class _PosEmbedAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, pc, table, scale):
@@ -77,7 +122,7 @@ class Blip2PointQFormer(nn.Module):
         query_tokens = self.query_tokens.expand(pc_embeds.shape[0], -1, -1)
         query_output = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=pc_embeds,
                                          encoder_attention_mask=image_atts, return_dict=True)
-        inputs_t5 = self.t5_proj(query_output.last_hidden_state)
+        inputs_t5 = linear_rows(query_output.last_hidden_state, self.t5_proj)
         atts_t5 = torch.ones(inputs_t5.size()[:-1], dtype=torch.long, device=pc_embeds.device)
         loss = None
         if self.language_head is not None:
