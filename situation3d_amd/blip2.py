@@ -20,6 +20,7 @@ neither vendored nor pinned by the reference (environment.yml), so the layout us
 reading of it, and the table is an ordinary buffer that a checkpoint may overwrite.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -82,6 +83,14 @@ def linear_rows(x, linear):
     return linear(x)
 
 
+# Measured (tools/linear_rows_bench.py, forward + backward, hipGraph-timed): 128 x 768 -> 2048 (B = 4, the t5_proj
+# shape) 110 us on the hand-written family against 31.6 us on the tuned library kernels; 512 rows: 117 vs 70.
+# With 24-64 workgroups and K loops of 768-2048 the hand-written tiles are latency-bound exactly as DESIGN.md 4b
+# found for the Q-Former's own layers, so the module's library path is the default and the single-launch form is
+# opt-in (SIG3D_T5_PROJ_HANDWRITTEN=1; parity-tested either way).
+T5_PROJ_HANDWRITTEN = os.environ.get("SIG3D_T5_PROJ_HANDWRITTEN", "0") == "1"
+
+
 class _PosEmbedAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, pc, table, scale):
@@ -122,7 +131,8 @@ class Blip2PointQFormer(nn.Module):
         query_tokens = self.query_tokens.expand(pc_embeds.shape[0], -1, -1)
         query_output = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=pc_embeds,
                                          encoder_attention_mask=image_atts, return_dict=True)
-        inputs_t5 = linear_rows(query_output.last_hidden_state, self.t5_proj)
+        hidden = query_output.last_hidden_state
+        inputs_t5 = linear_rows(hidden, self.t5_proj) if T5_PROJ_HANDWRITTEN else self.t5_proj(hidden)
         atts_t5 = torch.ones(inputs_t5.size()[:-1], dtype=torch.long, device=pc_embeds.device)
         loss = None
         if self.language_head is not None:
