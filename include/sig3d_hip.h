@@ -500,6 +500,34 @@ int sig3d_query_group_compact(int b, int n, int m, int c, int ld, int nsample, i
                               float radius, const float *xyz, const float *new_xyz, const float *features,
                               const float *features_pm, const int *cidx, const int *centre_of,
                               const int *n_act, float *out, void *stream);
+/* SURVEY.md 8(f) rank 1 -- the first SharedMLP layer of a set-abstraction level WITHOUT the grouped tensor:
+ * replaces QueryAndGroup (pointnet2_utils.py:348-359: grouping_operation x 2, centre subtraction, / radius,
+ * concat) + the first Conv2d of the stack (pytorch_utils.py:11-36, pointnet2_modules.py:242-259).  The MFMA
+ * operand is gathered while it is loaded: c feature channels from the point-major copy features_pm (b, n, c)
+ * at row idx[b][e], 3 channels xyz[idx] - new_xyz[centre] (/ radius when normalize_xyz), in the reference's
+ * channel order for the weight w (cout, 3 + c).  y (b, cout, m*nsample) and the BatchNorm statistics as
+ * sig3d_mlp_layer_fwd.  c must be a multiple of 32 (narrower levels keep the stored tensor: 29 MB at SA1).
+ * Compact lists (csrc/compact.hip): idx = the compact lists, centre_of / n_act / mult as the *_compact calls. */
+int sig3d_mlp_layer0_gather_fwd(int b, int n, int m, int nsample, int c, int cout, int normalize_xyz,
+                                float radius, const float *xyz, const float *new_xyz,
+                                const float *features_pm, const int *idx, const float *w, float *y,
+                                double *stat_sum, double *stat_sq, int accumulate, const int *centre_of,
+                                const int *n_act, const float *mult, void *stream);
+
+/* Backward of the gathering first layer (same operands):
+ *   _gather_dw : dW (cout, 3 + c) [+]= sum_{b,e} dY[b,:,e] X[b,:,e]^T with X gathered on load (dY (b, cout, e));
+ *   _scatter_dx: grad_features_pm (b, n, c) += the feature rows of W^T dY, added at the neighbours' rows in the
+ *                epilogue of the product (wt = W^T, (3 + c, cout); the caller zeroes the target; the xyz rows
+ *                carry no gradient, pointnet2_utils.py:334).  Replaces grouping_operation's backward
+ *                (group_points_gpu.cu:43-75) and the (b, 3 + c, npoint, nsample) gradient tensor. */
+int sig3d_mlp_layer0_gather_dw(int b, int n, int m, int nsample, int c, int cout, int normalize_xyz,
+                               float radius, const float *xyz, const float *new_xyz,
+                               const float *features_pm, const int *idx, const float *dY, float *dW,
+                               int accumulate, const int *centre_of, const int *n_act, void *stream);
+int sig3d_mlp_layer0_scatter_dx(int b, int n, int m, int nsample, int c, int cout, const int *idx,
+                                const float *dY, const float *wt, float *grad_features_pm,
+                                const int *n_act, void *stream);
+
 /* point_major != 0: grad (b,n,ld); else grad (b,c,n); zeroed here */
 int sig3d_query_group_compact_grad(int b, int n, int m, int c, int ld, int nsample, int c_total, int c_off,
                                    const float *grad_out, const int *cidx, const int *n_act, int point_major,

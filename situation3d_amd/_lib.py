@@ -31,6 +31,9 @@ SIGNATURES = {
     "sig3d_compact_neighbour_lists": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_compact": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_compact_grad": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
+    "sig3d_mlp_layer0_gather_fwd": [_I, _I, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
+    "sig3d_mlp_layer0_gather_dw": [_I, _I, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "sig3d_mlp_layer0_scatter_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
     "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],

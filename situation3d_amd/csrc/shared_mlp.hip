@@ -73,12 +73,29 @@ __host__ __device__ inline int ml_kpad(int cin) { return (cin + 2 * ML_KC - 1) /
 // The A operand (one activation value per lane per K-step, a coalesced 128-byte row segment per
 // half-wave) is software-pipelined in chunks of ML_KC steps: the loads of chunk c+1 are in flight
 // while the MFMAs of chunk c issue.
-template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
+// GATHER (first layer of a set-abstraction stack): the activation operand is not a
+// stored (B, 3 + C, npoint, nsample) tensor but is gathered while it is loaded -- position e of batch b is the
+// neighbour idx[b][e]: C feature channels from its row of the POINT-MAJOR feature copy (B, N, C) (16 floats
+// per lane per chunk, four 16-byte loads from one row) and 3 channels xyz[idx] - centre (/ radius), exactly
+// QueryAndGroup's arithmetic (pointnet2_utils.py:348-359, csrc/group_points.hip).  The reduction index is
+// permuted so that those loads are contiguous: LDS weight column c' holds the weight of feature channel c'
+// (column 3 + c' of the layer's weight) for c' < C and of xyz channel c' - C behind them; K-step i of chunk c
+// pairs channels 32c + i and 32c + 16 + i.  Sums are re-associated relative to the stored-tensor kernel
+// (f32, far inside 1e-4); nothing (B, 3 + C, P, S)-shaped is written or read.
+struct MlpGather {
+  const float *xyz, *centre, *feat_pm;
+  const int *idx, *centre_of;   // centre_of: compact lists only (else centre = e / S)
+  int N, P, S, C, normalize;
+  float radius;
+  float *scatter;               // input-gradient use: add the tile into this point-major (B, N, C) gradient
+};
+
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER>
 __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq,
-    const int *__restrict__ n_act, const float *__restrict__ mult) {
+    const int *__restrict__ n_act, const float *__restrict__ mult, MlpGather ga) {
   // Compact mode (n_act given, compact.hip): only the first n_act[b] positions of every row exist -- the
   // distinct neighbours -- and position u stands for mult[b][u] equal columns: the statistics are weighted.
   // E stays the row stride; En is the number of positions.
@@ -106,9 +123,11 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   for (int r0 = wave * 8; r0 < CT; r0 += ML_WAVES * 8) {
     for (int c = lane; c < kpad; c += 64) {
       float v[8];
+      // GATHER: LDS column c <- weight column of the channel that reduction slot c stands for
+      const int wc = GATHER ? (c < ga.C ? c + 3 : min(c - ga.C, 2)) : min(c, cin - 1);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        v[j] = w[(size_t)min(co0 + r0 + j, cout - 1) * cin + min(c, cin - 1)];
+        v[j] = w[(size_t)min(co0 + r0 + j, cout - 1) * cin + wc];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         s_w[(r0 + j) * ldw + c] = (c < cin && co0 + r0 + j < cout) ? v[j] : 0.f;
@@ -153,10 +172,35 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     // one multiply-add per address instead of a 64-bit pair
     const long e = e0_of(t) + l31;
     const unsigned eo = (unsigned)(e < En ? e : En - 1);
+    if constexpr (GATHER) {
+      const size_t pos = (size_t)bi * E + eo;
+      const int gi = ga.idx[pos];
+      if (c * 32 < ga.C) {   // feature chunk (uniform): 16 consecutive channels of the neighbour's row
+        const float4 *p4 = reinterpret_cast<const float4 *>(ga.feat_pm + ((size_t)bi * ga.N + gi) * ga.C + c * 32 + 16 * half);
 #pragma unroll
-    for (int i = 0; i < ML_KC; ++i) {
-      const int k = (c * ML_KC + i) * 2 + half;
-      buf[i] = xb[(unsigned)min(k, cin - 1) * (unsigned)E + eo];
+        for (int q = 0; q < 4; ++q) {
+          const float4 v4 = p4[q];
+          buf[4 * q + 0] = v4.x; buf[4 * q + 1] = v4.y; buf[4 * q + 2] = v4.z; buf[4 * q + 3] = v4.w;
+        }
+      } else {               // the xyz chunk: slots 0..2 of the lower half-wave
+        const int ctr = ga.centre_of ? ga.centre_of[pos] : (int)(eo / (unsigned)ga.S);
+        const float *pt = ga.xyz + ((size_t)bi * ga.N + gi) * 3;
+        const float *cc = ga.centre + ((size_t)bi * ga.P + ctr) * 3;
+#pragma unroll
+        for (int i = 0; i < ML_KC; ++i) buf[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float d = __fsub_rn(pt[j], cc[j]);
+          if (ga.normalize) d = __fdiv_rn(d, ga.radius);
+          buf[j] = half == 0 ? d : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ML_KC; ++i) {
+        const int k = (c * ML_KC + i) * 2 + half;
+        buf[i] = xb[(unsigned)min(k, cin - 1) * (unsigned)E + eo];
+      }
     }
   };
   auto consume = [&](const float (&buf)[ML_KC], int g) {
@@ -177,7 +221,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     if (!ragged) {
 #pragma unroll
       for (int i = 0; i < ML_KC; ++i) {
-        const int k = (c * ML_KC + i) * 2 + half;
+        const int k = GATHER ? c * 32 + 16 * half + i : (c * ML_KC + i) * 2 + half;
         float a = buf[i];
         if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);  // BN(prev) + ReLU on load
         a = (k < cin) ? a : 0.f;
@@ -188,8 +232,8 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     } else {
 #pragma unroll
       for (int i = 0; i < ML_KC; ++i) {
-        if ((c * ML_KC + i) * 2 < cin) {
-          const int k = (c * ML_KC + i) * 2 + half;
+        if (GATHER ? (c * 32 + i < cin) : ((c * ML_KC + i) * 2 < cin)) {
+          const int k = GATHER ? c * 32 + 16 * half + i : (c * ML_KC + i) * 2 + half;
           float a = buf[i];
           if (PROLOGUE) a = fmaxf(0.f, a * s_ps[k] + s_pb[k]);
           a = (k < cin) ? a : 0.f;
@@ -205,6 +249,31 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     // epilogue: acc[nt][4g..4g+3] = positions e0 + 8g + 4*half + (0..3) of channel co0+32nt+l31
     const long e0 = e0_of(t);
     const bool full = e0 + 32 <= En;
+    if (ga.scatter != nullptr) {
+      // Input gradient of a gathering first layer: row co of this product is d(loss)/d(grouped channel co);
+      // channel co >= 3 is feature co - 3 of neighbour idx[e], so the tile is ADDED into the point-major
+      // feature gradient right here (32 lanes = 32 consecutive floats of one row per atomic instruction) and
+      // the (B, 3 + C, P, S) gradient tensor never exists.  The xyz rows (co < 3) carry no gradient
+      // (QueryAndGroup's xyz is not differentiated: pointnet2_utils.py:334).
+      const int *ip = ga.idx + (size_t)bi * E;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        int gi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gi[q] = ip[min(e0 + 8 * g4 + 4 * half + q, En - 1)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = co0 + nt * 32 + l31;
+          if (co >= 3 && co < cout) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (e0 + 8 * g4 + 4 * half + q < En)
+                unsafeAtomicAdd(ga.scatter + ((size_t)bi * ga.N + gi[q]) * ga.C + (co - 3), acc[nt][4 * g4 + q]);
+          }
+        }
+      }
+      return;
+    }
     // (multiplicities are fetched where they are used, compact mode only: a 16-register array here cost the
     // dense NT = 4 instances their third wave per SIMD)
 #pragma unroll
@@ -808,11 +877,15 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_apply_kernel(int c, long 
 // LDS atomics and flushed with one global f32 atomic per element per workgroup.
 constexpr int DW_WAVES = 4;
 
-template <bool PROLOGUE, bool VEC>
+// GATHER: the activation operand of a FIRST layer is gathered on load like in mlp_layer_fwd_kernel<.., GATHER>
+// (the grouped tensor is never stored): lane = input channel ci in the reference's order (0..2 = xyz offset,
+// 3.. = feature ci - 3), so for one position the 32 lanes of a half-wave read 32 consecutive floats of the
+// neighbour's point-major feature row; the 16 neighbour indices of a fragment are the same for every lane.
+template <bool PROLOGUE, bool VEC, bool GATHER>
 __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     int cin, int cout, long E, int steps_per_wave, int nblk_n, const float *__restrict__ dY,
     const float *__restrict__ x, const float *__restrict__ pscale, const float *__restrict__ pshift,
-    float *__restrict__ dW, const int *__restrict__ n_act) {
+    float *__restrict__ dW, const int *__restrict__ n_act, MlpGather ga) {
   // one private image of the 2x2 tile block per wave (plain stores), summed once at the end: four
   // waves doing ds_add_f32 onto ONE image cost ~10 us per workgroup (cf. the attention backward)
   __shared__ float s_tile[DW_WAVES][4][32][33];
@@ -832,7 +905,7 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     aok[t] = co < cout;
     bok[t] = ci < cin;
     arow[t] = dY + ((size_t)bi * cout + (aok[t] ? co : 0)) * E;
-    brow[t] = x + ((size_t)bi * cin + (bok[t] ? ci : 0)) * E;
+    brow[t] = GATHER ? nullptr : x + ((size_t)bi * cin + (bok[t] ? ci : 0)) * E;
     bsc[t] = (PROLOGUE && bok[t]) ? pscale[ci] : 1.f;
     bsh[t] = (PROLOGUE && bok[t]) ? pshift[ci] : 0.f;
   }
@@ -870,13 +943,38 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     (void)ok;
   };
 
+  // gathered B fragments of BOTH channel tiles of a step (they share the 16 neighbour indices)
+  auto load_gather = [&](float (&f0)[16], float (&f1)[16], long e0) {
+    const long eb = e0 + 16 * half;
+    const int *ip = ga.idx + (size_t)bi * E;
+    const int fc0 = max(ci0 + l31 - 3, 0), fc1 = min(ci0 + 32 + l31 - 3, ga.C - 1);   // clamped feature columns
+    const bool xyz_lane = ci0 == 0 && l31 < 3;                                        // tile 0 of block 0 only
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long pos = min(eb + q, En - 1);      // positions past En are zeroed by the tail logic below
+      const int gi = ip[pos];
+      const float *frow = ga.feat_pm + ((size_t)bi * ga.N + gi) * ga.C;
+      float v0 = frow[min(fc0, ga.C - 1)];
+      if (ci0 == 0) {   // uniform: the block that holds the three xyz channels
+        const int ctr = ga.centre_of ? ga.centre_of[(size_t)bi * E + pos] : (int)(pos / ga.S);
+        const int j = min(l31, 2);
+        float d = __fsub_rn(ga.xyz[((size_t)bi * ga.N + gi) * 3 + j], ga.centre[((size_t)bi * ga.P + ctr) * 3 + j]);
+        if (ga.normalize) d = __fdiv_rn(d, ga.radius);
+        v0 = xyz_lane ? d : v0;
+      }
+      f0[q] = v0;
+      if (nj > 1) f1[q] = frow[fc1];
+    }
+  };
+
   float fa[2][2][16], fb[2][2][16];  // [buffer][tile][k]
   if (st_begin < st_end) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (t < ni) load_frag(fa[0][t], arow[t], st_begin * 32, aok[t]);
-      if (t < nj) load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
+      if (!GATHER && t < nj) load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
     }
+    if (GATHER) load_gather(fb[0][0], fb[0][1], st_begin * 32);
   }
   for (long st = st_begin; st < st_end; st += 2) {
 #pragma unroll
@@ -887,10 +985,11 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             if (t < ni) load_frag(fa[ph ^ 1][t], arow[t], (cur + 1) * 32, aok[t]);
-            if (t < nj) load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
+            if (!GATHER && t < nj) load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
           }
+          if (GATHER) load_gather(fb[ph ^ 1][0], fb[ph ^ 1][1], (cur + 1) * 32);
         }
-        const bool tail = (!VEC || n_act != nullptr) && (cur * 32 + 32 > En);
+        const bool tail = (!VEC || n_act != nullptr || GATHER) && (cur * 32 + 32 > En);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           float av[2], bv[2];
@@ -950,16 +1049,18 @@ extern "C" int sig3d_debug_mlp_marks(unsigned long long *host_out, int *n) {
 static thread_local const int *tl_n_act = nullptr;
 static thread_local const float *tl_mult = nullptr;
 
-template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
-static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
-                          const float *pscale, const float *pshift, float *y, double *stat_sum,
-                          double *stat_sq, hipStream_t stream) {
+static thread_local const MlpGather *tl_gather = nullptr;
+
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER>
+static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, const float *w,
+                            const float *pscale, const float *pshift, float *y, double *stat_sum,
+                            double *stat_sq, hipStream_t stream) {
   constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
   const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT + ML_WAVES * 16 * ML_TRLD);
   static bool attr_done = false;  // per template instance
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -977,10 +1078,24 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
   if (gy < 1) gy = 1;
   const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
   dim3 grid(cblocks, (unsigned)gy, b);
-  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED>), grid, dim3(ML_WAVES * 64), lds, stream,
-                     cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq, tl_n_act, tl_mult);
+  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER>), grid, dim3(ML_WAVES * 64), lds, stream,
+                     cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq, tl_n_act, tl_mult,
+                     tl_gather ? *tl_gather : MlpGather{});
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
   return 0;
+}
+
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED>
+static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
+                          const float *pscale, const float *pshift, float *y, double *stat_sum,
+                          double *stat_sq, hipStream_t stream) {
+  if constexpr (!PROLOGUE) {   // the gathering operand load exists for first layers only
+    if (tl_gather != nullptr && tl_gather->scatter == nullptr)
+      return launch_mlp_fwd_g<NT, PROLOGUE, VEC, RAGGED, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum,
+                                                              stat_sq, stream);
+  }
+  return launch_mlp_fwd_g<NT, PROLOGUE, VEC, RAGGED, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum,
+                                                            stat_sq, stream);
 }
 
 template <int NT, bool RAGGED>
@@ -1146,7 +1261,7 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
   return 0;
 }
 
-template <bool PROLOGUE, bool VEC>
+template <bool PROLOGUE, bool VEC, bool GATHER = false>
 static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, const float *x,
                          const float *pscale, const float *pshift, float *dW, hipStream_t stream) {
   const int nblk_m = sig3d_ceil_div(cout, 64), nblk_n = sig3d_ceil_div(cin, 64);
@@ -1159,8 +1274,8 @@ static int launch_mlp_dw(int b, int cin, int cout, long e, const float *dY, cons
   if (spw < 8) spw = 8;
   const long wgs = (n_steps + spw * DW_WAVES - 1) / (spw * DW_WAVES);
   dim3 grid((unsigned)wgs, nblk_m * nblk_n, b);
-  hipLaunchKernelGGL((mlp_dw_kernel<PROLOGUE, VEC>), grid, dim3(DW_WAVES * 64), 0, stream, cin, cout, e,
-                     (int)spw, nblk_n, dY, x, pscale, pshift, dW, tl_n_act);
+  hipLaunchKernelGGL((mlp_dw_kernel<PROLOGUE, VEC, GATHER>), grid, dim3(DW_WAVES * 64), 0, stream, cin, cout, e,
+                     (int)spw, nblk_n, dY, x, pscale, pshift, dW, tl_n_act, GATHER ? *tl_gather : MlpGather{});
   SIG3D_LAUNCH_CHECK("mlp_dw_kernel");
   return 0;
 }
@@ -1174,6 +1289,9 @@ extern "C" int sig3d_mlp_layer_dw(int b, int cin, int cout, long e, const float 
   if (!accumulate) SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
   if (b == 0 || e == 0) return 0;
   const bool vec = (e % 32 == 0);  // every 16-position run is in range and 16-byte aligned
+  if (tl_gather != nullptr && pscale == nullptr)
+    return vec ? launch_mlp_dw<false, true, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
+               : launch_mlp_dw<false, false, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
   if (pscale) return vec ? launch_mlp_dw<true, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
                          : launch_mlp_dw<true, false>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream);
   return vec ? launch_mlp_dw<false, true>(b, cin, cout, e, dY, x, pscale, pshift, dW, stream)
@@ -1191,6 +1309,76 @@ extern "C" int sig3d_mlp_layer_fwd_compact(int b, int cin, int cout, long e, con
   const int rc = sig3d_mlp_layer_fwd(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, accumulate, stream_);
   tl_n_act = nullptr;
   tl_mult = nullptr;
+  return rc;
+}
+
+// First layer of a set-abstraction stack with the grouped operand gathered on load (MlpGather above): same
+// outputs as sig3d_query_group_fused_pm / _compact followed by sig3d_mlp_layer_fwd(_compact) on its result, up
+// to the order of the f32 sums.  cin = 3 + c, c a multiple of 32; idx (b, e) i32 = the ball-query lists (or the
+// compact lists: then centre_of, n_act and -- with statistics -- mult are given as for the *_compact calls).
+extern "C" int sig3d_mlp_layer0_gather_fwd(int b, int n, int m, int nsample, int c, int cout, int normalize_xyz,
+                                           float radius, const float *xyz, const float *new_xyz,
+                                           const float *features_pm, const int *idx, const float *w, float *y,
+                                           double *stat_sum, double *stat_sq, int accumulate, const int *centre_of,
+                                           const int *n_act, const float *mult, void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 0 && cout >= 1, "bad size");
+  SIG3D_REQUIRE(c >= 32 && c % 32 == 0, "the gathering first layer needs a multiple of 32 feature channels");
+  SIG3D_REQUIRE(xyz && new_xyz && features_pm && idx && w && y, "null operand");
+  SIG3D_REQUIRE((centre_of == nullptr) == (n_act == nullptr), "centre_of and n_act come together (compact lists)");
+  SIG3D_REQUIRE(n_act == nullptr || stat_sum == nullptr || mult != nullptr, "statistics over compact lists need mult");
+  MlpGather ga;
+  ga.xyz = xyz; ga.centre = new_xyz; ga.feat_pm = features_pm; ga.idx = idx; ga.centre_of = centre_of;
+  ga.N = n; ga.P = m; ga.S = nsample; ga.C = c; ga.normalize = normalize_xyz; ga.radius = radius;
+  ga.scatter = nullptr;
+  tl_gather = &ga;
+  tl_n_act = n_act;
+  tl_mult = mult;
+  // x is unused by the gathering kernel; pass a valid pointer so that generic checks hold
+  const int rc = sig3d_mlp_layer_fwd(b, c + 3, cout, (long)m * nsample, features_pm, w, nullptr, nullptr, y, stat_sum,
+                                     stat_sq, accumulate, stream_);
+  tl_gather = nullptr;
+  tl_n_act = nullptr;
+  tl_mult = nullptr;
+  return rc;
+}
+
+// Backward of the gathering first layer.  dw: dW (cout, 3 + c) += dY X^T with X gathered on load.
+extern "C" int sig3d_mlp_layer0_gather_dw(int b, int n, int m, int nsample, int c, int cout, int normalize_xyz,
+                                          float radius, const float *xyz, const float *new_xyz,
+                                          const float *features_pm, const int *idx, const float *dY, float *dW,
+                                          int accumulate, const int *centre_of, const int *n_act, void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 0 && cout >= 1 && c >= 1, "bad size");
+  SIG3D_REQUIRE(xyz && new_xyz && features_pm && idx && dY && dW, "null operand");
+  SIG3D_REQUIRE((centre_of == nullptr) == (n_act == nullptr), "centre_of and n_act come together (compact lists)");
+  MlpGather ga;
+  ga.xyz = xyz; ga.centre = new_xyz; ga.feat_pm = features_pm; ga.idx = idx; ga.centre_of = centre_of;
+  ga.N = n; ga.P = m; ga.S = nsample; ga.C = c; ga.normalize = normalize_xyz; ga.radius = radius;
+  ga.scatter = nullptr;
+  tl_gather = &ga;
+  tl_n_act = n_act;
+  const int rc = sig3d_mlp_layer_dw(b, c + 3, cout, (long)m * nsample, dY, features_pm, nullptr, nullptr, dW, accumulate,
+                                    stream_);
+  tl_gather = nullptr;
+  tl_n_act = nullptr;
+  return rc;
+}
+
+// dx: grad_features_pm (b, n, c) += scatter of W^T dY over the neighbour lists (wt = W^T, (3 + c, cout));
+// the caller zeroes grad_features_pm.
+extern "C" int sig3d_mlp_layer0_scatter_dx(int b, int n, int m, int nsample, int c, int cout, const int *idx,
+                                           const float *dY, const float *wt, float *grad_features_pm,
+                                           const int *n_act, void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 0 && cout >= 1 && c >= 1, "bad size");
+  SIG3D_REQUIRE(idx && dY && wt && grad_features_pm, "null operand");
+  MlpGather ga = {};
+  ga.idx = idx; ga.N = n; ga.P = m; ga.S = nsample; ga.C = c; ga.scatter = grad_features_pm;
+  tl_gather = &ga;
+  tl_n_act = n_act;
+  // the product's output rows are the 3 + c grouped channels; y is never written in scatter mode
+  const int rc = sig3d_mlp_layer_fwd(b, cout, c + 3, (long)m * nsample, dY, wt, nullptr, nullptr, grad_features_pm,
+                                     nullptr, nullptr, 0, stream_);
+  tl_gather = nullptr;
+  tl_n_act = nullptr;
   return rc;
 }
 

@@ -231,3 +231,55 @@ def test_compact_sa_level_odd_shapes(npoint, nsample, radius, monkeypatch):
     for a, b_, what in [(o1, o2, "out"), (f1, f2, "dfeat")] + [(x, y, "dparam") for x, y in zip(p1, p2)]:
         err = (a - b_).abs().max().item()
         assert err <= 3e-5 * max(1.0, b_.abs().max().item()), (what, err)
+
+
+@pytest.mark.parametrize("b,n,m,ns,c,cout,normalize", [(2, 500, 64, 32, 128, 128, False), (1, 300, 33, 16, 256, 128, True),
+                                                       (3, 200, 20, 7, 32, 40, False), (2, 1024, 128, 32, 64, 256, True)])
+def test_first_layer_with_the_grouped_operand_gathered_on_load(b, n, m, ns, c, cout, normalize):
+    """sig3d_mlp_layer0_gather_fwd == sig3d_query_group_fused_pm followed by
+    sig3d_mlp_layer_fwd on the stored tensor: raw conv output and BatchNorm sums, dense lists."""
+    import ctypes
+    from situation3d_amd import _lib as L
+    from util import scene
+    g = torch.Generator().manual_seed(b * n + c)
+    xyz = scene(b, n, seed=n + c).to(DEV)
+    new_xyz = xyz[:, :m].contiguous()
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+    feat_pm = torch.randn(b, n, c, generator=g).to(DEV)
+    w = (torch.randn(cout, c + 3, generator=g) * 0.2).to(DEV)
+    radius = 0.7
+    e = m * ns
+    s = L.stream_ptr(torch.device(DEV))
+    grouped = torch.empty(b, c + 3, m, ns, device=DEV)
+    L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, 1, int(normalize), ctypes.c_float(radius), L.ptr(xyz),
+           L.ptr(new_xyz), L.ptr(feat_pm), L.ptr(idx), L.ptr(grouped), s)
+    y_ref = torch.empty(b, cout, e, device=DEV)
+    st_ref = torch.zeros(2, cout, dtype=torch.float64, device=DEV)
+    L.call("sig3d_mlp_layer_fwd", b, c + 3, cout, e, L.ptr(grouped), L.ptr(w), L.ptr(None), L.ptr(None), L.ptr(y_ref),
+           L.ptr(st_ref[0]), L.ptr(st_ref[1]), 0, s)
+    y = torch.full((b, cout, e), 7.0, device=DEV)
+    st = torch.zeros(2, cout, dtype=torch.float64, device=DEV)
+    L.call("sig3d_mlp_layer0_gather_fwd", b, n, m, ns, c, cout, int(normalize), ctypes.c_float(radius), L.ptr(xyz),
+           L.ptr(new_xyz), L.ptr(feat_pm), L.ptr(idx), L.ptr(w), L.ptr(y), L.ptr(st[0]), L.ptr(st[1]), 0, L.ptr(None),
+           L.ptr(None), L.ptr(None), s)
+    exact = torch.einsum("oc,bce->boe", w.double(), grouped.view(b, c + 3, e).double())
+    _close(y_ref, exact.float(), "stored-tensor kernel vs float64")
+    _close(y, exact.float(), "gathering kernel vs float64")
+    _close(st.float(), st_ref.float(), "BatchNorm sums", tol=1e-5)
+    # backward products of the same layer: dW with the operand gathered again, dX scattered in the epilogue
+    dy = torch.randn(b, cout, e, generator=g).to(DEV)
+    dw_ref = torch.zeros(cout, c + 3, device=DEV)
+    L.call("sig3d_mlp_layer_dw", b, c + 3, cout, e, L.ptr(dy), L.ptr(grouped), L.ptr(None), L.ptr(None), L.ptr(dw_ref), 0, s)
+    dw = torch.full((cout, c + 3), 3.0, device=DEV)
+    L.call("sig3d_mlp_layer0_gather_dw", b, n, m, ns, c, cout, int(normalize), ctypes.c_float(radius), L.ptr(xyz),
+           L.ptr(new_xyz), L.ptr(feat_pm), L.ptr(idx), L.ptr(dy), L.ptr(dw), 0, L.ptr(None), L.ptr(None), s)
+    dw_exact = torch.einsum("boe,bce->oc", dy.double(), grouped.view(b, c + 3, e).double())
+    _close(dw_ref, dw_exact.float(), "stored-tensor dW vs float64")
+    _close(dw, dw_exact.float(), "gathering dW vs float64")
+    wt = w.t().contiguous()
+    gpm = torch.zeros(b, n, c, device=DEV)
+    L.call("sig3d_mlp_layer0_scatter_dx", b, n, m, ns, c, cout, L.ptr(idx), L.ptr(dy), L.ptr(wt), L.ptr(gpm), L.ptr(None), s)
+    dx = torch.einsum("co,boe->bce", wt.double(), dy.double())[:, 3:]            # (b, c, e): feature rows only
+    exp = torch.zeros(b, n, c, dtype=torch.float64, device=DEV)
+    exp.scatter_add_(1, idx.view(b, e, 1).long().expand(b, e, c), dx.transpose(1, 2).contiguous())
+    _close(gpm, exp.float(), "scattered input gradient")
