@@ -90,7 +90,7 @@ struct MlpGather {
   float *scatter;               // input-gradient use: add the tile into this point-major (B, N, C) gradient
 };
 
-template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER>
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER>
 __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
@@ -210,6 +210,17 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
     }
+    // SCATTER: the 16 neighbour indices of this lane's accumulator positions are requested before the last
+    // chunk's MFMAs, so that the atomics of the epilogue do not start with a memory round trip per group
+    int sgi[16];
+    if constexpr (SCATTER) {
+      if (c == nchunks - 1) {
+        const int *ip = ga.idx + (size_t)bi * E;
+        const long e0s = e0_of(t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sgi[r] = ip[min(e0s + 8 * (r >> 2) + 4 * half + (r & 3), En - 1)];
+      }
+    }
     // Two bodies.  The common one is branch-free straight-line code (any per-step branch cuts the
     // chunk into basic blocks and exposes the LDS operand latency of every step: +25 % measured).
     // The ragged one -- last K chunk with padding steps (cin = 131 pads to 160, 259 to 288) or a
@@ -249,27 +260,20 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     // epilogue: acc[nt][4g..4g+3] = positions e0 + 8g + 4*half + (0..3) of channel co0+32nt+l31
     const long e0 = e0_of(t);
     const bool full = e0 + 32 <= En;
-    if (ga.scatter != nullptr) {
+    if constexpr (SCATTER) {
       // Input gradient of a gathering first layer: row co of this product is d(loss)/d(grouped channel co);
       // channel co >= 3 is feature co - 3 of neighbour idx[e], so the tile is ADDED into the point-major
       // feature gradient right here (32 lanes = 32 consecutive floats of one row per atomic instruction) and
       // the (B, 3 + C, P, S) gradient tensor never exists.  The xyz rows (co < 3) carry no gradient
       // (QueryAndGroup's xyz is not differentiated: pointnet2_utils.py:334).
-      const int *ip = ga.idx + (size_t)bi * E;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        int gi[4];
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + nt * 32 + l31;
+        if (co >= 3 && co < cout) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gi[q] = ip[min(e0 + 8 * g4 + 4 * half + q, En - 1)];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = co0 + nt * 32 + l31;
-          if (co >= 3 && co < cout) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (e0 + 8 * g4 + 4 * half + q < En)
-                unsafeAtomicAdd(ga.scatter + ((size_t)bi * ga.N + gi[q]) * ga.C + (co - 3), acc[nt][4 * g4 + q]);
-          }
+          for (int r = 0; r < 16; ++r)
+            if (e0 + 8 * (r >> 2) + 4 * half + (r & 3) < En)
+              unsafeAtomicAdd(ga.scatter + ((size_t)bi * ga.N + sgi[r]) * ga.C + (co - 3), acc[nt][r]);
         }
       }
       return;
@@ -943,22 +947,30 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
     (void)ok;
   };
 
-  // gathered B fragments of BOTH channel tiles of a step (they share the 16 neighbour indices)
-  auto load_gather = [&](float (&f0)[16], float (&f1)[16], long e0) {
+  // gathered B fragments of BOTH channel tiles of a step (they share the 16 neighbour indices).  The indices
+  // are loaded ONE STEP BEFORE the gathers that use them (gi: 16 registers, refilled right after the gathers
+  // have been issued): an index load followed at once by its dependent gathers makes every step wait for a
+  // full memory round trip in the middle of its prefetch (in-order vmcnt), 2.3x the stored-tensor kernel.
+  int gi[16];
+  auto load_idx = [&](long e0) {
     const long eb = e0 + 16 * half;
     const int *ip = ga.idx + (size_t)bi * E;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gi[q] = ip[min(eb + q, En - 1)];   // positions past En are zeroed by the tail logic
+  };
+  auto load_gather = [&](float (&f0)[16], float (&f1)[16], long e0) {
+    const long eb = e0 + 16 * half;
     const int fc0 = max(ci0 + l31 - 3, 0), fc1 = min(ci0 + 32 + l31 - 3, ga.C - 1);   // clamped feature columns
     const bool xyz_lane = ci0 == 0 && l31 < 3;                                        // tile 0 of block 0 only
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const long pos = min(eb + q, En - 1);      // positions past En are zeroed by the tail logic below
-      const int gi = ip[pos];
-      const float *frow = ga.feat_pm + ((size_t)bi * ga.N + gi) * ga.C;
+      const long pos = min(eb + q, En - 1);
+      const float *frow = ga.feat_pm + ((size_t)bi * ga.N + gi[q]) * ga.C;
       float v0 = frow[min(fc0, ga.C - 1)];
       if (ci0 == 0) {   // uniform: the block that holds the three xyz channels
         const int ctr = ga.centre_of ? ga.centre_of[(size_t)bi * E + pos] : (int)(pos / ga.S);
         const int j = min(l31, 2);
-        float d = __fsub_rn(ga.xyz[((size_t)bi * ga.N + gi) * 3 + j], ga.centre[((size_t)bi * ga.P + ctr) * 3 + j]);
+        float d = __fsub_rn(ga.xyz[((size_t)bi * ga.N + gi[q]) * 3 + j], ga.centre[((size_t)bi * ga.P + ctr) * 3 + j]);
         if (ga.normalize) d = __fdiv_rn(d, ga.radius);
         v0 = xyz_lane ? d : v0;
       }
@@ -974,7 +986,11 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
       if (t < ni) load_frag(fa[0][t], arow[t], st_begin * 32, aok[t]);
       if (!GATHER && t < nj) load_frag(fb[0][t], brow[t], st_begin * 32, bok[t]);
     }
-    if (GATHER) load_gather(fb[0][0], fb[0][1], st_begin * 32);
+    if (GATHER) {
+      load_idx(st_begin * 32);
+      load_gather(fb[0][0], fb[0][1], st_begin * 32);
+      load_idx(min(st_begin + 1, st_end - 1) * 32);
+    }
   }
   for (long st = st_begin; st < st_end; st += 2) {
 #pragma unroll
@@ -987,7 +1003,10 @@ __global__ __launch_bounds__(DW_WAVES * 64, 2) void mlp_dw_kernel(
             if (t < ni) load_frag(fa[ph ^ 1][t], arow[t], (cur + 1) * 32, aok[t]);
             if (!GATHER && t < nj) load_frag(fb[ph ^ 1][t], brow[t], (cur + 1) * 32, bok[t]);
           }
-          if (GATHER) load_gather(fb[ph ^ 1][0], fb[ph ^ 1][1], (cur + 1) * 32);
+          if (GATHER) {
+            load_gather(fb[ph ^ 1][0], fb[ph ^ 1][1], (cur + 1) * 32);   // indices: loaded during the previous step
+            load_idx(min(cur + 2, st_end - 1) * 32);
+          }
         }
         const bool tail = (!VEC || n_act != nullptr || GATHER) && (cur * 32 + 32 > En);
 #pragma unroll
@@ -1051,7 +1070,7 @@ static thread_local const float *tl_mult = nullptr;
 
 static thread_local const MlpGather *tl_gather = nullptr;
 
-template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER>
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER = false>
 static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, const float *w,
                             const float *pscale, const float *pshift, float *y, double *stat_sum,
                             double *stat_sq, hipStream_t stream) {
@@ -1060,7 +1079,7 @@ static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, co
   const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT + ML_WAVES * 16 * ML_TRLD);
   static bool attr_done = false;  // per template instance
   if (!attr_done) {
-    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER>,
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER, SCATTER>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -1078,7 +1097,7 @@ static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, co
   if (gy < 1) gy = 1;
   const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
   dim3 grid(cblocks, (unsigned)gy, b);
-  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER>), grid, dim3(ML_WAVES * 64), lds, stream,
+  hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER, SCATTER>), grid, dim3(ML_WAVES * 64), lds, stream,
                      cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq, tl_n_act, tl_mult,
                      tl_gather ? *tl_gather : MlpGather{});
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
@@ -1093,6 +1112,9 @@ static int launch_mlp_fwd(int b, int cin, int cout, long e, const float *x, cons
     if (tl_gather != nullptr && tl_gather->scatter == nullptr)
       return launch_mlp_fwd_g<NT, PROLOGUE, VEC, RAGGED, true>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum,
                                                               stat_sq, stream);
+    if (tl_gather != nullptr)
+      return launch_mlp_fwd_g<NT, PROLOGUE, VEC, RAGGED, false, true>(b, cin, cout, e, x, w, pscale, pshift, y,
+                                                                     stat_sum, stat_sq, stream);
   }
   return launch_mlp_fwd_g<NT, PROLOGUE, VEC, RAGGED, false>(b, cin, cout, e, x, w, pscale, pshift, y, stat_sum,
                                                             stat_sq, stream);

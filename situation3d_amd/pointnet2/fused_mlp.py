@@ -162,18 +162,31 @@ class _FusedMLPMax(torch.autograd.Function):
     separate ReLU / threshold / max-reduce / scatter launches."""
 
     @staticmethod
-    def forward(ctx, x, layers, library_gemm, compact, *flat):
+    def forward(ctx, x, layers, library_gemm, compact, gather, *flat):
         # flat = (W_1, gamma_1, beta_1, W_2, gamma_2, beta_2, ...) so that autograd tracks them
         # compact: None, or CompactLists.tensors(): x then holds the DISTINCT neighbours only (first n_act[b]
         # positions of every row) and every kernel below runs in compact mode (csrc/compact.hip)
+        # gather: None, or (xyz, new_xyz, idx, nsample, radius, normalize_xyz): x is then the level's INPUT
+        # features (B, C, N) and the first layer gathers its operand on load (SURVEY.md 8(f) rank 1: no grouped
+        # (B, 3 + C, npoint, nsample) tensor in either direction); idx = ball-query lists, or the compact lists
         dev = x.device
         if compact is not None:
             assert not library_gemm
             c_cidx, c_cent, c_mult, c_seg, c_nact = compact
         x = x.contiguous()
-        b, c0, p, s = x.shape
-        e = p * s
         stream = _lib.stream_ptr(dev)
+        feat_pm = None
+        if gather is not None:
+            assert not library_gemm
+            g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
+            b, c0, n_src = x.shape
+            p = g_new_xyz.shape[1]
+            feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
+        else:
+            b, c0, p, s = x.shape
+        e = p * s
         ys, affs, ws = [], [], []
         cur, ps, pb = x, None, None
         cmax = max(conv.out_channels for conv, _ in layers)
@@ -195,6 +208,14 @@ class _FusedMLPMax(torch.autograd.Function):
                     y = torch.bmm(w.unsqueeze(0).expand(b, cout, cin), act.view(b, cin, e)).view(b, cout, p, s)
                     _lib.call("sig3d_channel_stats", b, cout, e, _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
                               1, stream)
+                elif gather is not None and i == 0:
+                    y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_mlp_layer0_gather_fwd", b, n_src, p, s, c0, cout, int(g_norm),
+                              ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(feat_pm),
+                              _lib.ptr(g_idx), _lib.ptr(w), _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]), 1,
+                              _lib.ptr(c_cent if compact is not None else None),
+                              _lib.ptr(c_nact if compact is not None else None),
+                              _lib.ptr(c_mult if compact is not None else None), stream)
                 elif compact is not None:
                     y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
                     _lib.call("sig3d_mlp_layer_fwd_compact", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w),
@@ -225,8 +246,10 @@ class _FusedMLPMax(torch.autograd.Function):
             else:
                 _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps),
                           _lib.ptr(pb), _lib.ptr(out), _lib.ptr(arg), stream)
-        ctx.save_for_backward(x, arg, *ys, *affs, *ws)
+        # gather mode keeps the point-major feature copy (B, N, C) for the backward pass, not a grouped tensor
+        ctx.save_for_backward(feat_pm if gather is not None else x, arg, *ys, *affs, *ws)
         ctx.compact = compact
+        ctx.gather = gather
         ctx.nl = len(layers)
         ctx.dims = (b, p, s)
         ctx.library_gemm = library_gemm
@@ -248,9 +271,25 @@ class _FusedMLPMax(torch.autograd.Function):
         grads = [None] * (3 * nl)
         grad_x = None
         compact = ctx.compact
+        gather = ctx.gather
         if compact is not None:
             c_cidx, c_cent, c_mult, c_seg, c_nact = compact
+        regroup = None
+        if gather is not None:
+            g_xyz, g_new_xyz, g_idx, _, g_radius, g_norm = gather
+            n_src, c_src = x.shape[1], x.shape[2]          # x is the point-major feature copy here
         with torch.cuda.device(dev):
+            if gather is not None and compact is None:
+                # Dense lists: the backward products of the first layer run FASTER on a stored operand than with
+                # the gather / scatter fused in (SA2 at B = 8, 262 144 positions x 131 channels: weight gradient
+                # 148 us stored vs 319 us gathering, input gradient 243 us (product + merged-run scatter kernel)
+                # vs 521 us with the atomics in the product's epilogue), so the grouped tensor is RE-MATERIALISED
+                # here (30 us) -- recompute-in-backward: it is never kept between the passes.  Compact lists
+                # (a few thousand positions, launch-bound) take the fused kernels.
+                regroup = torch.empty((b, c_src + 3, p, s), dtype=torch.float32, device=dev)
+                _lib.call("sig3d_query_group_fused_pm", b, n_src, p, c_src, c_src, s, 1, int(g_norm),
+                          ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(x),
+                          _lib.ptr(g_idx), _lib.ptr(regroup), stream)
             dA = None
             # one fill each for every BatchNorm-gradient accumulator and every dW of the stack
             cmax = max(w.shape[0] for w in ws)
@@ -281,19 +320,46 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(None), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
                               _lib.ptr(dY), 1, stream)
-                prev = ys[k - 1] if k > 0 else x
+                prev = ys[k - 1] if k > 0 else (regroup if regroup is not None else x)
                 pps = affs[k - 1][0] if k > 0 else None
                 ppb = affs[k - 1][1] if k > 0 else None
                 dW = dw_all[dw_off:dw_off + cout * cin].view(cout, cin)
                 dw_off += cout * cin
-                if compact is not None:
+                if gather is not None and k == 0 and regroup is None:
+                    _lib.call("sig3d_mlp_layer0_gather_dw", b, n_src, p, s, c_src, cout, int(g_norm),
+                              ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(x),
+                              _lib.ptr(g_idx), _lib.ptr(dY), _lib.ptr(dW), 1,
+                              _lib.ptr(c_cent if compact is not None else None),
+                              _lib.ptr(c_nact if compact is not None else None), stream)
+                elif compact is not None:
                     _lib.call("sig3d_mlp_layer_dw_compact", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
                               _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, _lib.ptr(c_nact), stream)
                 else:
                     _lib.call("sig3d_mlp_layer_dw", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
                               _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, stream)
                 grads[3 * k] = dW.view(cout, cin, 1, 1)
-                if k > 0 or ctx.needs_input_grad[0]:
+                if k == 0 and regroup is not None:
+                    if ctx.needs_input_grad[0]:
+                        wt = ws[0].t().contiguous()
+                        dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt), _lib.ptr(None),
+                                  _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None), _lib.ptr(None), 0, stream)
+                        grad_pm = torch.empty((b, n_src, c_src), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_query_group_fused_grad_pm", b, n_src, p, c_src, c_src, s, cin, 3,
+                                  _lib.ptr(dA), _lib.ptr(g_idx), _lib.ptr(grad_pm), stream)
+                        grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
+                elif k == 0 and gather is not None:
+                    if ctx.needs_input_grad[0]:
+                        # W^T dY added straight into the point-major feature gradient at the neighbours' rows
+                        wt = ws[0].t().contiguous()
+                        grad_pm = torch.zeros((b, n_src, c_src), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_mlp_layer0_scatter_dx", b, n_src, p, s, c_src, cout, _lib.ptr(g_idx),
+                                  _lib.ptr(dY), _lib.ptr(wt), _lib.ptr(grad_pm),
+                                  _lib.ptr(c_nact if compact is not None else None), stream)
+                        grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
+                elif k > 0 or ctx.needs_input_grad[0]:
                     if ctx.library_gemm:
                         dA = torch.bmm(ws[k].t().unsqueeze(0).expand(b, cin, cout), dY.view(b, cout, e)).view(b, cin, p, s)
                     else:
@@ -314,26 +380,40 @@ class _FusedMLPMax(torch.autograd.Function):
                 cout = ws[k].shape[0]
                 grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma
                 grads[3 * k + 2] = sums32[k, 0, :cout]         # d beta
-        return (grad_x, None, None, None) + tuple(grads)
+        return (grad_x, None, None, None, None) + tuple(grads)
 
 
-def _fused_mlp_max_eval(layers, x, compact=None):
+def _fused_mlp_max_eval(layers, x, compact=None, gather=None):
     """Inference: BatchNorm2d.eval() is the affine map scale = gamma / sqrt(running_var + eps),
     shift = beta - running_mean * scale, so a layer is one sig3d_mlp_layer_fwd (previous layer's
     BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool.
     compact: CompactLists.tensors() when x holds the distinct neighbours only."""
     dev = x.device
     x = x.contiguous()
-    b, _, p, s = x.shape
-    e = p * s
     stream = _lib.stream_ptr(dev)
+    if gather is not None:   # x: the level's input features (B, C, N); first layer gathers on load
+        g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
+        b, c0, n_src = x.shape
+        p = g_new_xyz.shape[1]
+        feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
+    else:
+        b, _, p, s = x.shape
+    e = p * s
     cur, ps, pb = x, None, None
     with torch.no_grad(), torch.cuda.device(dev):
-        for conv, bn in layers:
+        for li, (conv, bn) in enumerate(layers):
             w = conv.weight.reshape(conv.out_channels, conv.in_channels).contiguous()
             cout, cin = w.shape
             y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
-            if compact is not None:
+            if gather is not None and li == 0:
+                _lib.call("sig3d_mlp_layer0_gather_fwd", b, n_src, p, s, c0, cout, int(g_norm), ctypes.c_float(g_radius),
+                          _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(feat_pm), _lib.ptr(g_idx), _lib.ptr(w),
+                          _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0,
+                          _lib.ptr(compact[1] if compact is not None else None),
+                          _lib.ptr(compact[4] if compact is not None else None), _lib.ptr(None), stream)
+            elif compact is not None:
                 _lib.call("sig3d_mlp_layer_fwd_compact", b, cin, cout, e, _lib.ptr(cur), _lib.ptr(w), _lib.ptr(ps),
                           _lib.ptr(pb), _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0, _lib.ptr(compact[4]),
                           _lib.ptr(None), stream)
@@ -366,7 +446,18 @@ def fused_mlp_max(mlp, x, library_gemm=None):
         flat += [conv.weight, bn.weight, bn.bias]
     if library_gemm is None:
         library_gemm = x.shape[0] * x.shape[2] * x.shape[3] < MIN_POSITIONS
-    return _FusedMLPMax.apply(x, layers, bool(library_gemm), None, *flat)
+    return _FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, *flat)
+
+
+# SIG3D_GATHER_L0=0: always store the grouped tensor (A/B timing; same results up to f32 summation order)
+GATHER_L0 = os.environ.get("SIG3D_GATHER_L0", "1") != "0"
+
+
+def gather_applies(features, use_xyz):
+    """The gathering first layer serves levels with a point-major feature copy: >= 32 channels in multiples of 32
+    (SA2-4: 128 / 256 / 256), xyz concatenated.  SA1 (3 input channels, a 29 MB grouped tensor) keeps the stored form."""
+    return (GATHER_L0 and features is not None and use_xyz and features.dim() == 3 and features.shape[1] >= 32
+            and features.shape[1] % 32 == 0 and features.is_cuda and features.dtype == torch.float32)
 
 
 def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_xyz, normalize_xyz):
@@ -376,14 +467,51 @@ def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_
     layers = _layers(mlp)
     cidx, centre_of, mult, seg_off, n_act = compact.tensors()
     feats = None if features is None else features.contiguous()
-    x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
-                                 float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
+    lists = (cidx, centre_of, mult, seg_off, n_act)
+    gather = None
+    if gather_applies(feats, use_xyz):
+        gather = (xyz.contiguous(), new_xyz.contiguous(), cidx, int(nsample), float(radius), bool(normalize_xyz))
+        x = feats
+    else:
+        x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
+                                     float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, x, (cidx, centre_of, mult, seg_off, n_act))
+        return _fused_mlp_max_eval(layers, x, lists, gather)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _FusedMLPMax.apply(x, layers, False, (cidx, centre_of, mult, seg_off, n_act), *flat)
+    return _FusedMLPMax.apply(x, layers, False, lists, gather, *flat)
+
+
+def dense_gather_applies(mlp, xyz, features, npoint, nsample, use_xyz):
+    """Dense (full-list) levels on the MFMA path whose first layer can gather on load."""
+    if not (gather_applies(features, use_xyz) and xyz.is_cuda and _layers(mlp) is not None):
+        return False
+    if xyz.shape[0] * npoint * nsample < MIN_POSITIONS:
+        return False          # small levels: library-GEMM hybrid on the stored tensor
+    if torch.is_grad_enabled() and xyz.requires_grad:
+        return False
+    if not mlp.training:
+        wants_grad = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in mlp.parameters()))
+        if wants_grad:
+            return False
+    return True
+
+
+def fused_sa_dense(mlp, xyz, new_xyz, features, ball_idx, nsample, radius, normalize_xyz):
+    """One dense set-abstraction level without the grouped tensor: QueryAndGroup + SharedMLP + max-pool
+    (pointnet2_modules.py:242-262) with the first layer gathering its operand from (xyz, features) through the
+    ball-query lists, the weight gradient gathering it again, and the input gradient scattered by the dX product."""
+    layers = _layers(mlp)
+    gather = (xyz.contiguous(), new_xyz.contiguous(), ball_idx.contiguous().view(ball_idx.shape[0], -1), int(nsample),
+              float(radius), bool(normalize_xyz))
+    feats = features.contiguous()
+    if not mlp.training:
+        return _fused_mlp_max_eval(layers, feats, None, gather)
+    flat = []
+    for conv, bn in layers:
+        flat += [conv.weight, bn.weight, bn.bias]
+    return _FusedMLPMax.apply(feats, layers, False, None, gather, *flat)
 
 
 def compact_applies(mlp, xyz, features, npoint, nsample):

@@ -157,9 +157,18 @@ class PointnetSAModuleVotes(nn.Module):
                                                       self.grouper.radius, self.grouper.use_xyz,
                                                       self.grouper.normalize_xyz)
             return new_xyz, new_features, inds
+        # dense MFMA-path levels with a wide feature input: no grouped tensor either (first layer gathers on load)
+        dense_gather = (self.pooling == 'max' and self.npoint is not None and not self.ret_unique_cnt
+                        and not getattr(self.grouper, "sample_uniformly", True)
+                        and fused_mlp.dense_gather_applies(self.mlp_module, xyz, features, self.npoint, self.nsample,
+                                                           self.grouper.use_xyz))
         if geometry is not None:
             inds, new_xyz, ball_idx = geometry[:3]
             assert inds.shape[1] == self.npoint
+            if dense_gather:
+                new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
+                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
         elif compactable:
             if inds is not None:
@@ -172,11 +181,20 @@ class PointnetSAModuleVotes(nn.Module):
                                                           self.nsample, self.grouper.radius, self.grouper.use_xyz,
                                                           self.grouper.normalize_xyz)
                 return new_xyz, new_features, inds
+            if dense_gather:
+                new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
+                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
         else:
             if inds is not None:
                 assert inds.shape[1] == self.npoint
             new_xyz, inds = _sample_centres(xyz, self.npoint, inds)
+            if dense_gather:
+                ball_idx = pointnet2_utils.ball_query(self.grouper.radius, self.nsample, xyz, new_xyz)
+                new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
+                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features)
         if self.ret_unique_cnt:
             grouped_features, grouped_xyz, unique_cnt = grouped

@@ -283,3 +283,65 @@ def test_first_layer_with_the_grouped_operand_gathered_on_load(b, n, m, ns, c, c
     exp = torch.zeros(b, n, c, dtype=torch.float64, device=DEV)
     exp.scatter_add_(1, idx.view(b, e, 1).long().expand(b, e, c), dx.transpose(1, 2).contiguous())
     _close(gpm, exp.float(), "scattered input gradient")
+
+
+@pytest.mark.parametrize("mode", ["dense", "compact", "dense-eval"])
+def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monkeypatch):
+    """PointnetSAModuleVotes on the MFMA path with the first SharedMLP layer gathering its operand on load
+    (fused_mlp.fused_sa_dense / fused_sa_compact) against the same module with the
+    grouped tensor stored (SIG3D_GATHER_L0=0): features out, feature gradient in, every parameter gradient and
+    the BatchNorm running statistics."""
+    from situation3d_amd.pointnet2 import fused_mlp, pointnet2_modules
+    from util import scene
+    b, n, c, npoint, ns = 2, 4096, 128, 1024, 64
+    torch.manual_seed(11)
+    mod = pointnet2_modules.PointnetSAModuleVotes(npoint=npoint, radius=0.9 if mode != "compact" else 0.25, nsample=ns,
+                                                  mlp=[c, 128, 128, 256], use_xyz=True, normalize_xyz=True).to(DEV)
+    ref = copy.deepcopy(mod)
+    if mode == "dense-eval":
+        mod.eval(); ref.eval()
+    xyz = scene(b, n, seed=3).to(DEV)
+    feats = torch.randn(b, c, n, device=DEV)
+    g = torch.randn(b, 256, npoint, device=DEV)
+    monkeypatch.setattr(fused_mlp, "COMPACT", mode == "compact")
+
+    def run(m, gather):
+        monkeypatch.setattr(fused_mlp, "GATHER_L0", gather)
+        f = feats.clone().requires_grad_(mode != "dense-eval")
+        with torch.set_grad_enabled(mode != "dense-eval"):
+            new_xyz, out, inds = m(xyz, f)
+            if mode != "dense-eval":
+                (out * g).sum().backward()
+        return out.detach(), (f.grad if mode != "dense-eval" else None), inds
+
+    calls = []
+    orig = fused_mlp._lib.call
+    monkeypatch.setattr(fused_mlp._lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    out1, gf1, i1 = run(mod, True)
+    assert "sig3d_mlp_layer0_gather_fwd" in calls
+    if mode == "compact":   # no grouped tensor in either direction
+        assert not any(nm.startswith("sig3d_query_group") for nm in calls)
+        assert "sig3d_mlp_layer0_gather_dw" in calls and "sig3d_mlp_layer0_scatter_dx" in calls
+    elif mode == "dense":   # forward without it; the backward re-materialises it (faster than gathering twice more)
+        assert calls.index("sig3d_query_group_fused_pm") > calls.index("sig3d_bn_relu_maxpool")
+    else:
+        assert not any(nm.startswith("sig3d_query_group") for nm in calls)
+    if mode == "compact":
+        assert mod._compact_decision is True
+    calls.clear()
+    out2, gf2, i2 = run(ref, False)
+    assert "sig3d_mlp_layer0_gather_fwd" not in calls and any(nm.startswith("sig3d_query_group") for nm in calls)
+    assert torch.equal(i1, i2)
+    _close(out1, out2, "features")
+    if mode != "dense-eval":
+        # the two forms sum the first layer in different orders: a max-pool winner that leads by one ulp can
+        # change, which moves the gradient of ONE (channel, centre) to another neighbour -- all input channels of
+        # two source points.  Everything else must agree to 1e-4.
+        bad = (gf1 - gf2).abs() > 1e-4 * max(1.0, float(gf2.abs().max())) + 1e-3 * gf2.abs()
+        assert bad.float().mean() < 1e-3, bad.float().mean()
+        assert bad.any(dim=1).sum() <= 8                      # ... confined to a handful of source points
+        for (n1, p1), (_, p2) in zip(mod.named_parameters(), ref.named_parameters()):
+            rel = float((p1.grad - p2.grad).norm() / p2.grad.norm())       # (a changed winner moves single terms)
+            assert rel < 1e-3, (n1, rel)
+        for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
+            _close(b1.float(), b2.float(), n1, tol=1e-5)
