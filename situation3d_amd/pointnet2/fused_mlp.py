@@ -46,7 +46,7 @@ def _layers(mlp):
 # Below this many (batch x npoint x nsample) positions the 1x1 convolutions go to the library GEMM
 # (a few thousand 32-position tiles do not fill the MFMA kernel; measured cross-over on MI355X is
 # between the SA2 (262 144 positions) and SA3 (65 536) shapes); BatchNorm / ReLU / pooling stay fused.
-MIN_POSITIONS = 100000
+MIN_POSITIONS = int(os.environ.get("SIG3D_MLP_MIN_POSITIONS", "100000"))
 
 
 def can_fuse(mlp, x, min_positions=None):
