@@ -209,6 +209,13 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
       if (t >= rj[u] && k != i + u + 1)
         bad |= (t > rj[u]) || mykey < fps_key((unsigned)(i + u + 1), L, bsmask);
     }
+    // a wave that has seen a violation is done: on an input that is NOT FPS-ordered almost every wave leaves
+    // after the first trip (half of all points beat point 1 in round 1), so calling the nested entry point
+    // on arbitrary clouds costs little more than the plain one
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+      if (bad) ok_all[blockIdx.y] = 0;
+      return;
+    }
   }
   for (; i + 1 < m; ++i) {
     const float4 p = *reinterpret_cast<const float4 *>(&s_prefix[4 * i]);

@@ -8,10 +8,15 @@ Host-side behaviour mirrors the reference C++ wrappers: contiguity / dtype / dev
 enqueued on torch's current stream.  There is no CPU implementation in this module by design.
 """
 import ctypes
+import os
 
 import torch
 
 from .. import _lib
+
+
+# SIG3D_NESTED_FPS=0: always run the dependent rounds (A/B timing; results are identical)
+NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
 
 
 def _check_contiguous(t, name):
@@ -66,6 +71,14 @@ def furthest_point_sampling(points, nsamples):
     nsamples = int(nsamples)
     out = torch.zeros((b, nsamples), dtype=torch.int32, device=dev)
     tmp = torch.empty((b, n), dtype=torch.float32, device=dev)
+    if NESTED_FPS and 1 < nsamples <= n <= 8192:
+        # stacked set-abstraction levels sample the FPS-ordered centres of the level above: the nested entry point
+        # proves the answer 0..m-1 instead of running the dependent rounds, and returns exactly what the plain
+        # one returns for ANY input (an unordered cloud fails the proof within its first steps)
+        flags = torch.empty((b,), dtype=torch.int32, device=dev)
+        _run("sig3d_furthest_point_sampling_nested", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
+             _lib.ptr(out), _lib.ptr(flags))
+        return out
     _run("sig3d_furthest_point_sampling", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
          _lib.ptr(out))
     return out
