@@ -274,9 +274,21 @@ extern "C" int sig3d_ball_query(int b, int n, int m, float radius, int nsample,
     return 0;
   }
   const float radius2 = radius * radius;  // ball_query_gpu.cu:22, f32 product on the host
-  dim3 grid(sig3d_ceil_div(m, BQ_WAVES * BQ_CPW), b);
-  hipLaunchKernelGGL((ball_query_scan_kernel<BQ_CPW>), grid, dim3(BQ_WAVES * 64), 0, stream, n, m,
-                     radius2, nsample, new_xyz, xyz, idx);
+  // Centres per wave: 8 amortise the point loads best, but the scan is a chain of n / 64 dependent steps per
+  // wave, and the small levels (SA2-4: 8192 / 4096 / 2048 centres in all) then leave most of the chip idle
+  // behind 1024 / 512 / 256 long-running waves (20 us each for 2 MB of work).  Fewer centres per wave until
+  // there are ~4096 waves: the scene (24 KB at SA2) is cache-resident anyway.
+  const long centres = (long)b * m;
+  const int cpw = centres >= 8L * 4096 ? 8 : centres >= 4L * 4096 ? 4 : centres >= 2L * 4096 ? 2 : 1;
+  dim3 grid(sig3d_ceil_div(m, BQ_WAVES * cpw), b);
+#define SIG3D_BQ_SCAN(CPW)                                                                                  \
+  hipLaunchKernelGGL((ball_query_scan_kernel<CPW>), grid, dim3(BQ_WAVES * 64), 0, stream, n, m, radius2,    \
+                     nsample, new_xyz, xyz, idx)
+  if (cpw == 8) SIG3D_BQ_SCAN(8);
+  else if (cpw == 4) SIG3D_BQ_SCAN(4);
+  else if (cpw == 2) SIG3D_BQ_SCAN(2);
+  else SIG3D_BQ_SCAN(1);
+#undef SIG3D_BQ_SCAN
   SIG3D_LAUNCH_CHECK("ball_query_scan_kernel");
   return 0;
 }
