@@ -430,6 +430,41 @@ def test_graphed_forward_with_prefetched_geometry_matches_inline():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_pipelined_forward_with_several_geometry_chains_in_flight_matches_inline(depth):
+    """serve.PipelinedForward: the geometry chains of the next `depth` batches run on their own streams / graphs
+    while the forward of the current batch replays; outputs equal the inline eval forward bit for bit, through the
+    pipeline prologue, in steady state and when the caller breaks the announced order."""
+    import bench
+    from situation3d_amd import _lib
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.serve import PipelinedForward
+    dev = torch.device(DEV)
+    torch.manual_seed(6)
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64)
+    model = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(dev).eval()
+    batches = []
+    for i in range(5):
+        bt = bench.synthetic_batch(2, 9000, 70 + i, dev)      # 9000 points: the cooperative FPS kernel
+        bt["q_feat"]["input_ids"] = bt["q_feat"]["input_ids"] % 100
+        batches.append(bt)
+    work = torch.cuda.Stream(dev)
+    _lib.fps_timeouts(reset=True)
+    with torch.cuda.stream(work), torch.no_grad():
+        refs = [model(dict(bt))["answer_scores"].clone() for bt in batches]
+        pipe = PipelinedForward(model, batches[0], depth=depth)
+        order = [0, 1, 2, 3, 4, 0, 1, 2, 4, 3, 3, 0, 1]      # ... 2, 4: the announced successor of 2 was 3
+        for k, i in enumerate(order):
+            coming = [order[k + 1 + j] if k + 1 + j < len(order) else (i + 1 + j) % 5 for j in range(depth)]
+            if k == 7:                                       # announce the regular order, then break it at k = 8
+                coming = [(i + 1 + j) % 5 for j in range(depth)]
+            out = pipe(batches[i], [batches[c] for c in coming])
+            assert torch.equal(out["answer_scores"], refs[i]), (depth, k, i)
+    torch.cuda.synchronize()
+    assert _lib.fps_timeouts() == 0
+
+
 def test_prefetched_geometry_is_never_reused_for_a_refilled_buffer():
     """a loader that refills ONE device buffer in place hands the same address over every step.
     The forked geometry branch must not be trusted then (identity = tensor object + version, or explicit

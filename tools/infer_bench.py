@@ -63,5 +63,26 @@ with torch.cuda.stream(work), torch.no_grad():
     p8 = (time.perf_counter() - t0) / 30
 print("forward only, B=8 x %d pts, geometry prefetched one batch ahead: %.2f ms (%.0f samples/s)"
       % (bench.N_POINTS, p8 * 1e3, 8 / p8))
+# two geometry chains in flight (serve.PipelinedForward): the FPS chain of one batch no longer bounds the step
+from situation3d_amd.serve import PipelinedForward
+for bsz in (4, 8):
+    with torch.cuda.stream(work), torch.no_grad():
+        bs = [bench.synthetic_batch(bsz, bench.N_POINTS, 300 + i, dev) for i in range(4)]
+        refs2 = [model(dict(bt))["answer_scores"].clone() for bt in bs]
+        for depth, hp in ((2, True), (3, True), (2, False), (3, False)):
+            pipe = PipelinedForward(model, bs[0], depth=depth, high_priority=hp)
+            for i in range(9):
+                out = pipe(bs[i % 4], [bs[(i + 1 + k) % 4] for k in range(depth)])
+                assert torch.equal(out["answer_scores"], refs2[i % 4]), "pipelined forward differs from the inline one"
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(9, 49):
+                pipe(bs[i % 4], [bs[(i + 1 + k) % 4] for k in range(depth)])
+            torch.cuda.synchronize()
+            pp = (time.perf_counter() - t0) / 40
+            print("forward only, B=%d x %d pts, %d geometry chains in flight (%s-priority streams): %.2f ms (%.0f samples/s)"
+                  % (bsz, bench.N_POINTS, depth, "high" if hp else "normal", pp * 1e3, bsz / pp))
+from situation3d_amd import _lib
+print("cooperative-FPS timeouts over the whole run:", _lib.fps_timeouts())
 print("forward only, B=%d x %d pts: eager %.2f ms (%.0f samples/s), hipGraph %.2f ms (%.0f samples/s)"
       % (B, bench.N_POINTS, eager * 1e3, B / eager, graphed * 1e3, B / graphed))
