@@ -209,16 +209,16 @@ class GraphedTrainStep:
                 and hasattr(model, "encoder") and hasattr(model, "Qformer")):
             from .ddp import GradBucketReducer
             layers = list(model.Qformer.bert.encoder.layer)
-            # SIG3D_QF_CUT=k: also cut the backward after Q-Former layer k (third graph / gather / bucket set), so
-            # that the upper layers' gradients travel under the lower layers' backward.  Costs ~0.3 ms per step
-            # (measured at world size 1: 9.04 -> 9.33 ms) and moves the start of the exchange 1.4 ms forward --
-            # worth it whenever the wire is the longer chain, which it is by far at 2 GPUs (ONE xGMI link between
-            # the pair: ~8 ms for 614 MB) and within the model's error at 4 and 8.
-            # Default: the middle layer when there are peers, no cut alone.
+            # SIG3D_QF_CUT=k (default 0 = off): also cut the backward after Q-Former layer k (third graph / gather /
+            # bucket set), so that the upper layers' gradients travel under the lower layers' backward.  Since the
+            # deferred weight gradients are written straight into the flat gradient buffers (kind-major parameter
+            # order, qformer.parameter_adjacency_groups) the layers above and below a cut INTERLEAVE in storage:
+            # the two bucket sets fall into dozens of small slices, and the cut costs ~1 ms per step at world size
+            # 1 (8.6 -> 9.5 ms) -- more than the 1.4 ms earlier start of the exchange can return even on the
+            # single xGMI link of a 2-GPU run.  Opt-in only.
             cut = 0
             if getattr(model.Qformer.bert, "segmented_layout", False) and len(layers) >= 2:
-                default_cut = len(layers) // 2 if getattr(reducer, "world", 1) > 1 else 0
-                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", str(default_cut))), len(layers) - 1))
+                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", "0")), len(layers) - 1))
             up_mods = layers[cut:] + [model.position_head, model.rotation_head, model.aux_reg, model.answer_cls]
             upper = [p for mod in up_mods for p in mod.parameters() if p.requires_grad]
             up_ids = {id(p) for p in upper}
@@ -252,6 +252,10 @@ class GraphedTrainStep:
                 optimizer._tables(1)   # later gathers' staging buffers: pinned allocation is illegal in capture
                 optimizer._tables(2)
                 self._split = True
+
+        if reducer is not None and fused_opt and hasattr(model, "Qformer"):
+            # deferred weight gradients straight into the flat gradient buffers the reducer owns
+            model.Qformer.bert.encoder.grad_store = optimizer.flat_grad_run
 
         def update():
             if not fused_opt and max_grad_value is not None and max_grad_value > 0:

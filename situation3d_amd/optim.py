@@ -81,6 +81,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._lr_dev = torch.full((1,), self._lr_host, dtype=torch.float32, device=dev)
         self._live = np.zeros(len(self._params), dtype=bool)   # which parameters the last gather saw a gradient for
         self._external = []   # parameters whose flat gradient slot is filled by someone else (see below)
+        self._aliased = {}    # group index -> [(lo, hi)] element ranges of the flat gradients that producers write in place
         self._flat_tables = {}
         self._static = np.array(recs, dtype=_REC)          # 'g' holds the byte offset inside the grad
         self._owners = np.array(owners, dtype=np.int64)
@@ -125,6 +126,7 @@ class FlatAdamW(torch.optim.Optimizer):
             for i, (p, gi, off) in enumerate(self._params):
                 base[i] = self._groups[gi]["g"].data_ptr() + 4 * off
             t["m"] = base[self._owners] + self._static["g"]
+            t["n"] = np.where(t["g"] == t["m"], 0, t["n"])   # the gradient already lives in its flat slot
         # eager: blocking copy (the pinned staging buffer is rewritten next step); inside a hipGraph
         # capture the copy becomes a memcpy node reading the (then static) staging buffer
         table.copy_(host, non_blocking=torch.cuda.is_current_stream_capturing())
@@ -145,9 +147,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_grad_buffers()
         if zero:
             self._live[:] = False
-            for g in self._groups:
-                if g is not None:
-                    g["g"].zero_()  # parameters without a gradient contribute zeros to the all-reduce
+            self._zero_unaliased()  # parameters without a gradient contribute zeros to the all-reduce
         table = self._upload(dst_field_from_flat_g=True, slot=slot)
         with torch.cuda.device(self._dev):
             _lib.call("sig3d_gather_table", len(self._static), _lib.ptr(table),
@@ -155,6 +155,41 @@ class FlatAdamW(torch.optim.Optimizer):
         self._gathered = True
         for p, _, _ in self._params:
             p.grad = None
+
+    def flat_grad_run(self, params):
+        """The slice of a flat gradient buffer that covers exactly `params`, in this order, or None when they do
+        not lie back to back in one group's storage.  A producer that writes the gradients of these parameters
+        straight into the slice (qformer._WeightGradArena) hands autograd views of it as `.grad`; gather_grads()
+        then neither copies nor zeroes the range."""
+        self.flat_grad_buffers()
+        index = {id(p): (gi, off) for p, gi, off in self._params}
+        if not params or any(id(p) not in index for p in params):
+            return None
+        gi, lo = index[id(params[0])]
+        pos = lo
+        for p in params:
+            g2, off = index[id(p)]
+            if g2 != gi or off != pos or p.numel() % 4 != 0:
+                return None
+            pos += p.numel()
+        runs = self._aliased.setdefault(gi, [])
+        if (lo, pos) not in runs:
+            runs.append((lo, pos))
+            runs.sort()
+        return self._groups[gi]["g"][lo:pos]
+
+    def _zero_unaliased(self):
+        """Zero the flat gradient buffers except the ranges their producers overwrite completely every step."""
+        for gi, g in enumerate(self._groups):
+            if g is None:
+                continue
+            pos = 0
+            for lo, hi in self._aliased.get(gi, ()):
+                if lo > pos:
+                    g["g"][pos:lo].zero_()
+                pos = max(pos, hi)
+            if pos < g["total"]:
+                g["g"][pos:].zero_()
 
     def mark_externally_reduced(self, param):
         """`param` gets no .grad from autograd: its slot of the flat gradient buffer is filled from outside

@@ -446,7 +446,7 @@ class _WeightGradArena:
     164-170), so they are ONE GEMM in the forward pass (tokens x [Wk0;Wv0;Wk2;Wv2;...]^T) and their weight /
     input gradients two GEMMs in flush() / the lowest cross-attention block instead of twelve."""
 
-    def __init__(self, layers, batch, tq, tt, part_rows, enc2, num_heads, return_enc_at):
+    def __init__(self, layers, batch, tq, tt, part_rows, enc2, num_heads, return_enc_at, grad_store=None):
         first = layers[0].attention
         wq = first.self.query.weight
         dev, H, I = wq.device, wq.shape[0], layers[0].intermediate_query.dense.weight.shape[0]
@@ -460,9 +460,24 @@ class _WeightGradArena:
         self.x_attn, self.att, self.x_ffn, self.act = e(NL, rows, H), e(NL, L, H), e(NL, rows, H), e(NL, rows, I)
         # operands written by the backward pass
         self.dyo_attn, self.dproj, self.dyo_ffn, self.gpre = e(NL, L, H), e(NL, L, 3 * H), e(NL, rows, H), e(NL, rows, I)
-        # results
-        self.gwqkv, self.gbqkv, self.gwo = e(NL, 3 * H, H), e(NL, 3 * H), e(NL, H, H)
-        self.gw1, self.gb1, self.gw2 = e(NL, 2, I, H), e(NL, 2, I), e(NL, 2, H, I)
+        # results.  grad_store (optim.FlatAdamW.flat_grad_run, data-parallel step): the big ones ARE slices of the
+        # optimizer's flat gradient buffers when the parameters they belong to lie there in this very order
+        # (parameter_adjacency_groups) -- the batched products then write the gradients where the all-reduce
+        # and AdamW read them, and nothing is gathered or zeroed for them
+        def res(params, *shape):
+            v = grad_store(list(params)) if grad_store is not None else None
+            if v is not None and v.numel() == math.prod(shape):
+                return v.view(*shape)
+            return e(*shape)
+
+        sa = [l.attention.self for l in layers]
+        self.gwqkv = res([w for a in sa for w in (a.query.weight, a.key.weight, a.value.weight)], NL, 3 * H, H)
+        self.gbqkv = e(NL, 3 * H)
+        self.gwo = res([l.attention.output.dense.weight for l in layers], NL, H, H)
+        self.gw1 = res([w for l in layers for w in (l.intermediate_query.dense.weight, l.intermediate.dense.weight)],
+                       NL, 2, I, H)
+        self.gb1 = e(NL, 2, I)
+        self.gw2 = res([w for l in layers for w in (l.output_query.dense.weight, l.output.dense.weight)], NL, 2, H, I)
         # LayerNorm-tail parameter gradients [d gamma | d beta | d bias]: per-workgroup partial rows of every
         # tail's backward kernel, folded over all layers at once
         self.ln_blocks_ffn, self.ln_blocks_attn = _ln_bwd_blocks(rows, P), _ln_bwd_blocks(rows)
@@ -475,8 +490,12 @@ class _WeightGradArena:
             self.sa_out, self.att_x = e(nc, rows, H), e(nc, rq, H)
             self.dyo_x, self.dq_x = e(nc, rq, H), e(nc, rq, H)
             self.kv, self.dkv = e(nrow_e, nc * 2 * H), e(nrow_e, nc * 2 * H)
-            self.gwq_x, self.gbq_x, self.gwo_x = e(nc, H, H), e(nc, H), e(nc, H, H)
-            self.gwkv, self.gbkv = e(nc * 2 * H, cenc), e(nc * 2 * H)
+            xs = [layers[i].crossattention for i in self.cross]
+            self.gwq_x = res([x.self.query.weight for x in xs], nc, H, H)
+            self.gbq_x = e(nc, H)
+            self.gwo_x = res([x.output.dense.weight for x in xs], nc, H, H)
+            self.gwkv = res([w for x in xs for w in (x.self.key.weight, x.self.value.weight)], nc * 2 * H, cenc)
+            self.gbkv = e(nc * 2 * H)
             self.ln_work_x, self.ln_x = e(nc, self.ln_blocks_attn, 3 * H), e(nc, 3, H)
             with torch.no_grad():   # [Wk;Wv] of every cross layer stacked: one projection GEMM for all of them
                 ws, bs = [], []
@@ -1197,7 +1216,8 @@ class BertEncoder(nn.Module):
         if encoder_hidden_states is not None:
             enc2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[2])
         arena = _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
-                                 self.layer[0].attention.self.num_attention_heads, ret)
+                                 self.layer[0].attention.self.num_attention_heads, ret,
+                                 grad_store=getattr(self, "grad_store", None))
         if self.flush_on_side_stream:
             dev = hidden_states.device
             if self._side is None or self._side.device != dev:
@@ -1335,21 +1355,44 @@ class BertModel(nn.Module):
 
 
 def parameter_adjacency_groups(module):
-    """Tuples of parameters the hot path wants back to back in memory (in this order), so that
-    [Wq;Wk;Wv] and the (query branch, text branch) pairs of the feed-forward blocks are zero-copy
-    views (_stacked / _pair).  trainer.build_optimizer passes the order on to optim.FlatAdamW; with any
-    other storage the views silently become copies."""
-    groups = []
-    for m in module.modules():
-        if isinstance(m, BertSelfAttention):
-            groups.append((m.query.weight, m.key.weight, m.value.weight))
-            groups.append((m.query.bias, m.key.bias, m.value.bias))
-        elif isinstance(m, BertLayer):
-            iq, it, oq, ot = m.intermediate_query, m.intermediate, m.output_query, m.output
-            groups += [(iq.dense.weight, it.dense.weight), (iq.dense.bias, it.dense.bias),
-                       (oq.dense.weight, ot.dense.weight), (oq.dense.bias, ot.dense.bias),
-                       (oq.LayerNorm.weight, ot.LayerNorm.weight), (oq.LayerNorm.bias, ot.LayerNorm.bias)]
-    return groups
+    """Tuples of parameters the hot path wants back to back in memory (in this order).  Two users:
+      * [Wq;Wk;Wv] of a layer, the (query branch, text branch) pairs of the feed-forward blocks and
+        [Wk0;Wv0;Wk2;Wv2;...] of all cross-attention layers are then zero-copy views (_stacked / _pair);
+      * the groups run over ALL layers of a kind, in layer order, so that the layer-batched result buffers of
+        the deferred weight gradients (_WeightGradArena: (layers, 3H, H), (layers, 2, I, H), ...) can BE slices of
+        a flat gradient buffer with the same layout (optim.FlatAdamW.flat_grad_run): the data-parallel step then
+        neither gathers nor zeroes 600 MB of gradients per step.
+    trainer.build_optimizer passes the order on to optim.FlatAdamW; with any other storage the views silently
+    become copies and the arena keeps buffers of its own."""
+    layers = [m for m in module.modules() if isinstance(m, BertLayer)]
+    if not layers:
+        return []
+    cross = [l for l in layers if l.has_cross_attention]
+    flat = lambda rows: tuple(p for row in rows for p in row if p is not None)   # noqa: E731
+    groups = [
+        flat((l.attention.self.query.weight, l.attention.self.key.weight, l.attention.self.value.weight) for l in layers),
+        flat((l.attention.self.query.bias, l.attention.self.key.bias, l.attention.self.value.bias) for l in layers),
+        flat((l.attention.output.dense.weight,) for l in layers),
+    ]
+    if cross:
+        groups += [
+            flat((l.crossattention.self.key.weight, l.crossattention.self.value.weight) for l in cross),
+            flat((l.crossattention.self.key.bias, l.crossattention.self.value.bias) for l in cross),
+            flat((l.crossattention.self.query.weight,) for l in cross),
+            flat((l.crossattention.self.query.bias,) for l in cross),
+            flat((l.crossattention.output.dense.weight,) for l in cross),
+        ]
+    full = [l for l in layers if l.intermediate is not None and l.output is not None]
+    if len(full) == len(layers):
+        groups += [
+            flat((l.intermediate_query.dense.weight, l.intermediate.dense.weight) for l in layers),
+            flat((l.intermediate_query.dense.bias, l.intermediate.dense.bias) for l in layers),
+            flat((l.output_query.dense.weight, l.output.dense.weight) for l in layers),
+            flat((l.output_query.dense.bias, l.output.dense.bias) for l in layers),
+            flat((l.output_query.LayerNorm.weight, l.output.LayerNorm.weight) for l in layers),
+            flat((l.output_query.LayerNorm.bias, l.output.LayerNorm.bias) for l in layers),
+        ]
+    return [g for g in groups if len(g) > 1]
 
 
 class QFormer(nn.Module):
