@@ -30,8 +30,13 @@ def _single_rank_rehearsal():
     return bool(os.environ.get("SIG3D_SINGLE_RANK_PG")) and dist.is_initialized()
 
 
+# SIG3D_BUCKET_MB: size of one all-reduce (default 64 MiB)
+BUCKET_BYTES = int(os.environ.get("SIG3D_BUCKET_MB", "64")) << 20
+
+
 class GradBucketReducer:
-    def __init__(self, params, process_group=None, bucket_bytes=64 << 20):
+    def __init__(self, params, process_group=None, bucket_bytes=None):
+        bucket_bytes = bucket_bytes or BUCKET_BYTES
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -45,10 +50,11 @@ class GradBucketReducer:
         self._avg = backend == "nccl"  # RCCL has ReduceOp.AVG; gloo needs SUM + scale
 
     @classmethod
-    def from_flat(cls, flat_buffers, process_group=None, bucket_bytes=64 << 20):
+    def from_flat(cls, flat_buffers, process_group=None, bucket_bytes=None):
         """Reducer over gradient storage that is ALREADY flat (optim.FlatAdamW.flat_grad_buffers()):
         buckets are plain slices of those buffers, reduced in place by reduce_all() / finish();
         zeroing is the optimizer's job and there are no per-parameter hooks."""
+        bucket_bytes = bucket_bytes or BUCKET_BYTES
         self = cls.__new__(cls)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1

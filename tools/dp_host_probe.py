@@ -11,11 +11,12 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from situation3d_amd import gemm_tuning  # noqa: E402
-from situation3d_amd.ddp import GradBucketReducer  # noqa: E402
+from situation3d_amd.ddp import GradBucketReducer, init_distributed  # noqa: E402
 from situation3d_amd.graph_step import GraphedTrainStep  # noqa: E402
 from situation3d_amd.model import SIG3DQFormer  # noqa: E402
 from situation3d_amd.trainer import build_optimizer  # noqa: E402
 
+init_distributed()   # SIG3D_SINGLE_RANK_PG=1: a real RCCL group of one
 dev = torch.device("cuda:0")
 gemm_tuning.enable(tune_missing=False)
 torch.manual_seed(1234)
