@@ -18,7 +18,8 @@ def timeit(fn, iters=20, warm=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3  # us
 
-for name, b, chans, p, ns in [("SA1", 8, [6, 64, 64, 128], 2048, 64), ("SA2", 8, [131, 128, 128, 256], 1024, 32)]:
+for name, b, chans, p, ns in [("SA1", 8, [6, 64, 64, 128], 2048, 64), ("SA2", 8, [131, 128, 128, 256], 1024, 32),
+                             ("SA3", 8, [259, 128, 128, 256], 512, 16), ("SA4", 8, [259, 128, 128, 256], 256, 16)]:
     e = p * ns
     x = torch.randn(b, chans[0], e, device=dev)
     for li in range(3):
