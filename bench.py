@@ -1,7 +1,7 @@
 """bench.py -- headline metric of BASELINE.json on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python bench.py --gpus N --steps K --warmup W            (N > 1: spawns its own N ranks, below)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one training pass of the hot path over one synthetic batch:
@@ -10,15 +10,93 @@ point encoder (SA1-4 on 40 000 points / scene) -> situational pose re-encode -> 
 GPU (BASELINE config "SQA3D train step fwd+bwd+Adam, 40k pts, B=8"), weak scaling over ranks
 (one process per GPU, bucketed RCCL all-reduce overlapped with backward).  Inputs are generated
 before the timed region and are resident in HBM.  Prints ONE JSON line on rank 0.
+
+Launching (reference: `python -m torch.distributed.run --nproc_per_node=4 train.py`,
+3DLLM_BLIP2-base/scripts/slurm_3dllm_run.slurm:30): under an external launcher (WORLD_SIZE set) this
+process IS one rank.  Without one, `--gpus N` with N > 1 makes this process a PARENT that starts the N ranks
+as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment),
+relays rank 0's JSON line as its own last line of stdout and exits non-zero when any rank fails.  The
+parent decides that before torch or the HIP library is imported: it never touches a GPU and never
+replaces itself with another program.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the dense-mode and surface-data lines printed beside the headline (N = 1 only)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
+    ap.add_argument("--torch-adamw", action="store_true",
+                    help="torch.optim.AdamW + clip_grad_value_ instead of the fused flat optimizer")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="library GEMMs with the default heuristic instead of the tuned solutions")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="compute FPS/ball-query geometry inline instead of one batch ahead")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(n, argv, script=None):
+    """Parent of a self-launched N-rank run: one child per GPU, same command line (`script`: this file).  Rank 0's stdout is
+    relayed (its JSON line stays the last line), the other ranks' output goes to stderr.
+    Returns the exit code: 0 only when every rank returned 0; the first failure ends the others."""
+    import threading
+    with socket.socket() as sk:       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                                      text=True, bufsize=1, start_new_session=True))
+    lines = []
+    relay = threading.Thread(target=lambda: lines.extend(ln.rstrip("\n") for ln in procs[0].stdout), daemon=True)
+    relay.start()
+    code, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
+                for o in live:        # exactly the process groups started above
+                    try:
+                        os.killpg(procs[o].pid, 15)
+                    except OSError:
+                        pass
+        time.sleep(0.05)
+    relay.join(timeout=10)
+    for ln in lines:
+        print(ln)
+    sys.stdout.flush()
+    return code
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _n = parse_args().gpus
+    if _n > 1:
+        sys.exit(spawn_ranks(_n, sys.argv[1:]))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -322,31 +400,26 @@ def pair_roofline(recs, distinct):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-variants", action="store_true",
-                    help="skip the dense-mode and surface-data lines printed beside the headline (N = 1 only)")
-    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly")
-    ap.add_argument("--torch-adamw", action="store_true",
-                    help="torch.optim.AdamW + clip_grad_value_ instead of the fused flat optimizer")
-    ap.add_argument("--force-reducer", action="store_true",
-                    help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
-    ap.add_argument("--no-gemm-tuning", action="store_true",
-                    help="library GEMMs with the default heuristic instead of the tuned solutions")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="compute FPS/ball-query geometry inline instead of one batch ahead")
-    args = ap.parse_args()
+    args = parse_args()
 
     rank, local, world = init_distributed()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d in the environment (an external launcher must "
+                         "start exactly --gpus ranks; without WORLD_SIZE bench.py starts them itself)"
+                         % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the HIP path has no CPU fallback"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if not args.no_gemm_tuning:
         gemm_tuning.enable(tune_missing=True)  # committed winners; unseen shapes tuned in warm-up
+
+    # ranks that really take part in the collectives: an all-reduce of ones over the process group
+    ranks_seen, backend = 1, None
+    if dist.is_initialized():
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        ranks_seen, backend = int(one.item()), dist.get_backend()
+        assert ranks_seen == dist.get_world_size() == world
 
     # ---- headline: SURVEY.md 8d distribution (volume-uniform points), compact set abstraction where it pays
     head = measure(args, rank, world, device, args.steps, args.warmup)
@@ -386,6 +459,8 @@ def main():
             "value": round(world * BATCH * args.steps / dt, 3),
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # ranks counted by an all-reduce of ones ("nccl" is RCCL on ROCm); 1 / None without a process group
+            "rccl_ranks": ranks_seen, "dist_backend": backend,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

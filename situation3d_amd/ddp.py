@@ -10,10 +10,13 @@ no data parallelism at all (lib/solver.py).  What this does instead, sized for x
     each one is all-reduced asynchronously the moment its last gradient has been accumulated
     (post-accumulate-grad hooks) -- the collective runs on RCCL's stream under the rest of
     backward;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring all-reduce time is
-    ~2*(N-1)/N*S/153 GB/s per bucket, and every collective pays a fixed launch latency, so
-    buckets are LARGE (default 64 MiB; the ~0.4 GB of gradients of the composed model make ~7
-    collectives per step instead of DDP's ~17);
+  * xGMI is point-to-point: 7 links per GPU, ~153 GB/s per link counted in BOTH directions (the
+    figure of the task brief and of AMD's MI355X sheet, 153.6 GB/s peer-to-peer) = 76.8 GB/s per
+    direction per link -- the ONE constant DESIGN.md section 6 prices the wire with.  A ring sends
+    2*(N-1)/N*S bytes out of every rank through one direction of the links it may use
+    (N = 2: one link, S / 76.8 GB/s), and every collective pays a fixed launch latency, so
+    buckets are LARGE (default 64 MiB; the 614 MB of gradients of the composed model make ten
+    collectives per step instead of DDP's ~25);
   * no find_unused_parameters graph walk: parameters that received no gradient keep their
     zero-filled slot and are reduced with their bucket at finish().
 """

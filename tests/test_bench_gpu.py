@@ -47,3 +47,17 @@ def test_data_parallel_path_over_real_rccl_group_of_one():
     ref = _run(["--no-variants"], {})
     # same seeds, same batches, mean over one rank == identity: the loss after 6 steps must agree
     assert abs(out["final_loss"] - ref["final_loss"]) <= 2e-3 * abs(ref["final_loss"])
+
+
+def test_bare_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two ranks itself
+    (reference launch: slurm_3dllm_run.slurm:30).  One-GPU box: both ranks share GPU 0 and the collectives run
+    over gloo -- the same graphs-around-collectives step that RCCL drives on the node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"SIG3D_DIST_BACKEND": "gloo", "SIG3D_SHARE_GPU": "1"})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0

@@ -135,6 +135,49 @@ def test_attention_fwd_bwd(b, h, nq, nk, use_mask, D):
     torch.testing.assert_close(untm(dv.cpu()).double(), v64.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("b,use_mask", [(1, True), (2, False)])
+def test_attention_fwd_bwd_config5_nk80000(b, use_mask):
+    """BASELINE config 5: 12 heads x 32 queries x 80 000 keys -- the key-split forward and the register-resident
+    one-query-tile backward (`attention_bwd_kernel<64, ONEQT>`), against float64 torch (Qformer.py:185-227).
+    Sharpened scores (q x 3) so that the softmax over 80 000 keys is not flat; relative max error, since the
+    outputs of an 80 000-key average are O(1e-2)."""
+    L = _lib()
+    h, nq, nk, D = 12, 32, 80000, 64
+    g = torch.Generator().manual_seed(8000 + b)
+    q = (torch.randn(b, nq, h * D, generator=g) * 3.0).to(DEV)
+    k = torch.randn(b, nk, h * D, generator=g).to(DEV)
+    v = torch.randn(b, nk, h * D, generator=g).to(DEV)
+    go = torch.randn(b, nq, h * D, generator=g).to(DEV)
+    mask = None
+    if use_mask:
+        keep = (torch.rand(b, nk, generator=g) > 0.2).float()
+        keep[:, 0] = 1.0
+        mask = ((1.0 - keep) * -10000.0).to(DEV)
+    scale = 1.0 / math.sqrt(D)
+    ld = h * D
+    out = torch.empty(b, nq, ld, device=DEV)
+    lse = torch.empty(b, h, nq, device=DEV)
+    L.call("sig3d_attention_fwd", b, h, nq, nk, D, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(q), L.ptr(k),
+           L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), ctypes.c_float(0.0), ctypes.c_uint(0),
+           L.ptr(None), 1, L.ptr(None), L.stream_ptr())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    L.call("sig3d_attention_bwd", b, h, nq, nk, D, nq, nk, 0, 0, 0, 0, ld, ld, ld, ctypes.c_float(scale), L.ptr(q), L.ptr(k),
+           L.ptr(v), L.ptr(mask), L.ptr(out), L.ptr(lse), L.ptr(go), L.ptr(dq), L.ptr(dk),
+           L.ptr(dv), ctypes.c_float(0.0), ctypes.c_uint(0), L.ptr(None), L.stream_ptr())
+    # float64 reference on the device (the same statements as _attn_ref; 0.5 GB of scores per batch element)
+    heads = lambda t: t.double().reshape(t.shape[0], t.shape[1], h, D).permute(0, 2, 1, 3)
+    q64, k64, v64 = (heads(t).detach().requires_grad_(True) for t in (q, k, v))
+    ref, ref_lse = _attn_ref(q64, k64, v64, mask, scale)
+    (ref * go.double()).sum().backward()
+    rel = lambda got, want: float((got.double() - want).abs().max() / want.abs().max())
+    untm = lambda t: t.reshape(t.shape[0], t.shape[1], h, D).permute(0, 2, 1, 3)
+    assert rel(out, ref.detach()) < 1e-4                       # north-star fp32 bar; observed ~1e-6
+    assert float((lse.double() - ref_lse.detach()).abs().max()) < 1e-4
+    assert rel(untm(dq), q64.grad) < 1e-4
+    assert rel(untm(dk), k64.grad) < 1e-4
+    assert rel(untm(dv), v64.grad) < 1e-4
+
+
 def _to_segments(t, seg, base2=None, rows=None, fill=0.0):
     """(b, n, c) plain token order -> two-segment row matrix (include/sig3d_hip.h); with base2 / rows
     the segments are padded (rows without a token hold `fill`)."""

@@ -156,6 +156,32 @@ def test_config5_blip2_reference_shape_nk5000_forward_backward_matches_oracle():
     assert n >= 6 * 5
 
 
+def test_config5_blip2_shape_nk80000_forward_backward_matches_oracle():
+    """BASELINE config 5's token count in BOTH directions (the largest tested backward was Nk = 5000):
+    B = 1, Nk = 80 000 point tokens of width 1408 -- the backward takes the register-resident one-query-tile
+    attention kernel (`attention_bwd_kernel<64, ONEQT>`, Qformer.py:185-227) and the K = 80 000 weight-gradient
+    products of the six cross-attention key / value projections."""
+    model, samples, reference = _blip2(80000, 1, seed=53)
+    G = torch.randn(1, 32, 2048, generator=torch.Generator().manual_seed(6))
+    feat, hidden, t5 = reference(True)
+    (t5 * G).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    gpu = copy.deepcopy(model).to(DEV)
+    gpu.zero_grad(set_to_none=True)
+    f = samples["pc_feat"].to(DEV).requires_grad_(True)
+    out = gpu({"pc_feat": f, "pc": samples["pc"].to(DEV)})
+    (out["inputs_t5"] * G.to(DEV)).sum().backward()
+    assert _rel(out["inputs_t5"].detach().cpu(), t5.detach()) < 1e-4      # north-star fp32 bar
+    assert _rel(f.grad.cpu(), feat.grad) < 1e-3
+    n = 0
+    for name, p in gpu.named_parameters():
+        if ("crossattention.self" in name or name in ("query_tokens", "t5_proj.weight")) and not _is_key_bias(name):
+            r = _rel(p.grad.cpu(), ref_grads[name])
+            assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
+            n += 1
+    assert n >= 6 * 5
+
+
 def test_full_size_qformer_forward_backward_matches_oracle():
     """768 wide / 12 layers / 12 heads / 6 cross-attention layers, B = 8, 32 queries + 20 question tokens,
     256 scene tokens of width 256: the Q-Former the bench times, two-segment layout, against qformer_ref --
