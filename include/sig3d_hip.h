@@ -399,7 +399,9 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  *          pre-activation acc + bias;  2 C = (acc + bias) * gelu_erf'(aux)  (BertIntermediate backward).
  * accumulate != 0: C += result (the caller's C holds the addend, e.g. the residual path's gradient).
  * rowsum : (m) or NULL; amode 1 only: rowsum[i] = sum_l A(i,l) -- the bias gradient of a dW product,
- *          taken from the A operand while it is staged.
+ *          taken from the A operand while it is staged.  With ksplit == 1 it is OVERWRITTEN; with a split K
+ *          (ksplit > 1, which also requires accumulate != 0) the K slices ADD their partial sums with float
+ *          atomics, so the CALLER MUST ZERO rowsum before the launch -- exactly as it initialises C.
  * tile   : 0 = choose; 1..4 = workgroup tile 64x64 / 32x128 / 64x128 / 128x64 (rows x columns of C).
  * ksplit : 0 = choose; s > 1 splits K over s workgroups per tile which meet through float atomics on C --
  *          only with act == 0 and accumulate != 0 (C initialised by the caller), else it is forced to 1. */

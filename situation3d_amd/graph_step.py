@@ -238,7 +238,8 @@ class GraphedTrainStep:
                 if table is not None:
                     from .ddp import SparseRowExchange
                     self._emb_sink = SparseRowExchange(q["input_ids"].numel(), table.shape[1], table.device,
-                                                       process_group=reducer.group)
+                                                       process_group=reducer.group,
+                                                       padding_idx=emb.word_embeddings.padding_idx)
                     emb.row_grad_sink = self._emb_sink
                     gi, lo, hi, self._emb_grad = optimizer.mark_externally_reduced(table)
                     self._emb_range = (gi, lo, hi)

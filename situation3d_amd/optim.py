@@ -20,7 +20,9 @@ The learning rate lives in a device scalar the kernels read when they EXECUTE: a
 mutates `param_groups[*]["lr"]` (lib/solver.py:239-247) is honoured by captured hipGraph replays too --
 `sync_lr()` (called by step() and by graph_step.GraphedTrainStep before every replay) refreshes it.
 `state_dict()` / `load_state_dict()` speak torch.optim.AdamW's layout (per-parameter `step`, `exp_avg`,
-`exp_avg_sq`), so the reference's checkpoints (lib/solver.py:652-660, train.py:256-262) round-trip.
+`exp_avg_sq`, indexed by position in `param_groups[*]["params"]` = the caller's `named_parameters()` order;
+the flat STORAGE order is a separate argument), so the reference's checkpoints (lib/solver.py:652-660,
+train.py:256-262) round-trip in both directions.
 """
 import ctypes
 
@@ -36,7 +38,11 @@ _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8")
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 clip_value=0.0):
+                 clip_value=0.0, storage_order=None):
+        """storage_order: optional, one list per parameter group -- the SAME trainable parameters in the order
+        they are to lie in the flat buffers (trainer.build_optimizer keeps operands the Q-Former stacks into one
+        GEMM adjacent).  `param_groups[*]["params"]` -- the order state_dict() / load_state_dict() index by, like
+        torch.optim -- stays the caller's order, so checkpoints are independent of the storage layout."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.clip_value = float(clip_value)
@@ -44,8 +50,15 @@ class FlatAdamW(torch.optim.Optimizer):
         dev = None
         recs, owners = [], []   # static part of the chunk table; owners[i] = index into self._params
         self._params = []
+        if storage_order is not None and len(storage_order) != len(self.param_groups):
+            raise ValueError("storage_order needs one list per parameter group")
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
+            if storage_order is not None:
+                layout = [p for p in storage_order[gi] if p.requires_grad]
+                if len(layout) != len(ps) or {id(p) for p in layout} != {id(p) for p in ps}:
+                    raise ValueError("storage_order[%d] is not a permutation of the group's parameters" % gi)
+                ps = layout
             if gi > 0 and (group["lr"], group["betas"], group["eps"]) != \
                     (self.param_groups[0]["lr"], self.param_groups[0]["betas"], self.param_groups[0]["eps"]):
                 raise RuntimeError("FlatAdamW: groups may differ in weight_decay only")
@@ -115,7 +128,7 @@ class FlatAdamW(torch.optim.Optimizer):
             gptr[i] = g.data_ptr()
             live[i] = True
         if dst_field_from_flat_g:
-            self._live |= live
+            self._live |= self._agree_on_liveness(live)
             self._live[self._external] = True
         host, t, table = self._tables(slot)
         t[:] = self._static
@@ -131,6 +144,21 @@ class FlatAdamW(torch.optim.Optimizer):
         # capture the copy becomes a memcpy node reading the (then static) staging buffer
         table.copy_(host, non_blocking=torch.cuda.is_current_stream_capturing())
         return table
+
+    def _agree_on_liveness(self, live):
+        """Data parallel: the gradients are averaged over ranks, so WHICH parameters get an AdamW record must be
+        the same everywhere -- a parameter is live when ANY rank produced a gradient for it (torch DDP with
+        find_unused_parameters treats one as unused only when it is unused on all ranks; runner_base.py:91-93).
+        One small MAX all-reduce in the eager data-parallel step (where the set can depend on the data); a captured
+        step has one static launch structure on every rank and skips it."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
+                or torch.cuda.is_current_stream_capturing():
+            return live
+        dev = self._dev if dist.get_backend() == "nccl" else "cpu"
+        mask = torch.from_numpy(live.astype(np.uint8)).to(dev)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+        return mask.cpu().numpy().astype(bool)
 
     # ---- public ----------------------------------------------------------------------------------
     def flat_grad_buffers(self):
@@ -319,7 +347,13 @@ class FlatAdamW(torch.optim.Optimizer):
         host.numpy().view(_REC)[:len(recs)] = arr
         table = torch.empty(host.numel(), dtype=torch.uint8, device=self._dev)
         table.copy_(host, non_blocking=torch.cuda.is_current_stream_capturing())
-        self._flat_tables[key] = (table, len(recs), host)   # the staging buffer stays alive (memcpy node)
+        if len(self._flat_tables) >= 64 and not torch.cuda.is_current_stream_capturing():
+            # liveness that varies from step to step (eager, data-dependent graphs) must not grow the cache without
+            # bound; tables referenced by a captured graph are only ever created during a capture and are kept
+            for k in [k for k, v in self._flat_tables.items() if not v[3]][:32]:
+                del self._flat_tables[k]
+        # the staging buffer stays alive (memcpy node); [3]: created inside a capture
+        self._flat_tables[key] = (table, len(recs), host, torch.cuda.is_current_stream_capturing())
         return table, len(recs)
 
     def _adamw_ranges(self, ranges, stream):
@@ -452,6 +486,11 @@ class FlatAdamW(torch.optim.Optimizer):
             if st is None or id(p) not in views:
                 continue
             m, v = views[id(p)]
+            for key in ("exp_avg", "exp_avg_sq"):   # copy_ would broadcast a (768,) state into a (768, 768) slot
+                if tuple(st[key].shape) != tuple(p.shape):
+                    raise ValueError("state %d: %s has shape %s, the parameter at that position %s -- the loaded "
+                                     "state dict orders its parameters differently"
+                                     % (i, key, tuple(st[key].shape), tuple(p.shape)))
             m.copy_(st["exp_avg"])
             v.copy_(st["exp_avg_sq"])
             steps.add(float(st["step"]))

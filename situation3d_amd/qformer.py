@@ -25,6 +25,7 @@ torch's Philox (same distribution, different bits); eval mode is deterministic.
 """
 import ctypes
 import math
+import weakref
 import os
 from types import SimpleNamespace
 
@@ -509,6 +510,12 @@ class _WeightGradArena:
         # above them (the lowest one; with a split backward pass also the lowest one of the upper piece)
         self.return_enc_at = sorted(set(return_enc_at) & set(self.cross), reverse=True) if nc else []
         self._enc_done_hi = nc          # cross ordinals >= this have had their dkv folded into a returned g_enc
+        self._layers = list(layers)
+        # shared: another grad-enabled forward ran while this arena was waiting for its backward pass (two forwards
+        # before one backward).  The views handed to autograd may then be accumulated into, cloned or joined by
+        # other contributions, so the result buffers were zero-filled (BertEncoder.forward) and flush() ADDS the
+        # products to whatever `.grad` has become instead of assuming it owns it.
+        self.shared = False
         self._marks = set()
         self._expected = 2 * NL + nc
         self._flushed_hi = NL           # layers >= this are flushed
@@ -535,6 +542,75 @@ class _WeightGradArena:
         H2 = 2 * self.H
         return self.dkv[:, j0 * H2:j1 * H2].mm(self.wkv_all[j0 * H2:j1 * H2])
 
+    # ---- which parameter gets which view (mirrors what the block functions return) --------------------------
+    _RESULTS = ("gwqkv", "gbqkv", "gwo", "gw1", "gb1", "gw2", "ln_ffn", "ln_attn",
+                "gwq_x", "gbq_x", "gwo_x", "gwkv", "gbkv", "ln_x")
+
+    def result_buffers(self):
+        return [getattr(self, k) for k in self._RESULTS if hasattr(self, k)]
+
+    def param_views(self, lo, hi):
+        """[(parameter, view of its deferred gradient)] for layers [lo, hi)."""
+        H = self.H
+        out = []
+        for l in range(lo, hi):
+            layer = self._layers[l]
+            sa, so = layer.attention.self, layer.attention.output
+            gw, gb, ln = self.gwqkv[l], self.gbqkv[l], self.ln_attn[l]
+            out += [(sa.query.weight, gw[:H]), (sa.query.bias, gb[:H]), (sa.key.weight, gw[H:2 * H]),
+                    (sa.key.bias, gb[H:2 * H]), (sa.value.weight, gw[2 * H:]), (sa.value.bias, gb[2 * H:]),
+                    (so.dense.weight, self.gwo[l]), (so.dense.bias, ln[2]), (so.LayerNorm.weight, ln[0]),
+                    (so.LayerNorm.bias, ln[1])]
+            out += [(layer.intermediate_query.dense.weight, self.gw1[l, 0]), (layer.intermediate_query.dense.bias, self.gb1[l, 0]),
+                    (layer.intermediate.dense.weight, self.gw1[l, 1]), (layer.intermediate.dense.bias, self.gb1[l, 1]),
+                    (layer.output_query.dense.weight, self.gw2[l, 0]), (layer.output.dense.weight, self.gw2[l, 1])]
+            for part, mod in ((0, layer.output_query), (1, layer.output)):
+                lf = self.ln_ffn[l, part]
+                out += [(mod.dense.bias, lf[2]), (mod.LayerNorm.weight, lf[0]), (mod.LayerNorm.bias, lf[1])]
+            if l in self.cross_ord:
+                j = self.cross_ord[l]
+                xa, xo = layer.crossattention.self, layer.crossattention.output
+                r0, lx = j * 2 * H, self.ln_x[j]
+                out += [(xa.query.weight, self.gwq_x[j]), (xa.query.bias, self.gbq_x[j]),
+                        (xa.key.weight, self.gwkv[r0:r0 + H]), (xa.key.bias, self.gbkv[r0:r0 + H]),
+                        (xa.value.weight, self.gwkv[r0 + H:r0 + 2 * H]), (xa.value.bias, self.gbkv[r0 + H:r0 + 2 * H]),
+                        (xo.dense.weight, self.gwo_x[j]), (xo.dense.bias, lx[2]), (xo.LayerNorm.weight, lx[0]),
+                        (xo.LayerNorm.bias, lx[1])]
+        return out
+
+    def _check_adopted(self, lo, hi):
+        """The deferred scheme is only right when autograd ADOPTED the (then unfilled) views as `.grad`.  A clone
+        (create_graph, tensor hooks, a shared reference) or an in-place accumulation into an older gradient has
+        copied / added unfilled memory: nothing can repair that afterwards, so fail loudly.  Host-side pointer
+        compares only; inside a hipGraph capture this runs once, at capture time."""
+        for prm, view in self.param_views(lo, hi):
+            g = prm.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                raise RuntimeError(
+                    "deferred Q-Former weight gradients: autograd did not adopt the gradient view of a %s parameter "
+                    "(another gradient contribution, create_graph or a tensor hook).  Set SIG3D_QF_DEFER=0 / "
+                    "encoder.defer_weight_grads = False for this pattern." % (tuple(prm.shape),))
+
+    def _products_shared(self, lo, hi):
+        """flush() of a shared arena: products into temporaries, then ADDED to whatever each `.grad` is by now --
+        the adopted view (zero-filled + anything accumulated into it in place), an older gradient the zeros were
+        added to, or a clone of the zeros."""
+        real = {k: getattr(self, k) for k in self._RESULTS if hasattr(self, k)}
+        views = self.param_views(lo, hi)
+        try:
+            for k, t in real.items():
+                setattr(self, k, torch.empty_like(t))
+            self._products(lo, hi)
+            temps = self.param_views(lo, hi)
+        finally:
+            for k, t in real.items():
+                setattr(self, k, t)
+        with torch.no_grad():
+            for (prm, view), (_, tmp) in zip(views, temps):
+                if prm.grad is None:
+                    continue               # this backward pass did not accumulate into the parameter
+                prm.grad.add_(tmp)         # the view itself when it was adopted
+
     # ---- the deferred products -------------------------------------------------------------------------
     def flush(self):
         """Weight / bias gradients of every layer whose blocks have all run their backward and that is not
@@ -551,6 +627,10 @@ class _WeightGradArena:
         if hi - lo <= 0:
             return
         self._flushed_hi = lo
+        if self.shared:
+            self._products_shared(lo, hi)
+            return
+        self._check_adopted(lo, hi)
         side = self.side_stream
         if side is None:
             self._products(lo, hi)
@@ -898,8 +978,13 @@ class BertEmbeddings(nn.Module):
                 :, past_key_values_length: seq_length + past_key_values_length].clone()
         if input_ids is not None:
             sink = getattr(self, "row_grad_sink", None)
-            if sink is not None and torch.is_grad_enabled() and sink.ids.numel() == input_ids.numel():
-                # data parallel: the table's gradient travels as rows (ddp.SparseRowExchange)
+            if sink is not None and torch.is_grad_enabled():
+                # data parallel: the table's gradient travels as rows (ddp.SparseRowExchange).  The sink is sized
+                # for one batch shape; the table's dense gradient has no bucket any more, so a differently sized
+                # batch must not fall back silently
+                if sink.ids.numel() != input_ids.numel():
+                    raise RuntimeError("word-embedding row exchange was set up for %d token positions per step, "
+                                       "this batch has %d" % (sink.ids.numel(), input_ids.numel()))
                 from .ddp import embedding_rows
                 embeddings = embedding_rows(self.word_embeddings.weight, input_ids, sink)
             else:
@@ -1194,7 +1279,17 @@ class BertEncoder(nn.Module):
         # opt-in: measured SLOWER on MI355X (9.27 vs 8.99 ms per step): the batched GEMMs fill every CU, the point
         # encoder's backward kernels beside them (and the FPS branch) only get in each other's way
         self.flush_on_side_stream = os.environ.get("SIG3D_QF_FLUSH_STREAM", "0") != "0"
-        self._arena, self._side = None, None
+        self._arena_ref, self._side = None, None
+
+    # The arena of the last grad-enabled forward, held WEAKLY: the autograd graph (every block's ctx) owns it, so an
+    # abandoned forward's arena dies with its outputs and never counts as pending.
+    @property
+    def _arena(self):
+        return self._arena_ref() if self._arena_ref is not None else None
+
+    @_arena.setter
+    def _arena(self, arena):
+        self._arena_ref = weakref.ref(arena) if arena is not None else None
 
     def _make_arena(self, hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut):
         if not (self.defer_weight_grads and torch.is_grad_enabled() and hidden_states.is_cuda):
@@ -1202,7 +1297,8 @@ class BertEncoder(nn.Module):
         if encoder_hidden_states is not None and encoder_hidden_states.dim() != 3:
             return None
         for p in self.parameters():
-            if not p.requires_grad or p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None):
+            if not p.requires_grad or p.grad is not None or getattr(p, "_post_accumulate_grad_hooks", None) \
+                    or getattr(p, "_backward_hooks", None):
                 return None
         for layer in self.layer:   # stripped text branch (Blip2T5) or no scene tokens for a cross layer
             if layer.intermediate is None or (layer.has_cross_attention and encoder_hidden_states is None):
@@ -1229,10 +1325,11 @@ class BertEncoder(nn.Module):
         """Fill the deferred weight gradients of every layer whose backward has run (see _WeightGradArena;
         automatic at the end of a whole backward pass, explicit between the pieces of a split one) and make
         the current stream wait for them."""
-        if self._arena is not None:
-            self._arena.flush()
-            self._arena.join()
-            if self._arena._flushed_hi == 0:
+        arena = self._arena
+        if arena is not None:
+            arena.flush()
+            arena.join()
+            if arena._flushed_hi == 0:
                 self._arena = None   # every gradient is in place (the views keep their storage alive)
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None,
@@ -1243,8 +1340,22 @@ class BertEncoder(nn.Module):
             # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
             batch, tq, tt, part_rows = segments
             cut, self.cut_after, self.cut = self.cut_after, None, None
-            arena = self._make_arena(hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut)
-            self._arena = arena
+            pending = self._arena
+            if pending is not None and torch.is_grad_enabled() and \
+                    (len(pending._marks) < pending._expected or pending._flushed_hi > 0):
+                # A grad-enabled forward while the previous one still waits for its backward pass (BLIP-2 stage-1
+                # style: several forwards, one backward -- or simply an abandoned forward).  Its views are not
+                # handed out yet: zero-fill its result buffers and let its flush ADD (shared mode); this forward
+                # runs with immediate weight gradients.
+                if not pending.shared:
+                    pending.shared = True
+                    for t in pending.result_buffers():
+                        t.zero_()
+                arena = None
+            else:
+                arena = self._make_arena(hidden_states, encoder_hidden_states, batch, tq, tt, part_rows, cut)
+            if arena is not None or pending is None or not pending.shared:
+                self._arena = arena   # else: the shared arena stays reachable for an explicit flush_weight_grads()
             for i, layer_module in enumerate(self.layer):
                 hidden_states = layer_module.forward_segmented(
                     hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,

@@ -124,12 +124,14 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
                         final.append(q)
             return final
 
-        decay, no_decay = ordered(decay), ordered(no_decay)
+        # the groups keep named_parameters() order (what a torch.optim.AdamW / reference checkpoint indexes by:
+        # lib/solver.py:657, train.py:262); only the flat buffers follow the adjacency order
+        layout = [ordered(decay), ordered(no_decay)]
     groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
     if name == "flat_adamw":
         # clip_grad_value_(1.0) + AdamW + zero_grad as one streaming kernel per group (optim.py)
         from .optim import FlatAdamW
-        return FlatAdamW(groups, lr=lr, betas=betas, eps=eps, clip_value=clip_value)
+        return FlatAdamW(groups, lr=lr, betas=betas, eps=eps, clip_value=clip_value, storage_order=layout)
     cls = torch.optim.AdamW if name == "adamw" else torch.optim.Adam
     # fused: one multi-tensor HIP kernel per step instead of ~4 launches per parameter;
     # capturable: step counters live on the device so the step can sit inside a hipGraph

@@ -207,3 +207,21 @@ def test_embedding_rows_single_process():
     ref = nn.Parameter(table.detach().clone())
     torch.nn.functional.embedding(ids, ref).pow(2).sum().backward()
     torch.testing.assert_close(dense, ref.grad)
+
+
+def test_embedding_rows_respect_padding_idx():
+    """nn.Embedding(padding_idx=0) (Qformer.py:56): the [PAD] row gets a zero gradient even when its positions
+    receive upstream gradient; the row exchange must agree with the dense backward."""
+    from situation3d_amd.ddp import SparseRowExchange, embedding_rows
+    torch.manual_seed(2)
+    table = nn.Parameter(torch.randn(20, 4))
+    ids = torch.tensor([[0, 1, 3], [19, 0, 0]])
+    sink = SparseRowExchange(6, 4, "cpu", padding_idx=0)
+    embedding_rows(table, ids, sink).pow(2).sum().backward()
+    dense = torch.zeros(20, 4)
+    sink.launch()
+    sink.finish_into(dense)
+    ref = nn.Parameter(table.detach().clone())
+    torch.nn.functional.embedding(ids, ref, padding_idx=0).pow(2).sum().backward()
+    assert float(ref.grad[0].abs().max()) == 0.0
+    torch.testing.assert_close(dense, ref.grad)

@@ -575,3 +575,90 @@ def test_deferred_layer_batched_weight_gradients_equal_immediate_ones(b, tq, tt,
     for n in g0:
         scale = max(1.0, g0[n].abs().max().item())
         torch.testing.assert_close(g1[n], g0[n], rtol=1e-4, atol=1e-5 * scale, msg=lambda m: n + ": " + m)
+
+
+def _small_qformer(tq=8):
+    from situation3d_amd.qformer import QFormer, QFormerConfig
+    torch.manual_seed(7)
+    cfg = QFormerConfig(vocab_size=200, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=64, encoder_width=96,
+                        cross_attention_freq=2, query_length=tq, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0)
+    return QFormer(cfg).to(DEV).train()
+
+
+@pytest.mark.parametrize("order", ["sum", "first_then_second", "second_then_first"])
+def test_two_forwards_before_one_backward_keep_deferred_weight_gradients_right(order):
+    """two grad-enabled Q-Former forwards before one backward (the BLIP-2 stage-1 ITC / ITM / LM
+    pattern) both passed the `p.grad is None` guard; the second contribution was then accumulated into / over
+    UNFILLED arena memory.  Now the waiting arena is zero-filled and switched to ADD its products (shared mode) and
+    the second forward runs with immediate weight gradients: every parameter gradient equals the non-deferred run."""
+    b, tq, tt = 3, 8, 5
+    model = _small_qformer(tq)
+    g = torch.Generator().manual_seed(3)
+    ids = [torch.randint(1, 200, (b, tt), generator=g).to(DEV) for _ in range(2)]
+    encs = [torch.randn(b, 13, 96, generator=g).to(DEV) for _ in range(2)]
+    att = torch.ones(b, tq + tt, dtype=torch.long, device=DEV)
+    q0 = (torch.randn(b, tq, 128, generator=g) * 0.1).to(DEV)
+    G = torch.randn(b, tq, 128, generator=g).to(DEV)
+    grads = []
+    for defer in (False, True):
+        model.bert.encoder.defer_weight_grads = defer
+        model.zero_grad(set_to_none=True)
+        outs = [model.bert(input_ids=ids[k], attention_mask=att, query_embeds=q0, encoder_hidden_states=encs[k],
+                           return_dict=True).query_hidden_state for k in range(2)]
+        if defer:
+            arena = model.bert.encoder._arena
+            assert arena is not None and arena.shared          # the first forward's arena, now in shared mode
+        l0, l1 = (outs[0] * G).sum(), (outs[1] * G).sum() * 0.5
+        if order == "sum":
+            (l0 + l1).backward()
+        elif order == "first_then_second":
+            l0.backward()
+            l1.backward()
+        else:
+            l1.backward()
+            l0.backward()
+        model.bert.encoder.flush_weight_grads()
+        grads.append({n: p.grad.clone() for n, p in model.bert.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 60
+    for n in grads[0]:
+        scale = max(1.0, grads[0][n].abs().max().item())
+        torch.testing.assert_close(grads[1][n], grads[0][n], rtol=1e-4, atol=1e-5 * scale, msg=lambda m: n + ": " + m)
+    # the next ordinary step defers again (the shared arena is complete)
+    del outs, l0, l1
+    model.zero_grad(set_to_none=True)
+    out = model.bert(input_ids=ids[0], attention_mask=att, query_embeds=q0, encoder_hidden_states=encs[0], return_dict=True)
+    assert model.bert.encoder._arena is not None and not model.bert.encoder._arena.shared
+
+
+def test_abandoned_forward_does_not_disable_deferred_weight_gradients():
+    """An evaluation forward with gradients enabled whose output is dropped: its arena dies with the autograd graph
+    (the encoder holds it weakly) and the next training forward defers as usual."""
+    b, tq, tt = 2, 8, 5
+    model = _small_qformer(tq)
+    ids = torch.randint(1, 200, (b, tt), device=DEV)
+    att = torch.ones(b, tq + tt, dtype=torch.long, device=DEV)
+    enc = torch.randn(b, 13, 96, device=DEV)
+    q0 = torch.randn(b, tq, 128, device=DEV) * 0.1
+    out = model.bert(input_ids=ids, attention_mask=att, query_embeds=q0, encoder_hidden_states=enc, return_dict=True)
+    assert model.bert.encoder._arena is not None
+    del out
+    assert model.bert.encoder._arena is None
+    out = model.bert(input_ids=ids, attention_mask=att, query_embeds=q0, encoder_hidden_states=enc, return_dict=True)
+    assert model.bert.encoder._arena is not None and not model.bert.encoder._arena.shared
+
+
+def test_tensor_hook_on_a_parameter_switches_deferred_weight_gradients_off():
+    b, tq, tt = 2, 8, 5
+    model = _small_qformer(tq)
+    seen = []
+    handle = model.bert.encoder.layer[1].attention.output.dense.weight.register_hook(lambda g: seen.append(g.abs().sum().item()))
+    ids = torch.randint(1, 200, (b, tt), device=DEV)
+    att = torch.ones(b, tq + tt, dtype=torch.long, device=DEV)
+    out = model.bert(input_ids=ids, attention_mask=att, query_embeds=torch.randn(b, tq, 128, device=DEV) * 0.1,
+                     encoder_hidden_states=torch.randn(b, 13, 96, device=DEV), return_dict=True)
+    assert model.bert.encoder._arena is None          # a hook would see (and may keep) the unfilled view
+    out.query_hidden_state.sum().backward()
+    assert len(seen) == 1 and seen[0] > 0
+    handle.remove()

@@ -199,3 +199,92 @@ def test_flat_adamw_learning_rate_schedule_reaches_captured_replays():
         assert opt.param_groups[0]["lr"] == pytest.approx(1e-5)
         for p, q in zip(a.parameters(), b.parameters()):
             torch.testing.assert_close(q, p, rtol=1e-4, atol=1e-6)
+
+
+def _tiny_sig3d():
+    from situation3d_amd.model import SIG3DQFormer
+    torch.manual_seed(0)
+    small = dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    return SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+
+
+def _sig3d_batch(seed, b=2, n=3000):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    pose = torch.cat([torch.rand(b, 3, generator=g), torch.tensor([[0.0, 0.0, 0.6, 0.8]]).expand(b, 4)], 1)
+    ans = torch.zeros(b, 16)
+    ans[:, 3] = 1.0
+    return {"point_clouds": torch.cat([xyz, torch.rand(b, n, 3, generator=g)], -1).to(DEV),
+            "auxiliary_task": pose.to(DEV),
+            "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
+                       "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
+            "answer_cat_scores": ans.to(DEV)}
+
+
+@pytest.mark.parametrize("direction", ["torch->flat", "flat->torch"])
+def test_build_optimizer_checkpoints_are_independent_of_the_flat_storage_order(direction):
+    """trainer.build_optimizer(name="flat_adamw") lays the Q-Former's parameters out kind-major
+    (all layers' query/key/value, then all out-projections, ...) -- far from named_parameters() order -- and every
+    768 x 768 matrix has the same shape, so a checkpoint indexed by STORAGE position would silently hand the
+    moments to the wrong parameters.  The groups keep named_parameters() order: a torch.optim.AdamW checkpoint
+    (lib/solver.py:657, train.py:262) loads into FlatAdamW and back, compared per parameter NAME."""
+    from situation3d_amd.trainer import build_optimizer, train_step
+    src_name, dst_name = [{"torch": "adamw", "flat": "flat_adamw"}[k] for k in direction.split("->")]
+    model = _tiny_sig3d()
+    src = build_optimizer(model, name=src_name, lr=1e-3)
+    for i in range(3):
+        train_step(model, src, _sig3d_batch(10 + i))
+    ckpt = copy.deepcopy(src.state_dict())
+    # the moments of the source, by parameter name (torch's convention: position in the concatenated group lists)
+    names = {id(p): n for n, p in model.named_parameters()}
+    by_name, i = {}, 0
+    for group in src.param_groups:
+        for p in group["params"]:
+            if i in ckpt["state"]:
+                by_name[names[id(p)]] = ckpt["state"][i]
+            i += 1
+    assert len(by_name) > 60
+    model2 = _tiny_sig3d()
+    model2.load_state_dict(model.state_dict())
+    dst = build_optimizer(model2, name=dst_name, lr=1e-3)
+    # same group lists in both optimizers: named_parameters() order, whatever the flat layout is
+    order = lambda opt, m: [[{id(p): n for n, p in m.named_parameters()}[id(p)] for p in g["params"]]
+                            for g in opt.param_groups]
+    assert order(src, model) == order(dst, model2)
+    dst.load_state_dict(ckpt)
+    back = dst.state_dict()
+    names2 = {id(p): n for n, p in model2.named_parameters()}
+    i, seen = 0, 0
+    for group in dst.param_groups:
+        for p in group["params"]:
+            n = names2[id(p)]
+            if n in by_name:
+                st = back["state"][i]
+                assert float(st["step"]) == 3.0
+                torch.testing.assert_close(st["exp_avg"].to(DEV), by_name[n]["exp_avg"].to(DEV), rtol=0, atol=0,
+                                           msg=lambda m: n + " exp_avg: " + m)
+                torch.testing.assert_close(st["exp_avg_sq"].to(DEV), by_name[n]["exp_avg_sq"].to(DEV), rtol=0, atol=0)
+                seen += 1
+            i += 1
+    assert seen == len(by_name)
+    # and training continues identically to an uninterrupted run of the source kind
+    ref = build_optimizer(model, name=src_name, lr=1e-3)
+    ref.load_state_dict(ckpt)
+    for k in range(2):
+        train_step(model, ref, _sig3d_batch(20 + k))
+        train_step(model2, dst, _sig3d_batch(20 + k))
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        torch.testing.assert_close(q, p, rtol=1e-3, atol=2e-5, msg=lambda m: n + ": " + m)
+
+
+def test_flat_adamw_load_state_dict_rejects_a_differently_ordered_checkpoint():
+    from situation3d_amd.optim import FlatAdamW
+    net = _net()
+    opt = FlatAdamW(_groups(net, 0.05), lr=1e-2)
+    (net(torch.randn(4, 37, device=DEV)).sum()).backward()
+    opt.step()
+    sd = opt.state_dict()
+    sd["state"][0], sd["state"][2] = sd["state"][2], sd["state"][0]     # (300, 37) <-> (300, 300) moments swapped
+    with pytest.raises(ValueError, match="orders its parameters differently"):
+        opt.load_state_dict(sd)

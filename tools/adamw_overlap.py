@@ -49,7 +49,7 @@ with torch.cuda.stream(main):
     def launch_adam():
         g0 = opt.param_groups[0]; b1, b2 = g0["betas"]
         _lib.call("sig3d_adamw_table", len(opt._static), _lib.ptr(opt._table), _lib.ptr(opt._step), ctypes.c_float(g0["lr"]),
-                  ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]), ctypes.c_float(opt.clip_value),
+                  _lib.ptr(opt._lr_dev), ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]), ctypes.c_float(opt.clip_value),
                   _lib.stream_ptr(dev))
     opt._upload()
     with torch.cuda.graph(g_ad, stream=main):
