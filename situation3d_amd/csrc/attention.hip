@@ -283,7 +283,8 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_fwd_kernel(
     float wgt[AT_WAVES], lt = 0.f;
 #pragma unroll
     for (int w = 0; w < AT_WAVES; ++w) {
-      wgt[w] = __expf(s_m[w][qq] - mt);  // waves without a tile: exp(-inf) = 0
+      // waves without a tile: exp(-inf) = 0; a workgroup without ANY tile (mt = -inf) must give 0, not exp(nan)
+      wgt[w] = mt == -INFINITY ? 0.f : __expf(s_m[w][qq] - mt);
       lt += s_l[w][qq] * wgt[w];
     }
     if (key_splits > 1) {
@@ -860,6 +861,10 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   if (key_splits < 1) key_splits = 1;
   const int ntiles_fwd = (nk + 31) / 32;
   if (key_splits > ntiles_fwd) key_splits = ntiles_fwd;
+  if (key_splits > 1) {   // no split may be left without a tile: ceil(tiles / splits) per split covers the range early
+    const int tps = (ntiles_fwd + key_splits - 1) / key_splits;
+    key_splits = (ntiles_fwd + tps - 1) / tps;
+  }
   SIG3D_REQUIRE(key_splits == 1 || workspace != nullptr,
                 "key_splits > 1 needs a workspace of b*h*roundup32(nq)*key_splits*(d+2) floats");
   dim3 grid(h, ((nq + 31) / 32) * key_splits, b);

@@ -529,7 +529,12 @@ class _WeightGradArena:
                                "(retain_graph is not supported; set encoder.defer_weight_grads = False)")
         self._marks.add(key)
         if len(self._marks) == self._expected:
-            self.flush()
+            if self.shared:
+                # the products are ADDED to `.grad`, which autograd only completes after this backward call has
+                # returned (the gradients of this very block are still on their way): run when the pass is over
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            else:
+                self.flush()
 
     def _layer_done(self, l):
         return ("attn", l) in self._marks and ("ffn", l) in self._marks and \

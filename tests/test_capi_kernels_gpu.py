@@ -227,10 +227,13 @@ def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad):
         assert torch.equal(_to_segments(a.view(b, n, ld), seg, base2, rows, fill=0.0), c.view(rows, ld)), name
 
 
-@pytest.mark.parametrize("b,h,nq,nk,splits", [(2, 3, 32, 5000, 7), (1, 2, 40, 1000, 32), (1, 1, 5, 77, 3)])
+@pytest.mark.parametrize("b,h,nq,nk,splits", [(2, 3, 32, 5000, 7), (1, 2, 40, 1000, 32), (1, 1, 5, 77, 3),
+                                              (1, 2, 32, 9 * 32, 4), (1, 12, 32, 80000, 64)])
 def test_attention_fwd_key_splits_match_single_pass(b, h, nq, nk, splits):
     """key_splits only re-associates the streaming softmax over key ranges: same result as one pass
-    within rounding (1e-5), lse included; more splits than 32-key tiles are clamped."""
+    within rounding (1e-5), lse included; more splits than 32-key tiles are clamped.  9 tiles / 4 splits and
+    2500 tiles / 64 splits (what qformer._fwd_key_splits picks at B = 1, Nk = 80 000) leave the LAST split
+    without a tile at ceil(tiles / splits) tiles per split: round 3 found that split writing NaN partials."""
     L = _lib()
     g = torch.Generator().manual_seed(nk)
     ld = h * 64
