@@ -87,12 +87,31 @@ int sig3d_gather_xyz(int b, int n, int m, const float *xyz, const int *idx, floa
 int sig3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                      const float *xyz, int *idx, void *stream);
 
-/* Same result, bit for bit, through a hashed uniform grid (cells of 1.01*radius; one wave per centre
- * walks the 27 neighbour buckets, hits are put back into index order by rank counting; centres with
- * more than 256 hits fall back to the ordered scan): ~45 distance tests per centre instead of n at the
- * SA1 shape.  workspace: b*(3*H+1)*4 bytes rounded up to 16, plus b*n*16 bytes, H = smallest power of
- * two >= max(1024, 2n), at most 2^20.  n < 1024 is forwarded to sig3d_ball_query.  Assumes
- * |coordinate| / radius < ~1e5 (cell indexing in f32). */
+/* Same result, bit for bit, for several problems in ONE launch pair (the levels of a set-abstraction stack).
+ * Scenes of more than 4096 points: the CENTRES of a scene are binned into hashed cells of edge 2.02*radius
+ * inside LDS and the scene's points are streamed past them once, in index order; every point appends itself to
+ * the centres it hits (at most eight buckets to look at), and a second kernel puts each centre's hit list back
+ * into index order by rank counting, truncates to nsample, pads with the first hit / writes the zero row;
+ * centres with more than 256 hits fall back to the ordered scan.  ~5 distance tests per POINT instead of n per
+ * centre.  Scenes of at most 4096 points (deeper levels: a ball holds a tenth of the scene) run the ordered scan
+ * of sig3d_ball_query from an LDS copy of the scene, in the same launch.
+ * levels: HOST array; radius > 0; m of any size (blocks of 4096 centres, 16 blocks per launch at most).
+ * workspace: sig3d_ball_query_levels_workspace_bytes(b, nlevels, levels) bytes (-1: does not fit one launch);
+ * at most 4 * (1 + 256) bytes per centre.  Assumes |coordinate| / radius < ~4e4 (cell indexing in f32). */
+typedef struct {
+  int n, m, nsample;
+  float radius;
+  const float *xyz;      /* (b, n, 3) */
+  const float *new_xyz;  /* (b, m, 3) */
+  int *idx;              /* (b, m, nsample) */
+} sig3d_bq_level;
+long sig3d_ball_query_levels_workspace_bytes(int b, int nlevels, const sig3d_bq_level *levels);
+int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
+                            long workspace_bytes, void *stream);
+
+/* One problem through sig3d_ball_query_levels (the round-1 name: it was a hashed grid over the points).
+ * workspace: 1028 * b * m bytes.  n < 256, radius <= 0 or more than 65536 centres are forwarded to
+ * sig3d_ball_query. */
 int sig3d_ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                           const float *xyz, int *idx, void *workspace, long workspace_bytes,
                           void *stream);

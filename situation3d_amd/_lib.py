@@ -124,7 +124,29 @@ def gemm_group(device, *problems):
     with torch.cuda.device(device):
         call("sig3d_gemm_group", len(problems), arr, stream_ptr(device))
 
-INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes")
+class BqLevel(ctypes.Structure):
+    """sig3d_bq_level of include/sig3d_hip.h: one ball-query problem of a multi-level launch."""
+    _fields_ = [("n", _I), ("m", _I), ("nsample", _I), ("radius", _F), ("xyz", _P), ("new_xyz", _P), ("idx", _P)]
+
+
+SIGNATURES["sig3d_ball_query_levels"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _P]
+
+
+def bq_levels(problems):
+    """problems: [(xyz (b,n,3), new_xyz (b,m,3), radius, nsample, idx (b,m,nsample))] -> ctypes array."""
+    arr = (BqLevel * len(problems))()
+    for q, (xyz, new_xyz, radius, nsample, idx) in zip(arr, problems):
+        q.n, q.m, q.nsample, q.radius = xyz.shape[1], new_xyz.shape[1], int(nsample), float(radius)
+        q.xyz, q.new_xyz, q.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+    return arr
+
+
+def bq_levels_workspace_bytes(batch, arr):
+    return int(load().sig3d_ball_query_levels_workspace_bytes(batch, len(arr), arr))
+
+
+INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes",
+                "sig3d_ball_query_levels_workspace_bytes")
 
 _lib = None
 
@@ -152,6 +174,8 @@ def load():
     lib.sig3d_last_error.restype = ctypes.c_char_p
     lib.sig3d_voxelize_workspace_bytes.argtypes = [_I, ctypes.c_long, _I]
     lib.sig3d_voxelize_workspace_bytes.restype = ctypes.c_long
+    lib.sig3d_ball_query_levels_workspace_bytes.argtypes = [_I, _I, ctypes.POINTER(BqLevel)]
+    lib.sig3d_ball_query_levels_workspace_bytes.restype = ctypes.c_long
     _lib = lib
     return lib
 

@@ -33,7 +33,8 @@ class GeometryPlan:
         self.batch, self.n_points = batch, n_points
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
-        self._bq_work = None  # scratch of the grid ball query (allocated once: static under hipGraph)
+        self._bq_work = None    # scratch of the multi-level ball query (allocated once: static under hipGraph)
+        self._bq_levels = None  # its level table (ctypes array of sig3d_bq_level: raw pointers of the plan's buffers)
         n = n_points
         for npoint, radius, nsample in self.levels:
             self.inds.append(torch.zeros(batch, npoint, dtype=torch.int32, device=device))
@@ -57,6 +58,7 @@ class GeometryPlan:
         cur = xyz
         with torch.cuda.device(dev):
             timeline.mark("geo:start")
+            srcs = []
             for lvl, (npoint, radius, nsample) in enumerate(self.levels):
                 if lvl == 0 or not NESTED_FPS:
                     _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
@@ -70,20 +72,25 @@ class GeometryPlan:
                 timeline.mark("geo:L%d fps" % (lvl + 1))
                 _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
                           _lib.ptr(self.new_xyz[lvl]), s)
-                if n >= _ext.GRID_MIN_POINTS:
-                    if self._bq_work is None or self._bq_work.numel() < _ext.ball_query_workspace_bytes(b, n):
-                        self._bq_work = torch.empty(_ext.ball_query_workspace_bytes(b, n), dtype=torch.uint8,
-                                                    device=dev)
-                    _lib.call("sig3d_ball_query_grid", b, n, npoint, ctypes.c_float(radius), nsample,
-                              _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]),
-                              _lib.ptr(self._bq_work), self._bq_work.numel(), s)
-                else:
-                    _lib.call("sig3d_ball_query", b, n, npoint, ctypes.c_float(radius), nsample,
-                              _lib.ptr(self.new_xyz[lvl]), _lib.ptr(cur), _lib.ptr(self.ball_idx[lvl]), s)
+                srcs.append(cur)
+                cur, n = self.new_xyz[lvl], npoint
+            # the neighbour lists of ALL levels depend on coordinates only: one scatter + one rank launch
+            # (csrc/ball_query.hip: centres binned into cells, points streamed once) instead of a chain per level
+            ptrs = [t.data_ptr() for t in srcs]
+            if self._bq_levels is None or self._bq_srcs != ptrs:   # the level table holds raw pointers
+                probs = [(srcs[l], self.new_xyz[l], lv[1], lv[2], self.ball_idx[l]) for l, lv in enumerate(self.levels)]
+                self._bq_levels = _lib.bq_levels(probs)
+                need = _lib.bq_levels_workspace_bytes(b, self._bq_levels)
+                assert need >= 0, "too many centres for one multi-level ball query"
+                if self._bq_work is None or self._bq_work.numel() < need:
+                    self._bq_work = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+                self._bq_srcs = ptrs
+            _lib.call("sig3d_ball_query_levels", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
+                      self._bq_work.numel(), s)
+            for lvl in range(len(self.levels)):
                 if self.compact[lvl] is not None:
                     self.compact[lvl].compute(self.ball_idx[lvl])
-                timeline.mark("geo:L%d lists" % (lvl + 1))
-                cur, n = self.new_xyz[lvl], npoint
+            timeline.mark("geo:lists")
         return self
 
     def level(self, i):

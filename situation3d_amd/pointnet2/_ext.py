@@ -152,8 +152,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     nsample = int(nsample)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=dev)
     if n >= GRID_MIN_POINTS and radius > 0:
-        # large scenes: hashed uniform grid, same output bit for bit (csrc/ball_query.hip)
-        work = torch.empty(ball_query_workspace_bytes(b, n), dtype=torch.uint8, device=dev)
+        # centres binned into cells, points streamed once: same output bit for bit (csrc/ball_query.hip)
+        work = torch.empty(ball_query_workspace_bytes(b, m), dtype=torch.uint8, device=dev)
         _run("sig3d_ball_query_grid", dev, b, n, m, ctypes.c_float(radius), nsample, _lib.ptr(new_xyz),
              _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(work), work.numel())
         return idx
@@ -162,16 +162,37 @@ def ball_query(new_xyz, xyz, radius, nsample):
     return idx
 
 
-GRID_MIN_POINTS = 8192   # below: the ordered brute-force scan is faster than building the grid
+GRID_MIN_POINTS = 256   # below: the ordered brute-force scan (a chain of n / 64 steps) is the right tool
 
 
-def ball_query_workspace_bytes(b, n):
-    """Scratch of sig3d_ball_query_grid (include/sig3d_hip.h)."""
-    h = 2048
-    while h < 2 * n and h < (1 << 20):
-        h <<= 1
-    ints = b * (3 * h + 1 + h // 2048) * 4
-    return (ints + 15) // 16 * 16 + b * n * 16
+def ball_query_workspace_bytes(b, m):
+    """Scratch of sig3d_ball_query_grid (include/sig3d_hip.h): a counter and 256 list slots per centre."""
+    return max(b * m * 4 * 257, 16)
+
+
+def ball_query_levels(problems, workspace=None):
+    """Several ball queries in ONE launch pair (sig3d_ball_query_levels): problems = [(new_xyz, xyz, radius,
+    nsample)] in ball_query's argument order, all with the same batch size and radius > 0 -> [idx]."""
+    outs, recs = [], []
+    dev = None
+    for new_xyz, xyz, radius, nsample in problems:
+        _check_contiguous(new_xyz, "new_xyz"); _check_contiguous(xyz, "xyz")
+        _check_float(new_xyz, "new_xyz"); _check_float(xyz, "xyz")
+        dev = _lib.require_device(new_xyz, xyz)
+        idx = torch.empty((new_xyz.shape[0], new_xyz.shape[1], int(nsample)), dtype=torch.int32, device=dev)
+        outs.append(idx)
+        recs.append((xyz, new_xyz, radius, nsample, idx))
+    if not recs:
+        return outs
+    b = recs[0][0].shape[0]
+    arr = _lib.bq_levels(recs)
+    need = _lib.bq_levels_workspace_bytes(b, arr)
+    if need < 0:
+        raise RuntimeError("too many centres for one multi-level ball query")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    _run("sig3d_ball_query_levels", dev, b, len(arr), arr, _lib.ptr(workspace), workspace.numel())
+    return outs
 
 
 def group_points(points, idx):

@@ -142,9 +142,10 @@ def test_ball_query(hip_ext, oracle, n, m, r, ns):
                                                     (9000, 300, 0.4, 32, 1000, 0), (20000, 256, 1.5, 16, 0, 500),
                                                     (8192, 64, 0.05, 8, 0, 0)])
 def test_ball_query_grid_path_bit_exact(hip_ext, oracle, n, m, r, ns, dup, zero_tail):
-    """n >= 8192 takes the hashed-grid kernels: index order, padding, all-zero rows and dense
-    neighbourhoods (duplicates, a zero-padded tail with thousands of coincident points -> the
-    ordered-scan fallback) must equal the reference's serial scan bit for bit."""
+    """n >= 256 takes the cell-binned kernels (centres hashed into cells in LDS, points streamed once, hit lists
+    ranked back into index order): index order, padding, all-zero rows and dense neighbourhoods (duplicates, a
+    zero-padded tail with thousands of coincident points -> the ordered-scan fallback) must equal the
+    reference's serial scan bit for bit."""
     from situation3d_amd.pointnet2 import _ext
     assert n >= _ext.GRID_MIN_POINTS
     xyz = scene(2, n, seed=n + ns, dup=dup)
@@ -158,6 +159,55 @@ def test_ball_query_grid_path_bit_exact(hip_ext, oracle, n, m, r, ns, dup, zero_
     ref = oracle.ball_query(new_xyz, xyz, r, ns)
     got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
     assert torch.equal(got, ref)
+
+
+def test_ball_query_levels_one_launch_pair_for_a_whole_stack(hip_ext, oracle):
+    """sig3d_ball_query_levels: the four SA levels of BASELINE config 3 (each level queries the centres of the
+    level above) in ONE scatter + ONE rank launch -- every list equal to the reference's serial scan."""
+    from situation3d_amd.pointnet2 import _ext
+    b = 2
+    xyz = scene(b, 40000, seed=77, dup=3000)
+    g = torch.Generator().manual_seed(3)
+    chain, cur = [], xyz
+    for m, r, ns in ((2048, 0.2, 64), (1024, 0.4, 32), (512, 0.8, 16), (256, 1.2, 16)):
+        sel = torch.randperm(cur.shape[1], generator=g)[:m]
+        nxt = cur[:, sel].contiguous()
+        chain.append((nxt, cur, r, ns))
+        cur = nxt
+    got = _ext.ball_query_levels([(a.to(DEV), c.to(DEV), r, ns) for a, c, r, ns in chain])
+    for (a, c, r, ns), idx in zip(chain, got):
+        assert torch.equal(idx.cpu(), oracle.ball_query(a, c, r, ns)), (a.shape, r, ns)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(2049, 5000, 0.3, 8), (300, 4097, 0.5, 4), (6000, 9000, 0.25, 16)])
+def test_ball_query_more_centres_than_one_table(hip_ext, oracle, n, m, r, ns):
+    """More than 4096 centres: blocks of 4096 share the launch (one LDS table each)."""
+    xyz = scene(2, n, seed=n + m)
+    g = torch.Generator().manual_seed(5)
+    new_xyz = (xyz[:, torch.randint(0, n, (m,), generator=g)] + torch.randn(2, m, 3, generator=g) * 0.05).contiguous()
+    ref = oracle.ball_query(new_xyz, xyz, r, ns)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_ball_query_cells_survive_far_away_negative_and_colliding_coordinates(hip_ext, oracle):
+    """Hash collisions (a scene hundreds of cells wide hashed into 2m buckets), negative coordinates, points on
+    cell boundaries (multiples of the cell edge 2.02 r) and a cluster of 600 coincident points around ONE centre
+    (more hits than the 256 list slots: ordered-scan fallback next to ranked neighbours in the same wave)."""
+    g = torch.Generator().manual_seed(11)
+    n, m, r, ns = 20000, 700, 0.25, 32
+    xyz = (torch.rand(2, n, 3, generator=g) - 0.5) * torch.tensor([300.0, 300.0, 40.0])
+    e = 2.02 * r
+    xyz[:, :2000] = torch.round(xyz[:, :2000] / e) * e           # exactly on cell boundaries (as far as f32 goes)
+    xyz[:, 5000:5600] = xyz[:, 4999:5000]                         # 600 coincident points
+    sel = torch.randperm(n, generator=g)[:m]
+    sel[3] = 5003
+    new_xyz = xyz[:, sel].contiguous()
+    new_xyz[:, 10:200] += torch.randn(2, 190, 3, generator=g) * 0.1
+    ref = oracle.ball_query(new_xyz, xyz, r, ns)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), r, ns).cpu()
+    assert torch.equal(got, ref)
+    assert int((ref[:, 3] != ref[:, 3, :1]).sum()) > 0            # the cluster's centre really has a full list
 
 
 @pytest.mark.parametrize("c,n,p,s", [(3, 4096, 512, 64), (6, 9, 2, 3), (131, 2048, 256, 32),
