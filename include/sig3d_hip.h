@@ -563,6 +563,13 @@ int sig3d_mlp_layer_dw_compact(int b, int cin, int cout, long e, const float *dY
 /* arg = offset of the first maximum inside the centre's segment */
 int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const float *y, const float *scale,
                                   const float *shift, const int *seg_off, float *out, int *arg, void *stream);
+/* sig3d_bn_relu_maxpool / _compact (seg_off != NULL: compact lists, e = row stride, s ignored) with a second,
+ * POINT-MAJOR copy of the pooled features: out_pm (b,p,c) -- what the next level's gathers and the Q-Former's
+ * scene tokens read (pointnet2_modules.py:259-262 followed by the `.transpose(1, 2)` of its callers), written
+ * from the pooling pass instead of by a transpose launch. */
+int sig3d_bn_relu_maxpool_pm(int b, int c, int p, int s, long e, const float *y, const float *scale,
+                             const float *shift, const int *seg_off, float *out, int *arg, float *out_pm,
+                             void *stream);
 int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const float *dA, const float *dOut, const int *arg,
                               const float *y, const float *scale, const float *shift, const float *mean,
                               const float *invstd, double *s1, double *s2, float *dY, int accumulate,

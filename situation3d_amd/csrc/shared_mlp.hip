@@ -505,6 +505,96 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_vec_kernel(unsigned group
 }
 
 
+// ---- max-pool with a POINT-MAJOR second output --------------------------------------------------------------
+// The next set-abstraction level gathers whole feature rows of its neighbours (point-major, (b, p, c)), and the
+// Q-Former reads its scene tokens row by row, while the SharedMLP above produced channel-major rows.  Round 2 ran
+// a transpose launch between every two levels (six per step, 84 MB of traffic for no algorithmic byte).  These
+// kernels write BOTH layouts from the pooling pass: a workgroup owns a tile of PM_TC channels x TP centres,
+// pools channel by channel (coalesced reads of y, the channel-major outputs as before), parks the pooled values
+// in LDS and writes the tile once more with the channels of a centre adjacent (64-byte runs).
+constexpr int PM_TC = 16;
+
+template <int LPG>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_pm_kernel(int c, int P, const float *__restrict__ y,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 float *__restrict__ out, int *__restrict__ arg,
+                                                                 float *__restrict__ out_pm) {
+  constexpr int TP = 256 / LPG;
+  __shared__ float tile[PM_TC][TP + 1];
+  const int bi = blockIdx.z, c0 = blockIdx.y * PM_TC, p0 = blockIdx.x * TP;
+  const int tid = threadIdx.x, sub = tid % LPG, pl = tid / LPG;
+  const int gp = min(p0 + pl, P - 1);
+  float4 v[PM_TC];
+#pragma unroll
+  for (int it = 0; it < PM_TC; ++it) {   // every load of the tile in flight before the first use
+    const int ch = min(c0 + it, c - 1);
+    v[it] = reinterpret_cast<const float4 *>(y + (((size_t)bi * c + ch) * P + gp) * (4 * LPG))[sub];
+  }
+#pragma unroll
+  for (int it = 0; it < PM_TC; ++it) {
+    const int ch = min(c0 + it, c - 1);
+    const float sc = scale[ch], sh = shift[ch];
+    const float r[4] = {fmaxf(0.f, v[it].x * sc + sh), fmaxf(0.f, v[it].y * sc + sh), fmaxf(0.f, v[it].z * sc + sh),
+                        fmaxf(0.f, v[it].w * sc + sh)};
+    float best = r[0];
+    int bidx = 4 * sub;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (r[q] > best) { best = r[q]; bidx = 4 * sub + q; }
+#pragma unroll
+    for (int off = 1; off < LPG; off <<= 1) {   // ties go to the smaller sample index: first maximum
+      const float ob = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bidx, off);
+      if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (sub == 0) {
+      tile[it][pl] = best;
+      if (c0 + it < c && p0 + pl < P) {
+        const size_t g = ((size_t)bi * c + ch) * P + gp;
+        out[g] = best;
+        arg[g] = bidx;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TP * PM_TC; i += 256) {
+    const int pp = i / PM_TC, cc = i % PM_TC;
+    if (p0 + pp < P && c0 + cc < c) out_pm[((size_t)bi * P + p0 + pp) * c + c0 + cc] = tile[cc][pp];
+  }
+}
+
+// compact lists: thread = (channel, centre) of a 16 x 16 tile, the centre's segment [seg[j], seg[j+1])
+__global__ __launch_bounds__(256) void bn_relu_maxpool_seg_pm_kernel(int c, int P, long E, const float *__restrict__ y,
+                                                                     const float *__restrict__ scale,
+                                                                     const float *__restrict__ shift,
+                                                                     const int *__restrict__ seg,
+                                                                     float *__restrict__ out, int *__restrict__ arg,
+                                                                     float *__restrict__ out_pm) {
+  __shared__ float tile[PM_TC][17];
+  const int bi = blockIdx.z, c0 = blockIdx.y * PM_TC, p0 = blockIdx.x * 16;
+  const int cl = threadIdx.x >> 4, pl = threadIdx.x & 15;
+  const int ch = min(c0 + cl, c - 1), j = min(p0 + pl, P - 1);
+  const int *sg = seg + (size_t)bi * (P + 1);
+  const int lo = sg[j], hi = sg[j + 1];
+  const float sc = scale[ch], sh = shift[ch];
+  const float *row = y + ((size_t)bi * c + ch) * E;
+  float best = -1.f;
+  int bt = 0;
+  for (int u = lo; u < hi; ++u) {
+    const float v = fmaxf(0.f, row[u] * sc + sh);
+    if (v > best) { best = v; bt = u - lo; }  // first maximum, like max_pool2d over the padded list
+  }
+  tile[cl][pl] = best;
+  if (c0 + cl < c && p0 + pl < P) {
+    out[((size_t)bi * c + ch) * P + j] = best;
+    arg[((size_t)bi * c + ch) * P + j] = bt;
+  }
+  __syncthreads();
+  const int pp = threadIdx.x >> 4, cc = threadIdx.x & 15;
+  if (p0 + pp < P && c0 + cc < c) out_pm[((size_t)bi * P + p0 + pp) * c + c0 + cc] = tile[cc][pp];
+}
+
 // ---- backward: BatchNorm(train) + ReLU ------------------------------------------------------
 // With z = y*scale + shift, a = relu(z), xhat = (y - mean)*invstd and upstream gradient dA:
 //   dZ = dA * [z > 0];  S1 = sum dZ (= d beta);  S2 = sum dZ*xhat (= d gamma)
@@ -1422,6 +1512,33 @@ extern "C" int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const 
   hipLaunchKernelGGL(bn_relu_maxpool_seg_kernel, dim3(sig3d_ceil_div(p, 256), c, b), dim3(256), 0,
                      (hipStream_t)stream_, c, p, e, y, scale, shift, seg_off, out, arg);
   SIG3D_LAUNCH_CHECK("bn_relu_maxpool_seg_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_bn_relu_maxpool_pm(int b, int c, int p, int s, long e, const float *y, const float *scale,
+                                        const float *shift, const int *seg_off, float *out, int *arg, float *out_pm,
+                                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && p >= 0 && out_pm != nullptr, "bad size");
+  if (b == 0 || p == 0) return 0;
+  if (seg_off != nullptr) {
+    SIG3D_REQUIRE(e >= 0, "bad size");
+    hipLaunchKernelGGL(bn_relu_maxpool_seg_pm_kernel, dim3(sig3d_ceil_div(p, 16), sig3d_ceil_div(c, PM_TC), b), dim3(256),
+                       0, stream, c, p, e, y, scale, shift, seg_off, out, arg, out_pm);
+  } else if (s == 64) {
+    hipLaunchKernelGGL(bn_relu_maxpool_pm_kernel<16>, dim3(sig3d_ceil_div(p, 16), sig3d_ceil_div(c, PM_TC), b), dim3(256), 0,
+                       stream, c, p, y, scale, shift, out, arg, out_pm);
+  } else if (s == 32) {
+    hipLaunchKernelGGL(bn_relu_maxpool_pm_kernel<8>, dim3(sig3d_ceil_div(p, 32), sig3d_ceil_div(c, PM_TC), b), dim3(256), 0,
+                       stream, c, p, y, scale, shift, out, arg, out_pm);
+  } else if (s == 16) {
+    hipLaunchKernelGGL(bn_relu_maxpool_pm_kernel<4>, dim3(sig3d_ceil_div(p, 64), sig3d_ceil_div(c, PM_TC), b), dim3(256), 0,
+                       stream, c, p, y, scale, shift, out, arg, out_pm);
+  } else {   // other neighbourhood sizes: the generic pooling kernel, then one transpose
+    if (int rc = sig3d_bn_relu_maxpool(b, c, p, s, y, scale, shift, out, arg, stream_)) return rc;
+    return sig3d_transpose_cn(b, c, p, out, out_pm, stream_);
+  }
+  SIG3D_LAUNCH_CHECK("bn_relu_maxpool_pm_kernel");
   return 0;
 }
 

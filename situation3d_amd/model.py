@@ -12,6 +12,7 @@ question tokens attend to them in a BLIP-2 Q-Former (cross-attention every 2nd l
 import torch
 import torch.nn as nn
 
+from .pointnet2.fused_mlp import point_major_of
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .qformer import init_Qformer
 from .situational import gaussian_localisation_target, situational_transform
@@ -31,6 +32,8 @@ class PointNet2Encoder(nn.Module):
                                          mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
         self.sa4 = PointnetSAModuleVotes(npoint=256, radius=1.2, nsample=16,
                                          mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        for sa in (self.sa1, self.sa2, self.sa3, self.sa4):
+            sa.emit_point_major = True   # pooled features also point-major: no transpose between the levels
         self.use_fp = use_fp
         if use_fp:
             self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
@@ -96,7 +99,8 @@ class SIG3DQFormer(nn.Module):
         xyz = pc[..., :3].contiguous()
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
         tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("geometry_plan"))
-        tok_feat = tok_feat.transpose(1, 2).contiguous()            # (B,T,256)
+        tok_pm = point_major_of(tok_feat)                           # SA4's pooling kernel wrote (B,T,256) as well
+        tok_feat = tok_pm if tok_pm is not None else tok_feat.transpose(1, 2).contiguous()
         data_dict["scene_positions"] = tok_xyz
         data_dict["att_feat_pre"] = tok_feat
 

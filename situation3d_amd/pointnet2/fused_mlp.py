@@ -162,7 +162,10 @@ class _FusedMLPMax(torch.autograd.Function):
     separate ReLU / threshold / max-reduce / scatter launches."""
 
     @staticmethod
-    def forward(ctx, x, layers, library_gemm, compact, gather, *flat):
+    def forward(ctx, x, layers, library_gemm, compact, gather, want_pm, x_is_pm, *flat):
+        # want_pm: also return the pooled features POINT-MAJOR (B, npoint, C) -- written by the pooling kernel
+        # itself (sig3d_bn_relu_maxpool_pm), for the next level's gathers / the Q-Former's scene tokens
+        # x_is_pm (gather mode): x is already the point-major feature copy (B, N, C) of the level below
         # flat = (W_1, gamma_1, beta_1, W_2, gamma_2, beta_2, ...) so that autograd tracks them
         # compact: None, or CompactLists.tensors(): x then holds the DISTINCT neighbours only (first n_act[b]
         # positions of every row) and every kernel below runs in compact mode (csrc/compact.hip)
@@ -170,6 +173,7 @@ class _FusedMLPMax(torch.autograd.Function):
         # features (B, C, N) and the first layer gathers its operand on load (no grouped
         # (B, 3 + C, npoint, nsample) tensor in either direction); idx = ball-query lists, or the compact lists
         dev = x.device
+        ctx.set_materialize_grads(False)   # an unused output (channel-major OR point-major) arrives as None, not zeros
         if compact is not None:
             assert not library_gemm
             c_cidx, c_cent, c_mult, c_seg, c_nact = compact
@@ -179,11 +183,15 @@ class _FusedMLPMax(torch.autograd.Function):
         if gather is not None:
             assert not library_gemm
             g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
-            b, c0, n_src = x.shape
             p = g_new_xyz.shape[1]
-            feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
+            if x_is_pm:
+                b, n_src, c0 = x.shape
+                feat_pm = x
+            else:
+                b, c0, n_src = x.shape
+                feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
         else:
             b, c0, p, s = x.shape
         e = p * s
@@ -240,7 +248,13 @@ class _FusedMLPMax(torch.autograd.Function):
             c_last = ws[-1].shape[0]
             out = torch.empty((b, c_last, p), dtype=torch.float32, device=dev)
             arg = torch.empty((b, c_last, p), dtype=torch.int32, device=dev)
-            if compact is not None:
+            out_pm = None
+            if want_pm:
+                out_pm = torch.empty((b, p, c_last), dtype=torch.float32, device=dev)
+                _lib.call("sig3d_bn_relu_maxpool_pm", b, c_last, p, s, e, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                          _lib.ptr(c_seg if compact is not None else None), _lib.ptr(out), _lib.ptr(arg),
+                          _lib.ptr(out_pm), stream)
+            elif compact is not None:
                 _lib.call("sig3d_bn_relu_maxpool_compact", b, c_last, p, e, _lib.ptr(cur), _lib.ptr(ps),
                           _lib.ptr(pb), _lib.ptr(c_seg), _lib.ptr(out), _lib.ptr(arg), stream)
             else:
@@ -253,10 +267,11 @@ class _FusedMLPMax(torch.autograd.Function):
         ctx.nl = len(layers)
         ctx.dims = (b, p, s)
         ctx.library_gemm = library_gemm
-        return out
+        ctx.x_is_pm = bool(x_is_pm)
+        return out, out_pm
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_out_pm=None):
         saved = ctx.saved_tensors
         nl = ctx.nl
         x, arg = saved[0], saved[1]
@@ -267,6 +282,14 @@ class _FusedMLPMax(torch.autograd.Function):
         e = p * s
         dev = x.device
         stream = _lib.stream_ptr(dev)
+        if grad_out_pm is not None:
+            # the point-major output's gradient (the level above scattered rows into it / the Q-Former's token
+            # gradient) back to the channel-major rows the BatchNorm backward walks: the ONE transpose of the pair
+            gp = grad_out_pm.contiguous()
+            g_cm = torch.empty((b, gp.shape[2], p), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("sig3d_transpose_cn", b, p, gp.shape[2], _lib.ptr(gp), _lib.ptr(g_cm), stream)
+            grad_out = g_cm if grad_out is None else grad_out + g_cm
         grad_out = grad_out.contiguous()
         grads = [None] * (3 * nl)
         grad_x = None
@@ -347,8 +370,11 @@ class _FusedMLPMax(torch.autograd.Function):
                         grad_pm = torch.empty((b, n_src, c_src), dtype=torch.float32, device=dev)
                         _lib.call("sig3d_query_group_fused_grad_pm", b, n_src, p, c_src, c_src, s, cin, 3,
                                   _lib.ptr(dA), _lib.ptr(g_idx), _lib.ptr(grad_pm), stream)
-                        grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
-                        _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
+                        if ctx.x_is_pm:
+                            grad_x = grad_pm      # the level below takes its gradient point-major
+                        else:
+                            grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
+                            _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
                 elif k == 0 and gather is not None:
                     if ctx.needs_input_grad[0]:
                         # W^T dY added straight into the point-major feature gradient at the neighbours' rows
@@ -357,8 +383,11 @@ class _FusedMLPMax(torch.autograd.Function):
                         _lib.call("sig3d_mlp_layer0_scatter_dx", b, n_src, p, s, c_src, cout, _lib.ptr(g_idx),
                                   _lib.ptr(dY), _lib.ptr(wt), _lib.ptr(grad_pm),
                                   _lib.ptr(c_nact if compact is not None else None), stream)
-                        grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
-                        _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
+                        if ctx.x_is_pm:
+                            grad_x = grad_pm
+                        else:
+                            grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
+                            _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
                 elif k > 0 or ctx.needs_input_grad[0]:
                     if ctx.library_gemm:
                         dA = torch.bmm(ws[k].t().unsqueeze(0).expand(b, cin, cout), dY.view(b, cout, e)).view(b, cin, p, s)
@@ -380,10 +409,28 @@ class _FusedMLPMax(torch.autograd.Function):
                 cout = ws[k].shape[0]
                 grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma
                 grads[3 * k + 2] = sums32[k, 0, :cout]         # d beta
-        return (grad_x, None, None, None, None) + tuple(grads)
+        return (grad_x, None, None, None, None, None, None) + tuple(grads)
 
 
-def _fused_mlp_max_eval(layers, x, compact=None, gather=None):
+def _with_pm(out, out_pm):
+    """The channel-major result with its point-major twin riding along as an attribute: the next level (or the
+    model, for the scene tokens) picks it up from the very tensor object it is handed; any op in between creates
+    a new tensor without it, and the consumer falls back to a transpose."""
+    if out_pm is not None:
+        out._pm = out_pm
+    return out
+
+
+def point_major_of(features):
+    """(B, N, C) twin of channel-major features (B, C, N), if the producer wrote one (see _with_pm)."""
+    pm = getattr(features, "_pm", None)
+    if pm is not None and pm.dim() == 3 and features.dim() == 3 and \
+            (pm.shape[0], pm.shape[2], pm.shape[1]) == tuple(features.shape) and pm.is_contiguous():
+        return pm
+    return None
+
+
+def _fused_mlp_max_eval(layers, x, compact=None, gather=None, want_pm=False, x_is_pm=False):
     """Inference: BatchNorm2d.eval() is the affine map scale = gamma / sqrt(running_var + eps),
     shift = beta - running_mean * scale, so a layer is one sig3d_mlp_layer_fwd (previous layer's
     BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool.
@@ -393,11 +440,15 @@ def _fused_mlp_max_eval(layers, x, compact=None, gather=None):
     stream = _lib.stream_ptr(dev)
     if gather is not None:   # x: the level's input features (B, C, N); first layer gathers on load
         g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
-        b, c0, n_src = x.shape
         p = g_new_xyz.shape[1]
-        feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
+        if x_is_pm:
+            b, n_src, c0 = x.shape
+            feat_pm = x
+        else:
+            b, c0, n_src = x.shape
+            feat_pm = torch.empty((b, n_src, c0), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("sig3d_transpose_cn", b, c0, n_src, _lib.ptr(x), _lib.ptr(feat_pm), stream)
     else:
         b, _, p, s = x.shape
     e = p * s
@@ -426,27 +477,34 @@ def _fused_mlp_max_eval(layers, x, compact=None, gather=None):
         c_last = cur.shape[1]
         out = torch.empty((b, c_last, p), dtype=torch.float32, device=dev)
         arg = torch.empty((b, c_last, p), dtype=torch.int32, device=dev)
-        if compact is not None:
+        out_pm = None
+        if want_pm:
+            out_pm = torch.empty((b, p, c_last), dtype=torch.float32, device=dev)
+            _lib.call("sig3d_bn_relu_maxpool_pm", b, c_last, p, s, e, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
+                      _lib.ptr(compact[3] if compact is not None else None), _lib.ptr(out), _lib.ptr(arg),
+                      _lib.ptr(out_pm), stream)
+        elif compact is not None:
             _lib.call("sig3d_bn_relu_maxpool_compact", b, c_last, p, e, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
                       _lib.ptr(compact[3]), _lib.ptr(out), _lib.ptr(arg), stream)
         else:
             _lib.call("sig3d_bn_relu_maxpool", b, c_last, p, s, _lib.ptr(cur), _lib.ptr(ps), _lib.ptr(pb),
                       _lib.ptr(out), _lib.ptr(arg), stream)
-    return out
+    return _with_pm(out, out_pm)
 
 
-def fused_mlp_max(mlp, x, library_gemm=None):
+def fused_mlp_max(mlp, x, library_gemm=None, want_pm=False):
     """max over nsample of SharedMLP(x): x (B,C,npoint,nsample) -> (B,C_out,npoint).
-    library_gemm=None: decided by the position count (MIN_POSITIONS)."""
+    library_gemm=None: decided by the position count (MIN_POSITIONS).
+    want_pm: the result carries its point-major twin (point_major_of)."""
     layers = _layers(mlp)
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, x)
+        return _fused_mlp_max_eval(layers, x, want_pm=want_pm)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
     if library_gemm is None:
         library_gemm = x.shape[0] * x.shape[2] * x.shape[3] < MIN_POSITIONS
-    return _FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, *flat)
+    return _with_pm(*_FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, bool(want_pm), False, *flat))
 
 
 # SIG3D_GATHER_L0=0: always store the grouped tensor (A/B timing; same results up to f32 summation order)
@@ -460,7 +518,7 @@ def gather_applies(features, use_xyz):
             and features.shape[1] % 32 == 0 and features.is_cuda and features.dtype == torch.float32)
 
 
-def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_xyz, normalize_xyz):
+def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_xyz, normalize_xyz, want_pm=False):
     """One set-abstraction level over the distinct neighbours only (training mode, MFMA path):
     grouped tensor -> SharedMLP -> max over the neighbourhood, same result as the dense path up to
     floating-point summation order.  compact: CompactLists of this level's ball-query result."""
@@ -468,19 +526,22 @@ def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_
     cidx, centre_of, mult, seg_off, n_act = compact.tensors()
     feats = None if features is None else features.contiguous()
     lists = (cidx, centre_of, mult, seg_off, n_act)
-    gather = None
+    gather, x_is_pm = None, False
     if gather_applies(feats, use_xyz):
         gather = (xyz.contiguous(), new_xyz.contiguous(), cidx, int(nsample), float(radius), bool(normalize_xyz))
-        x = feats
+        x = point_major_of(features)       # written by the level below's pooling kernel: no transpose launch
+        x_is_pm = x is not None
+        if x is None:
+            x = feats
     else:
         x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
                                      float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, x, lists, gather)
+        return _fused_mlp_max_eval(layers, x, lists, gather, want_pm, x_is_pm)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _FusedMLPMax.apply(x, layers, False, lists, gather, *flat)
+    return _with_pm(*_FusedMLPMax.apply(x, layers, False, lists, gather, bool(want_pm), x_is_pm, *flat))
 
 
 def dense_gather_applies(mlp, xyz, features, npoint, nsample, use_xyz):
@@ -498,20 +559,23 @@ def dense_gather_applies(mlp, xyz, features, npoint, nsample, use_xyz):
     return True
 
 
-def fused_sa_dense(mlp, xyz, new_xyz, features, ball_idx, nsample, radius, normalize_xyz):
+def fused_sa_dense(mlp, xyz, new_xyz, features, ball_idx, nsample, radius, normalize_xyz, want_pm=False):
     """One dense set-abstraction level without the grouped tensor: QueryAndGroup + SharedMLP + max-pool
     (pointnet2_modules.py:242-262) with the first layer gathering its operand from (xyz, features) through the
     ball-query lists, the weight gradient gathering it again, and the input gradient scattered by the dX product."""
     layers = _layers(mlp)
     gather = (xyz.contiguous(), new_xyz.contiguous(), ball_idx.contiguous().view(ball_idx.shape[0], -1), int(nsample),
               float(radius), bool(normalize_xyz))
-    feats = features.contiguous()
+    x = point_major_of(features)
+    x_is_pm = x is not None
+    if x is None:
+        x = features.contiguous()
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, feats, None, gather)
+        return _fused_mlp_max_eval(layers, x, None, gather, want_pm, x_is_pm)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _FusedMLPMax.apply(feats, layers, False, None, gather, *flat)
+    return _with_pm(*_FusedMLPMax.apply(x, layers, False, None, gather, bool(want_pm), x_is_pm, *flat))
 
 
 def compact_applies(mlp, xyz, features, npoint, nsample):

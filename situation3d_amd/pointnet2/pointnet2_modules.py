@@ -125,6 +125,10 @@ class PointnetSAModuleVotes(nn.Module):
 
     # compact mode is kept for a layer while at most this fraction of its (centre, sample) positions is distinct
     COMPACT_MAX_FRACTION = 0.6
+    # True: the fused paths also write the pooled features point-major (B, npoint, C) from the pooling kernel and
+    # hang that twin on the returned tensor (fused_mlp.point_major_of) -- the next level's gathers and the
+    # Q-Former's scene tokens read rows; set by a backbone that chains levels (model.PointNet2Encoder)
+    emit_point_major = False
 
     def _compact_pays(self, compact):
         """Decided ONCE per layer from the first batch it sees (one host read of the counts, outside any
@@ -155,7 +159,7 @@ class PointnetSAModuleVotes(nn.Module):
         if geometry is not None and compactable:
             new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features, compact, self.nsample,
                                                       self.grouper.radius, self.grouper.use_xyz,
-                                                      self.grouper.normalize_xyz)
+                                                      self.grouper.normalize_xyz, want_pm=self.emit_point_major)
             return new_xyz, new_features, inds
         # dense MFMA-path levels with a wide feature input: no grouped tensor either (first layer gathers on load)
         dense_gather = (self.pooling == 'max' and self.npoint is not None and not self.ret_unique_cnt
@@ -167,7 +171,8 @@ class PointnetSAModuleVotes(nn.Module):
             assert inds.shape[1] == self.npoint
             if dense_gather:
                 new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
-                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                                                        self.grouper.radius, self.grouper.normalize_xyz,
+                                                        want_pm=self.emit_point_major)
                 return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
         elif compactable:
@@ -179,11 +184,12 @@ class PointnetSAModuleVotes(nn.Module):
             if self._compact_pays(compact):
                 new_features = fused_mlp.fused_sa_compact(self.mlp_module, xyz, new_xyz, features, compact,
                                                           self.nsample, self.grouper.radius, self.grouper.use_xyz,
-                                                          self.grouper.normalize_xyz)
+                                                          self.grouper.normalize_xyz, want_pm=self.emit_point_major)
                 return new_xyz, new_features, inds
             if dense_gather:
                 new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
-                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                                                        self.grouper.radius, self.grouper.normalize_xyz,
+                                                        want_pm=self.emit_point_major)
                 return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features, idx=ball_idx)
         else:
@@ -193,7 +199,8 @@ class PointnetSAModuleVotes(nn.Module):
             if dense_gather:
                 ball_idx = pointnet2_utils.ball_query(self.grouper.radius, self.nsample, xyz, new_xyz)
                 new_features = fused_mlp.fused_sa_dense(self.mlp_module, xyz, new_xyz, features, ball_idx, self.nsample,
-                                                        self.grouper.radius, self.grouper.normalize_xyz)
+                                                        self.grouper.radius, self.grouper.normalize_xyz,
+                                                        want_pm=self.emit_point_major)
                 return new_xyz, new_features, inds
             grouped = self.grouper(xyz, new_xyz, features)
         if self.ret_unique_cnt:
@@ -203,7 +210,7 @@ class PointnetSAModuleVotes(nn.Module):
 
         if self.pooling == 'max' and fused_mlp.can_fuse(self.mlp_module, grouped_features):
             # training-mode Conv1x1+BN+ReLU stack and the max over nsample as fused MFMA kernels
-            new_features = fused_mlp.fused_mlp_max(self.mlp_module, grouped_features)
+            new_features = fused_mlp.fused_mlp_max(self.mlp_module, grouped_features, want_pm=self.emit_point_major)
             if self.ret_unique_cnt:
                 return new_xyz, new_features, inds, unique_cnt
             return new_xyz, new_features, inds

@@ -148,20 +148,27 @@ class _QueryGroupFused(Function):
     """One-kernel version of pointnet2_utils.py:348-359 (xyz / new_xyz treated as constants)."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, features, idx, radius, use_xyz, normalize_xyz):
-        dev = _lib.require_device(xyz, new_xyz, features, idx)
+    def forward(ctx, xyz, new_xyz, features, idx, radius, use_xyz, normalize_xyz, features_pm=None):
+        """features_pm: the point-major twin (B, N, C) of the features when their producer wrote one
+        (fused_mlp.point_major_of); it is then THE differentiable input (features = None), and its gradient
+        is returned point-major too -- no transpose launch in either direction."""
+        dev = _lib.require_device(xyz, new_xyz, features, idx, features_pm)
         b, n, _ = xyz.shape
         m, nsample = idx.shape[1], idx.shape[2]
-        c = 0 if features is None else features.shape[1]
+        c = features_pm.shape[2] if features_pm is not None else (0 if features is None else features.shape[1])
         c_total = (3 if use_xyz else 0) + c
         out = torch.empty((b, c_total, m, nsample), dtype=torch.float32, device=dev)
+        ctx.from_pm = features_pm is not None
         with torch.cuda.device(dev):
             if c >= POINT_MAJOR_MIN_CHANNELS and c % 4 == 0:
                 # wide levels: one coalesced row per neighbour from a point-major copy of the features
                 # (8 MB at the bench shapes) instead of c strided 4-byte gathers
-                feat_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
-                _lib.call("sig3d_transpose_cn", b, c, n, _lib.ptr(features), _lib.ptr(feat_pm),
-                          _lib.stream_ptr(dev))
+                if features_pm is not None:
+                    feat_pm = features_pm.contiguous()
+                else:
+                    feat_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_transpose_cn", b, c, n, _lib.ptr(features), _lib.ptr(feat_pm),
+                              _lib.stream_ptr(dev))
                 _lib.call("sig3d_query_group_fused_pm", b, n, m, c, c, nsample, int(use_xyz),
                           int(normalize_xyz), ctypes.c_float(radius), _lib.ptr(xyz), _lib.ptr(new_xyz),
                           _lib.ptr(feat_pm), _lib.ptr(idx), _lib.ptr(out), _lib.stream_ptr(dev))
@@ -179,6 +186,16 @@ class _QueryGroupFused(Function):
         (idx,) = ctx.saved_tensors
         b, n, m, c, nsample, c_total, c_off = ctx.dims
         grad_features = None
+        if ctx.from_pm:
+            grad_pm = None
+            if c > 0 and ctx.needs_input_grad[7]:
+                grad_out = grad_out.contiguous()
+                dev = grad_out.device
+                grad_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.call("sig3d_query_group_fused_grad_pm", b, n, m, c, c, nsample, c_total, c_off,
+                              _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_pm), _lib.stream_ptr(dev))
+            return None, None, None, None, None, None, None, grad_pm
         if c > 0 and ctx.needs_input_grad[2]:
             grad_out = grad_out.contiguous()
             dev = grad_out.device
@@ -197,7 +214,7 @@ class _QueryGroupFused(Function):
                     _lib.call("sig3d_query_group_fused_grad", b, n, m, c, nsample, c_total, c_off,
                               _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_features),
                               _lib.stream_ptr(dev))
-        return None, None, grad_features, None, None, None, None
+        return None, None, grad_features, None, None, None, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -242,9 +259,15 @@ class QueryAndGroup(nn.Module):
             (self.use_xyz or features is not None)
         if fused_ok:
             feats = None if features is None else features.contiguous()
-            fused = _QueryGroupFused.apply(xyz.contiguous(), new_xyz.contiguous(), feats, idx,
+            # the producer of `features` may have written them point-major as well (fused_mlp.point_major_of)
+            pm = getattr(features, "_pm", None) if features is not None else None
+            if pm is not None and not (pm.dim() == 3 and features.dim() == 3 and pm.is_contiguous() and pm.shape[2] % 4 == 0
+                                       and pm.shape[2] >= POINT_MAJOR_MIN_CHANNELS
+                                       and (pm.shape[0], pm.shape[2], pm.shape[1]) == tuple(features.shape)):
+                pm = None
+            fused = _QueryGroupFused.apply(xyz.contiguous(), new_xyz.contiguous(), None if pm is not None else feats, idx,
                                            float(self.radius), bool(self.use_xyz) or features is None,
-                                           bool(self.normalize_xyz))
+                                           bool(self.normalize_xyz), pm)
             new_features = fused
             grouped_xyz = None
             if self.ret_grouped_xyz:

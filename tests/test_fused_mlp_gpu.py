@@ -62,7 +62,7 @@ def test_fused_path_is_taken_by_sa_module_in_train_and_inference():
     xyz, f = scene(2, 500, seed=1).to(DEV), feats(2, 5, 500).to(DEV)
     calls = []
     orig, orig_min, orig_c = fused_mlp.fused_mlp_max, fused_mlp.MIN_POSITIONS, fused_mlp.fused_sa_compact
-    fused_mlp.fused_mlp_max = lambda m, x: calls.append(1) or orig(m, x)
+    fused_mlp.fused_mlp_max = lambda m, x, **k: calls.append(1) or orig(m, x, **k)
     # training mode above MIN_POSITIONS runs over the distinct neighbours only: also a fused path
     fused_mlp.fused_sa_compact = lambda *a, **k: calls.append(1) or orig_c(*a, **k)
     fused_mlp.MIN_POSITIONS = 0
@@ -345,3 +345,96 @@ def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monke
             assert rel < 1e-3, (n1, rel)
         for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
             _close(b1.float(), b2.float(), n1, tol=1e-5)
+
+
+@pytest.mark.parametrize("s,c,p", [(64, 5, 37), (32, 128, 70), (16, 40, 512), (24, 33, 19)])
+def test_bn_relu_maxpool_pm_writes_both_layouts(s, c, p):
+    """sig3d_bn_relu_maxpool_pm == sig3d_bn_relu_maxpool (values and first-maximum indices, bit for bit) plus the
+    point-major copy (b, p, c) the next level / the Q-Former reads -- tiles that overhang c and p included."""
+    from situation3d_amd import _lib as L
+    b = 2
+    g = torch.Generator().manual_seed(s + c)
+    y = torch.randn(b, c, p, s, generator=g)
+    y[..., s // 3:] = y[..., :1]
+    scale = (torch.rand(c, generator=g) + 0.5) * torch.where(torch.arange(c) % 7 == 3, -1.0, 1.0)
+    shift = torch.randn(c, generator=g) * 0.3
+    yd, sd, hd = y.to(DEV), scale.to(DEV), shift.to(DEV)
+    out0, arg0 = torch.empty(b, c, p, device=DEV), torch.empty(b, c, p, dtype=torch.int32, device=DEV)
+    L.call("sig3d_bn_relu_maxpool", b, c, p, s, L.ptr(yd), L.ptr(sd), L.ptr(hd), L.ptr(out0), L.ptr(arg0), L.stream_ptr())
+    out1, arg1 = torch.full((b, c, p), -7.0, device=DEV), torch.full((b, c, p), -7, dtype=torch.int32, device=DEV)
+    pm = torch.full((b, p, c), -7.0, device=DEV)
+    L.call("sig3d_bn_relu_maxpool_pm", b, c, p, s, p * s, L.ptr(yd), L.ptr(sd), L.ptr(hd), L.ptr(None), L.ptr(out1),
+           L.ptr(arg1), L.ptr(pm), L.stream_ptr())
+    assert torch.equal(out1, out0) and torch.equal(arg1, arg0)
+    assert torch.equal(pm, out0.transpose(1, 2))
+
+
+def test_bn_relu_maxpool_pm_compact_lists():
+    from situation3d_amd import _lib as L
+    b, c, p, ns = 2, 70, 45, 8
+    g = torch.Generator().manual_seed(4)
+    counts = torch.randint(1, ns + 1, (b, p), generator=g)
+    seg = torch.zeros(b, p + 1, dtype=torch.int32)
+    seg[:, 1:] = counts.cumsum(1)
+    e = p * ns
+    y = torch.randn(b, c, e, generator=g)
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    yd, sd, hd, segd = y.to(DEV), scale.to(DEV), shift.to(DEV), seg.to(DEV)
+    out0, arg0 = torch.empty(b, c, p, device=DEV), torch.empty(b, c, p, dtype=torch.int32, device=DEV)
+    L.call("sig3d_bn_relu_maxpool_compact", b, c, p, e, L.ptr(yd), L.ptr(sd), L.ptr(hd), L.ptr(segd), L.ptr(out0),
+           L.ptr(arg0), L.stream_ptr())
+    out1, arg1 = torch.empty_like(out0), torch.empty_like(arg0)
+    pm = torch.empty(b, p, c, device=DEV)
+    L.call("sig3d_bn_relu_maxpool_pm", b, c, p, ns, e, L.ptr(yd), L.ptr(sd), L.ptr(hd), L.ptr(segd), L.ptr(out1),
+           L.ptr(arg1), L.ptr(pm), L.stream_ptr())
+    assert torch.equal(out1, out0) and torch.equal(arg1, arg0) and torch.equal(pm, out0.transpose(1, 2))
+
+
+@pytest.mark.parametrize("second", ["compact-gather", "dense-gather", "library"])
+def test_chained_levels_hand_features_over_point_major_without_transposes(second, monkeypatch):
+    """Two stacked SA levels with emit_point_major: the first level's pooling kernel writes the (B, npoint, C) twin,
+    the second level gathers from it (MFMA path: first layer gathering on load; small level: point-major grouping)
+    and returns its feature gradient point-major -- same outputs bit for bit and the same gradients as the plain
+    chain, with NO transpose launch in the forward pass and ONE (the pair's) in the backward pass."""
+    import copy
+    from situation3d_amd.pointnet2 import fused_mlp
+    from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from util import scene
+    torch.manual_seed(5)
+    b, n = 2, 5000
+    xyz = scene(b, n, seed=9).to(DEV)
+    feats = torch.randn(b, 3, n, device=DEV)
+    r2, ns2, m2 = {"compact-gather": (0.15, 32, 2048), "dense-gather": (0.9, 64, 1024), "library": (0.8, 16, 256)}[second]
+    monkeypatch.setattr(fused_mlp, "COMPACT", second == "compact-gather")
+    l1 = PointnetSAModuleVotes(npoint=2048, radius=0.3, nsample=16, mlp=[3, 32, 64], use_xyz=True, normalize_xyz=True).to(DEV)
+    l2 = PointnetSAModuleVotes(npoint=m2, radius=r2, nsample=ns2, mlp=[64, 64, 128], use_xyz=True, normalize_xyz=True).to(DEV)
+    r1, r2m = copy.deepcopy(l1), copy.deepcopy(l2)
+    l1.emit_point_major = l2.emit_point_major = True
+    G = torch.randn(b, m2, 128, device=DEV)
+
+    def run(a, c, pm):
+        f = feats.clone().requires_grad_(True)
+        x1, f1, _ = a(xyz, f)
+        x2, f2, _ = c(x1, f1)
+        if pm:
+            tw = fused_mlp.point_major_of(f2)
+            assert tw is not None and torch.equal(tw, f2.transpose(1, 2))
+            (tw * G).sum().backward()                      # the consumer reads the point-major twin (the Q-Former does)
+        else:
+            (f2.transpose(1, 2) * G).sum().backward()
+        return f2.detach(), f.grad, [p.grad for p in list(a.parameters()) + list(c.parameters())]
+
+    calls = []
+    orig = fused_mlp._lib.call
+    monkeypatch.setattr(fused_mlp._lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    out1, gf1, gp1 = run(l1, l2, True)
+    assert calls.count("sig3d_bn_relu_maxpool_pm") == 2
+    # forward: none; backward: each level turns ITS point-major output gradient once
+    assert calls.count("sig3d_transpose_cn") == 2, calls
+    calls.clear()
+    out2, gf2, gp2 = run(r1, r2m, False)
+    assert "sig3d_bn_relu_maxpool_pm" not in calls
+    assert torch.equal(out1, out2)
+    _close(gf1, gf2, "input feature gradient", tol=1e-4)
+    for a, c in zip(gp1, gp2):
+        _close(a, c, "parameter gradient", tol=1e-4)
