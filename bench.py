@@ -333,8 +333,14 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
                 _lib.enable_timing(TIMED_ENTRY_POINTS)
                 if reducer is not None:
                     reducer.hooks_enabled = True
+                # the same launches as the replayed graph: geometry through a GeometryPlan (all ball queries of the
+                # stack in one launch pair), then the step over that plan
+                from situation3d_amd.geometry import GeometryPlan
+                eplan = GeometryPlan(BATCH, N_POINTS, model.encoder.LEVELS, device)
                 for i in range(KSTEPS):
-                    train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
+                    bt = dict(batches[i % n_batches])
+                    bt["geometry_plan"] = eplan.compute(bt["point_clouds"][..., :3].contiguous())
+                    train_step(model, optimizer, bt, reducer=reducer)
                 torch.cuda.synchronize()
                 recs = _lib.timing_records()
                 _lib.enable_timing(None)
@@ -400,6 +406,67 @@ def pair_roofline(recs, distinct):
     for s_ev, e_ev, ints in recs["sig3d_transpose_cn"]:   # point-major copies feeding the wide levels: pure overhead
         add("sig3d_transpose_cn", s_ev.elapsed_time(e_ev), 0)
     return t_ms, nbytes, launches, parts
+
+
+def ops_roofline(device, seed=1234):
+    """The pair as the reference's API exposes it -- ball_query + QueryAndGroup's grouping (pointnet2_utils.py:
+    260-376) -- DENSE, at the four SA shapes of BASELINE config 3 (B = 8; SURVEY.md 8d: 314.8 MB algorithmic per
+    pass), through the C ABI, every launch bracketed by HIP events on the launch stream.  The training step itself
+    has fused most of this away (compact lists at SA1 / SA2, the first SharedMLP layer gathering on load), so its
+    own pair (`roofline`) is a handful of latency-sized launches; this is the bandwidth the op kernels reach when
+    they are used the way the reference uses them."""
+    import ctypes
+    from situation3d_amd.pointnet2 import _ext
+    pc = synthetic_batch(BATCH, N_POINTS, seed, device)["point_clouds"]
+    cur = pc[..., :3].contiguous()
+    from situation3d_amd.model import PointNet2Encoder
+    radii = [lv[1] for lv in PointNet2Encoder.LEVELS]
+    probs, feats = [], []
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for (n, m, ns, c), radius in zip(SA_LEVELS, radii):
+        inds = _ext.furthest_point_sampling(cur, m)
+        nxt = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        probs.append((cur, nxt, radius, ns, torch.empty(BATCH, m, ns, dtype=torch.int32, device=device)))
+        f = torch.rand(BATCH, c, n, generator=g).to(device)
+        # wide levels read the point-major twin their producer writes (sig3d_bn_relu_maxpool_pm)
+        feats.append(f.transpose(1, 2).contiguous() if c >= 32 else f)
+        cur = nxt
+    arr = _lib.bq_levels(probs)
+    work = torch.empty(max(_lib.bq_levels_workspace_bytes(BATCH, arr), 16), dtype=torch.uint8, device=device)
+    outs = [torch.empty(BATCH, 3 + c, m, ns, device=device) for n, m, ns, c in SA_LEVELS]
+    s = _lib.stream_ptr(device)
+    reps, t_bq, t_gr = 5, [], []
+    for it in range(reps + 2):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record()
+        _lib.call("sig3d_ball_query_levels", BATCH, len(arr), arr, _lib.ptr(work), work.numel(), s)
+        ev[1].record()
+        for li, ((n, m, ns, c), (xyz, nxt, radius, _, idx)) in enumerate(zip(SA_LEVELS, probs)):
+            if c >= 32:
+                _lib.call("sig3d_query_group_fused_pm", BATCH, n, m, c, c, ns, 1, 1, ctypes.c_float(radius), _lib.ptr(xyz),
+                          _lib.ptr(nxt), _lib.ptr(feats[li]), _lib.ptr(idx), _lib.ptr(outs[li]), s)
+            else:
+                _lib.call("sig3d_query_group_fused", BATCH, n, m, c, ns, 1, 1, ctypes.c_float(radius), _lib.ptr(xyz),
+                          _lib.ptr(nxt), _lib.ptr(feats[li]), _lib.ptr(idx), _lib.ptr(outs[li]), s)
+            ev[2 + li].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            t_bq.append(ev[0].elapsed_time(ev[1]))
+            t_gr.append([ev[1 + li].elapsed_time(ev[2 + li]) for li in range(4)])
+    bq_ms = sum(t_bq) / reps
+    gr_ms = [sum(t[li] for t in t_gr) / reps for li in range(4)]
+    bq_bytes = sum(ball_query_algorithmic_bytes(BATCH, n, m, ns) for n, m, ns, _ in SA_LEVELS)
+    gr_bytes = [group_algorithmic_bytes(BATCH, n, m, ns, c) for n, m, ns, c in SA_LEVELS]
+    total_ms, total_b = bq_ms + sum(gr_ms), bq_bytes + sum(gr_bytes)
+    gbs = total_b / (total_ms * 1e-3) / 1e9
+    grp_gbs = sum(gr_bytes) / (sum(gr_ms) * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ball_query (SA1-4, one launch pair) + query_group_fused[_pm] (SA1-4), dense lists, "
+                                      "BASELINE config 3 shapes, standalone launches through the C ABI",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes": total_b, "ms": round(total_ms, 4),
+            "ball_query": {"ms": round(bq_ms, 4), "algorithmic_bytes": bq_bytes},
+            "group_points": {"ms": [round(t, 4) for t in gr_ms], "algorithmic_bytes": gr_bytes,
+                             "achieved": round(grp_gbs, 1), "frac": round(grp_gbs / HBM_PEAK_GBS, 4)}}
 
 
 def main():
@@ -487,6 +554,13 @@ def main():
                          "parts": {k: {"launches": v["launches"] // KSTEPS, "ms": round(v["ms"] / KSTEPS, 4),
                                        "algorithmic_bytes": v["algorithmic_bytes"] // KSTEPS}
                                    for k, v in pair_parts.items()},
+                         # what ANY implementation of this launch list would take at least: 1.5 us per kernel
+                         # boundary + the algorithmic bytes at the 6.3 TB/s this part's float4 copy reaches
+                         # (MI355X_MICROARCH.md); vs_floor = floor / measured
+                         "floor_model": {"launches": pair_launches // KSTEPS, "us_per_launch": 1.5, "stream_gbs": 6300.0,
+                                         "floor_ms": round((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3, 4),
+                                         "vs_floor": round(((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3)
+                                                           / (pair_ms / KSTEPS), 4) if pair_ms else None},
                          "dense_equivalent_frac": round(sum(ball_query_algorithmic_bytes(BATCH, n, m, ns)
                                                             + group_algorithmic_bytes(BATCH, n, m, ns, c)
                                                             for n, m, ns, c in SA_LEVELS) * KSTEPS
@@ -530,6 +604,8 @@ def main():
             del v
         if rank == 0:
             out["variants"] = variants
+    if rank == 0 and world == 1:
+        out["roofline_ops"] = ops_roofline(device)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             if model is None:   # the variants released the headline's model: same seed, initial weights
