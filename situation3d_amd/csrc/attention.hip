@@ -19,6 +19,7 @@
 // The reduction index of every MFMA is permuted (k-step s covers d = s and d = 32+s): sums are
 // reassociated relative to a sequential dot product, well inside the f32 tolerance.
 #include "sig3d_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,7 +145,10 @@ __device__ __forceinline__ bool at_keep(const AttnDropout &d, unsigned row_base,
 
 // ------------------------------------------------------------------------------------------
 // forward: grid (q_tiles, h, b), 256 threads.
-template <int D>
+#ifndef SIG3D_ATTN_NT
+#define SIG3D_ATTN_NT 1   // K / V of the long-key (rotating) forward are read exactly once, coalesced: non-temporal (+2 %)
+#endif
+template <int D, bool PIPE = false>
 __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_fwd_kernel(
     int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int ldq, int ldk,
     int ldv, float scale, float p_drop,
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_fwd_kernel(
   __shared__ float s_o[AT_WAVES][D][32];
   __shared__ float s_m[AT_WAVES][32];
   __shared__ float s_l[AT_WAVES][32];
+  __shared__ __attribute__((aligned(16))) float s_k[PIPE ? AT_WAVES : 1][PIPE ? 32 : 1][D + 4];   // PIPE: K staging tiles
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -257,11 +262,126 @@ __global__ __launch_bounds__(AT_WAVES * 64, 2) void attention_fwd_kernel(
       for (int j = 0; j < NB; ++j) o[j] = mfma32(va[j][s], p[s], o[j]);
     }
   };
-  for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+  if constexpr (!PIPE) {
+    for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+      float kf[DH], mk[16], va[NB][16];
+      load_tile(kf, mk, va, t);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_tile(kf, mk, va, t);
+    }
+  } else if constexpr (D == 64) {
+   if (t_begin + wave < t_end) {
+    // Long key ranges (3D-LLM shapes): ROTATING prefetch without a second operand set.  The K rows and mask values
+    // of a tile are dead once S^T and the masked scores exist, the V^T operands once the PV product has consumed
+    // them -- so the next tile's K (+ mask) is requested right after the scores, under the softmax and the PV
+    // MFMAs, and the next tile's V right after PV, under the next tile's S MFMAs: every MFMA phase of a wave has
+    // 8 KB of its own loads in flight, in the same 177 + 32 registers (two waves per SIMD).
     float kf[DH], mk[16], va[NB][16];
-    load_tile(kf, mk, va, t);
-    __builtin_amdgcn_sched_barrier(0);
-    compute_tile(kf, mk, va, t);
+    const int last = t_begin + wave + ((t_end - 1 - t_begin - wave) / AT_WAVES) * AT_WAVES;   // this wave's last tile
+    auto load_k = [&](int t) {
+      const int key0 = t * 32;
+      // COALESCED: 16 lanes read one key row of this head (256 contiguous bytes), four rows per instruction, so
+      // every cache line is requested once.  (A lane that owns a whole row -- the MFMA operand layout, as in
+      // load_half_row -- touches its two lines in eight separate instructions: 8x the L1 requests, and the
+      // non-temporal form of THAT pattern runs at 0.66x because it defeats the L1 hits it lives on.)  The rows
+      // reach the operand layout through a wave-private LDS tile right before S^T (k_to_operands).
+      static_assert(D == 64, "coalesced K staging is written for 64-wide heads");
+      constexpr bool NTLOAD = SIG3D_ATTN_NT != 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned row = tok_row(min(key0 + 4 * i + (lane >> 4), nk - 1), bi, nk, k_seg, k_base2);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 tv = NTLOAD ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(K + row * (unsigned)ldk + 4 * (lane & 15)))
+                             : *reinterpret_cast<const f4 *>(K + row * (unsigned)ldk + 4 * (lane & 15));
+        kf[4 * i + 0] = tv.x; kf[4 * i + 1] = tv.y; kf[4 * i + 2] = tv.z; kf[4 * i + 3] = tv.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[r] = Mz[min(key0 + mfma_row(r, half), nk - 1)];
+    };
+    auto load_v = [&](int t) {
+      constexpr bool NTLOAD = SIG3D_ATTN_NT != 0;
+      const int key0 = t * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned voff = tok_row(min(key0 + mfma_row(r, half), nk - 1), bi, nk, k_seg, k_base2) * (unsigned)ldv + l31;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) va[j][r] = NTLOAD ? __builtin_nontemporal_load(V + voff + 32 * j) : V[voff + 32 * j];
+      }
+    };
+    float(*sk)[D + 4] = s_k[wave];
+    auto k_to_operands = [&]() {   // staged rows -> lane (key l31, half) holds its 32 floats
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<float4 *>(&sk[4 * i + (lane >> 4)][4 * (lane & 15)]) =
+            make_float4(kf[4 * i + 0], kf[4 * i + 1], kf[4 * i + 2], kf[4 * i + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float4 tv = *reinterpret_cast<const float4 *>(&sk[l31][half * DH + 4 * i]);
+        kf[4 * i + 0] = tv.x; kf[4 * i + 1] = tv.y; kf[4 * i + 2] = tv.z; kf[4 * i + 3] = tv.w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();   // the tile is free for the next staging only after every lane has read
+    };
+    load_k(t_begin + wave);
+    load_v(t_begin + wave);
+    for (int t = t_begin + wave; t < t_end; t += AT_WAVES) {
+      const int key0 = t * 32;
+      const int tn = min(t + AT_WAVES, last);   // past the end: the last tile again (an L2 hit that nobody reads)
+      __builtin_amdgcn_sched_barrier(0);
+      k_to_operands();
+      f32x16 st = {0};
+#pragma unroll
+      for (int s2 = 0; s2 < DH; ++s2) st = mfma32(kf[s2], qf[s2], st);  // S^T[key][q]
+      float p[16];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + mfma_row(r, half);
+        float sv = st[r] * scale;
+        sv += has_mask ? mk[r] : 0.f;
+        sv = key < nk ? sv : -INFINITY;
+        p[r] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_k(tn);
+      __builtin_amdgcn_sched_barrier(0);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __expf(m_run - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __expf(p[r] - m_new);
+        rs += p[r];
+      }
+      if (drop.on) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const unsigned hsh = at_pair_hash(drop, row_base, key0 + mfma_row(r, half));
+          p[r] = (hsh & 0xFFFFu) >= drop.thresh ? p[r] * drop.inv_keep : 0.f;
+          p[r + 1] = (hsh >> 16) >= drop.thresh ? p[r + 1] * drop.inv_keep : 0.f;
+        }
+      }
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {  // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int j = 0; j < NB; ++j) o[j] = mfma32(va[j][s2], p[s2], o[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(tn);
+    }
+   }
   }
 
   // combine the AT_WAVES partial (m, l, O^T) triples
@@ -870,10 +990,20 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   dim3 grid(h, ((nq + 31) / 32) * key_splits, b);
   (void)k_rows;
   const long rows = (long)b * h * nq;
+  // rotating K / V prefetch when a wave streams many key tiles (3D-LLM shapes); SIG3D_ATTN_FWD_PIPE=0/1 forces it
+  static const char *pipe_env = getenv("SIG3D_ATTN_FWD_PIPE");
+  const int tiles_per_wave = ntiles_fwd / (key_splits * AT_WAVES);
+  // (head size 64 only: at 96 the rotating form spills)
+  const bool pipe = d == 64 && (pipe_env ? pipe_env[0] == '1' : tiles_per_wave >= 4);
 #define SIG3D_ATT_FWD(DD)                                                                                         \
-  hipLaunchKernelGGL((attention_fwd_kernel<DD>), grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg, k_seg,    \
-                     q_base2, k_base2, q_rows, ldq, ldk, ldv, scale, p_drop, call_id, rng_counter, q, k, v, mask,  \
-                     out, lse, key_splits, workspace)
+  if (pipe)                                                                                                       \
+    hipLaunchKernelGGL((attention_fwd_kernel<64, true>), grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg,   \
+                       k_seg, q_base2, k_base2, q_rows, ldq, ldk, ldv, scale, p_drop, call_id, rng_counter, q, k,  \
+                       v, mask, out, lse, key_splits, workspace);                                                  \
+  else                                                                                                            \
+    hipLaunchKernelGGL((attention_fwd_kernel<DD, false>), grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg,  \
+                       k_seg, q_base2, k_base2, q_rows, ldq, ldk, ldv, scale, p_drop, call_id, rng_counter, q, k,  \
+                       v, mask, out, lse, key_splits, workspace)
   if (d == 64) {
     SIG3D_ATT_FWD(64);
     if (key_splits > 1)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from situation3d_amd import _lib as L
 from situation3d_amd.qformer import _fwd_key_splits
 dev = torch.device("cuda", 0)
-def timeit(fn, iters=10, warm=2):
+def timeit(fn, iters=30, warm=50):   # the clocks of an idle GPU ramp over the first ~20 ms: 52 vs 69 TFLOP/s for the same kernel
     for _ in range(warm): fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
