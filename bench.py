@@ -469,6 +469,43 @@ def ops_roofline(device, seed=1234):
                              "achieved": round(grp_gbs, 1), "frac": round(grp_gbs / HBM_PEAK_GBS, 4)}}
 
 
+def forward_only_variant(device, bsz=4, reps=20):
+    from situation3d_amd.serve import PipelinedForward
+    torch.manual_seed(1234)
+    model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).eval()
+    bs = [synthetic_batch(bsz, N_POINTS, 5000 + i, device) for i in range(4)]
+    work = torch.cuda.Stream(device)
+    with torch.cuda.stream(work), torch.no_grad():
+        for _ in range(3):
+            model(dict(bs[0]))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with gemm_tuning.no_tuning(), torch.cuda.graph(g, stream=work):
+            model(dict(bs[0]))
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - t0) / reps
+        pipe = PipelinedForward(model, bs[0], depth=2, high_priority=False)
+        for i in range(6):
+            pipe(bs[i % 4], [bs[(i + 1 + k) % 4] for k in range(2)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(6, 6 + 2 * reps):
+            pipe(bs[i % 4], [bs[(i + 1 + k) % 4] for k in range(2)])
+        torch.cuda.synchronize()
+        piped = (time.perf_counter() - t0) / (2 * reps)
+    del pipe, g, model
+    torch.cuda.empty_cache()
+    return {"single_batch_latency_ms": round(single * 1e3, 3), "single_batch_samples_per_s": round(bsz / single, 1),
+            "pipelined_ms_per_batch": round(piped * 1e3, 3), "value": round(bsz / piped, 1), "unit": "samples/s",
+            "batch": bsz, "note": "hipGraph replay of one forward; and two geometry chains in flight (serve.PipelinedForward)"}
+
+
 def main():
     args = parse_args()
 
@@ -602,6 +639,10 @@ def main():
                              "compact_levels": v["compact_info"], "distinct_neighbour_fraction": v["distinct"],
                              "final_loss": round(v["final_loss"], 5)}
             del v
+        # BASELINE config 2 (forward only, B = 4, eval mode, no autograd): the latency of ONE batch through a captured
+        # graph (bound by the 2047 dependent FPS rounds of SA1) and the throughput with geometry chains of two
+        # batches in flight (serve.PipelinedForward)
+        variants["config 2: forward only, B=4"] = forward_only_variant(device)
         if rank == 0:
             out["variants"] = variants
     if rank == 0 and world == 1:

@@ -17,10 +17,28 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# gradient bounds = ~2x the worst value observed on MI355X (SIG3D_TEST_REPORT=1 pytest -s prints them)
+ENC_GRAD_TOL = 8e-3       # point-encoder weights: 1 M positions x 8 scenes through BatchNorm batch statistics and
+                          # max-pool winners, float atomics vs MKL order; observed 2.4e-3 .. 3.7e-3 from run to run
+QF_GRAD_TOL = 2e-5        # Q-Former / head parameters and inputs: observed 1.6e-6 .. 5.2e-6 (was 1e-3 until round 3)
 
 
 def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+_OBSERVED = {}
+
+
+def _within(what, r, bound):
+    """assert r < bound; the worst value seen per class of check is printed by `pytest -s` when SIG3D_TEST_REPORT is
+    set (how the bounds below were chosen: ~2x the observed worst)."""
+    import os
+    key = what.split(":")[0]
+    _OBSERVED[key] = max(_OBSERVED.get(key, 0.0), r)
+    if os.environ.get("SIG3D_TEST_REPORT"):
+        print("[observed] %-40s worst %.3g (bound %.3g)" % (key, _OBSERVED[key], bound))
+    assert r < bound, "%s: relative max error %.3g (bound %.3g)" % (what, r, bound)
 
 
 def _is_key_bias(name):
@@ -90,8 +108,9 @@ def test_config3_sqa3d_train_forward_b8_40k_matches_oracle():
                     "encoder.sa2.mlp_module.layer1.bn.bn.weight"):
             r = _rel(p.grad.cpu(), cpu_params[name].grad)
             # both sides are f32; a weight gradient of SA1 sums 1 M positions x 8 scenes through BatchNorm's
-            # batch statistics in a different order (MFMA tiles + float atomics vs MKL): observed 2.4e-3
-            assert r < 5e-3, "grad %s: relative max error %.3g" % (name, r)
+            # batch statistics in a different order (MFMA tiles + float atomics vs MKL)
+            enc = name.startswith("encoder.")
+            _within(("config3 encoder grad: " if enc else "config3 head/Q-Former grad: ") + name, r, ENC_GRAD_TOL if enc else QF_GRAD_TOL)
             checked += 1
     assert checked == 8
 
@@ -146,12 +165,12 @@ def test_config5_blip2_reference_shape_nk5000_forward_backward_matches_oracle():
     out = gpu({"pc_feat": f, "pc": samples["pc"].to(DEV)})
     (out["inputs_t5"] * G.to(DEV)).sum().backward()
     assert _rel(out["inputs_t5"].detach().cpu(), t5.detach()) < 1e-4
-    assert _rel(f.grad.cpu(), feat.grad) < 1e-3                    # 1408-long dot products, 12 layers deep
+    _within("config5 d/d pc_feat (Nk=5000)", _rel(f.grad.cpu(), feat.grad), QF_GRAD_TOL)   # 1408-long dot products, 12 layers deep
     n = 0
     for name, p in gpu.named_parameters():
         if ("crossattention.self" in name or name in ("query_tokens", "t5_proj.weight")) and not _is_key_bias(name):
             r = _rel(p.grad.cpu(), ref_grads[name])
-            assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
+            _within("config5 cross-attention grad: " + name, r, QF_GRAD_TOL)
             n += 1
     assert n >= 6 * 5
 
@@ -172,12 +191,12 @@ def test_config5_blip2_shape_nk80000_forward_backward_matches_oracle():
     out = gpu({"pc_feat": f, "pc": samples["pc"].to(DEV)})
     (out["inputs_t5"] * G.to(DEV)).sum().backward()
     assert _rel(out["inputs_t5"].detach().cpu(), t5.detach()) < 1e-4      # north-star fp32 bar
-    assert _rel(f.grad.cpu(), feat.grad) < 1e-3
+    _within("config5 d/d pc_feat (Nk=80000)", _rel(f.grad.cpu(), feat.grad), QF_GRAD_TOL)
     n = 0
     for name, p in gpu.named_parameters():
         if ("crossattention.self" in name or name in ("query_tokens", "t5_proj.weight")) and not _is_key_bias(name):
             r = _rel(p.grad.cpu(), ref_grads[name])
-            assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
+            _within("config5 cross-attention grad: " + name, r, QF_GRAD_TOL)
             n += 1
     assert n >= 6 * 5
 
@@ -221,8 +240,8 @@ def test_full_size_qformer_forward_backward_matches_oracle():
                    encoder_hidden_states=e, return_dict=True).last_hidden_state
     (out * G.to(DEV)).sum().backward()
     assert _rel(out.detach().cpu(), ref.detach()) < 1e-4           # north-star fp32 bar
-    assert _rel(e.grad.cpu(), e_ref.grad) < 1e-3
-    assert _rel(q.grad.cpu(), q_ref.grad) < 1e-3
+    _within("full-size Q-Former d/d scene tokens", _rel(e.grad.cpu(), e_ref.grad), QF_GRAD_TOL)
+    _within("full-size Q-Former d/d query tokens", _rel(q.grad.cpu(), q_ref.grad), QF_GRAD_TOL)
     worst, n = 0.0, 0
     for name, p in gpu.bert.named_parameters():
         if _is_key_bias(name):
@@ -234,5 +253,5 @@ def test_full_size_qformer_forward_backward_matches_oracle():
         else:
             r = _rel(p.grad.cpu(), ref_grads[name])
         worst, n = max(worst, r), n + 1
-        assert r < 1e-3, "grad %s: relative max error %.3g" % (name, r)
+        _within("full-size Q-Former grad: " + name, r, QF_GRAD_TOL)
     assert n > 230, n
