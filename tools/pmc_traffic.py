@@ -14,7 +14,7 @@ import re
 import sys
 
 fetch_dir, write_dir, dst, cmd, commit = sys.argv[1:6]
-PATS = ("query_group", "ball_query", "bqg_", "transpose_cn_kernel")
+PATS = ("query_group", "ball_query", "bqg_", "bqc_", "transpose_cn_kernel")
 STEPS = 1 + 2 + 3   # warm-up + timed + event-bracketed eager steps of the command above
 
 
