@@ -43,6 +43,8 @@ def parse_args(argv=None):
                     help="use the data-parallel code path (flat gradient buckets, two graphs) at N=1")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="library GEMMs with the default heuristic instead of the tuned solutions")
+    ap.add_argument("--no-ops-roofline", action="store_true",
+                    help="skip the stand-alone dense op-level pair (roofline_ops); for --pmc passes over the step's own kernels")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute FPS/ball-query geometry inline instead of one batch ahead")
     return ap.parse_args(argv)
@@ -645,7 +647,7 @@ def main():
         variants["config 2: forward only, B=4"] = forward_only_variant(device)
         if rank == 0:
             out["variants"] = variants
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_ops_roofline:
         out["roofline_ops"] = ops_roofline(device)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -570,6 +570,15 @@ int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const float *y, c
 int sig3d_bn_relu_maxpool_pm(int b, int c, int p, int s, long e, const float *y, const float *scale,
                              const float *shift, const int *seg_off, float *out, int *arg, float *out_pm,
                              void *stream);
+/* The max-pool gradient arriving point-major, dout_pm (b,p,c) (the twin sig3d_bn_relu_maxpool_pm handed on): one
+ * launch writes its channel-major copy dout_cm (b,c,p) AND the top layer's BatchNorm-backward statistics
+ * s1 = sum dZ, s2 = sum dZ*xhat (zeroed here unless accumulate).  Follow with sig3d_bn_relu_bwd[_compact](...,
+ * dOut = dout_cm, ..., accumulate = 2): 2 = "statistics are complete, skip that pass".
+ * seg_off NULL: dense lists (y (b,c,p,s), e ignored); else compact lists (y (b,c,e) rows, s ignored). */
+int sig3d_bn_relu_bwd_top_from_pm(int b, int c, int p, int s, long e, const float *dout_pm, const int *arg,
+                                  const float *y, const float *scale, const float *shift, const float *mean,
+                                  const float *invstd, const int *seg_off, float *dout_cm, double *s1, double *s2,
+                                  int accumulate, void *stream);
 int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const float *dA, const float *dOut, const int *arg,
                               const float *y, const float *scale, const float *shift, const float *mean,
                               const float *invstd, double *s1, double *s2, float *dY, int accumulate,

@@ -898,6 +898,56 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_fix_c_kernel(
   if (y[u] * sc + sh > 0.f) dY[u] += sc * dOut[grow + j];  // one writer per position: segments are disjoint
 }
 
+// ---- the max-pool gradient arriving POINT-MAJOR ---------------------------------------------------------------
+// A level that handed its pooled features on point-major (bn_relu_maxpool_pm) gets their gradient back the same
+// way: dOut_pm (b, P, c) -- rows scattered by the level above, or the Q-Former's token gradient.  The BatchNorm
+// backward below walks channel-major rows; instead of a transpose launch in front of it, this kernel turns the
+// tile through LDS (64-byte runs in, coalesced rows out), writes the channel-major copy the apply / fix kernels
+// read, and takes the top layer's statistics S1 = sum dZ, S2 = sum dZ * xhat on the way (what
+// bn_relu_bwd_top_stats[_c] computes): transpose + statistics pass = ONE launch.
+// seg == nullptr: dense lists (arg-max sample of centre j is y[(grow + j) * S + arg]); else compact segments.
+__global__ __launch_bounds__(256) void bn_relu_bwd_top_from_pm_kernel(
+    int c, int P, int S, long E, const float *__restrict__ dout_pm, const int *__restrict__ arg,
+    const float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const int *__restrict__ seg_all,
+    float *__restrict__ dout_cm, double *__restrict__ s1, double *__restrict__ s2) {
+  __shared__ float tile[PM_TC][65];
+  const int bi = blockIdx.z, c0 = blockIdx.y * PM_TC, p0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {   // 64 centres x 16 channels, a centre's 16 channels adjacent
+    const int i = it * 256 + tid, pp = i / PM_TC, cc = i % PM_TC;
+    tile[cc][pp] = (p0 + pp < P && c0 + cc < c) ? dout_pm[((size_t)bi * P + p0 + pp) * c + c0 + cc] : 0.f;
+  }
+  __syncthreads();
+  const int lane = tid & 63, w = tid >> 6;
+  const int j = p0 + lane;
+#pragma unroll
+  for (int it = 0; it < PM_TC / 4; ++it) {   // a wave = one channel's 64 centres
+    const int cc = it * 4 + w, ch = c0 + cc;
+    if (ch >= c) break;   // wave-uniform
+    float a1 = 0.f, a2 = 0.f;
+    if (j < P) {
+      const float g = tile[cc][lane];
+      const size_t grow = ((size_t)bi * c + ch) * (size_t)P;
+      dout_cm[grow + j] = g;
+      const int a = arg[grow + j];
+      const size_t u = seg_all ? ((size_t)bi * c + ch) * (size_t)E + seg_all[(size_t)bi * (P + 1) + j] + a
+                               : (grow + j) * (size_t)S + a;
+      const float yv = y[u];
+      const float dz = (yv * scale[ch] + shift[ch] > 0.f) ? g : 0.f;
+      a1 = dz;
+      a2 = dz * ((yv - mean[ch]) * invstd[ch]);
+    }
+    a1 = wave_allreduce_sum_f32(a1);
+    a2 = wave_allreduce_sum_f32(a2);
+    if (lane == 0) {
+      unsafeAtomicAdd(s1 + ch, (double)a1);
+      unsafeAtomicAdd(s2 + ch, (double)a2);
+    }
+  }
+}
+
 // ---- stand-alone batch statistics / BN+ReLU apply (small levels: the 1x1 conv is a library GEMM) ----
 // sum(y), sum(y^2) per channel of y (B, C, E); same launch geometry as the backward statistics.
 __global__ __launch_bounds__(BNB_THREADS) void channel_stats_kernel(int c, long E, const float *__restrict__ y,
@@ -1364,8 +1414,9 @@ extern "C" int sig3d_bn_relu_bwd(int b, int c, long e, int s, const float *dA, c
   } else {
     const int P = (int)(e / s);
     dim3 tgrid(P >= 4 * BNB_THREADS ? 4 : 1, c, b);
-    hipLaunchKernelGGL(bn_relu_bwd_top_stats_kernel, tgrid, dim3(BNB_THREADS), 0, stream, c, P, s, dOut,
-                       arg, y, scale, shift, mean, invstd, s1, s2);
+    if (accumulate != 2)   // 2: sig3d_bn_relu_bwd_top_from_pm has taken the statistics already
+      hipLaunchKernelGGL(bn_relu_bwd_top_stats_kernel, tgrid, dim3(BNB_THREADS), 0, stream, c, P, s, dOut,
+                         arg, y, scale, shift, mean, invstd, s1, s2);
     hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<true>), grid, dim3(BNB_THREADS), 0, stream, c, e, s,
                        count, dA, dOut, arg, y, scale, shift, mean, invstd, s1, s2, dY);
   }
@@ -1542,6 +1593,21 @@ extern "C" int sig3d_bn_relu_maxpool_pm(int b, int c, int p, int s, long e, cons
   return 0;
 }
 
+extern "C" int sig3d_bn_relu_bwd_top_from_pm(int b, int c, int p, int s, long e, const float *dout_pm, const int *arg,
+                                             const float *y, const float *scale, const float *shift,
+                                             const float *mean, const float *invstd, const int *seg_off,
+                                             float *dout_cm, double *s1, double *s2, int accumulate, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && c >= 1 && p >= 0 && s >= 1 && e >= 0, "bad size");
+  SIG3D_REQUIRE(dout_pm && arg && y && dout_cm && s1 && s2, "null argument");
+  if (int rc = zero_pair(s1, s2, c, accumulate, stream)) return rc;
+  if (b == 0 || p == 0) return 0;
+  hipLaunchKernelGGL(bn_relu_bwd_top_from_pm_kernel, dim3(sig3d_ceil_div(p, 64), sig3d_ceil_div(c, PM_TC), b), dim3(256), 0,
+                     stream, c, p, s, e, dout_pm, arg, y, scale, shift, mean, invstd, seg_off, dout_cm, s1, s2);
+  SIG3D_LAUNCH_CHECK("bn_relu_bwd_top_from_pm_kernel");
+  return 0;
+}
+
 extern "C" int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const float *dA, const float *dOut,
                                          const int *arg, const float *y, const float *scale, const float *shift,
                                          const float *mean, const float *invstd, double *s1, double *s2,
@@ -1564,8 +1630,9 @@ extern "C" int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const floa
                        dOut, arg, y, scale, shift, mean, invstd, n_act, mult, centre_of, seg_off, s1, s2, dY);
   } else {
     dim3 ggrid(sig3d_ceil_div(p, BNB_THREADS), c, b);
-    hipLaunchKernelGGL(bn_relu_bwd_top_stats_c_kernel, dim3(p >= 4 * BNB_THREADS ? 4 : 1, c, b), dim3(BNB_THREADS), 0,
-                       stream, c, e, p, dOut, arg, y, scale, shift, mean, invstd, seg_off, s1, s2);
+    if (accumulate != 2)   // 2: sig3d_bn_relu_bwd_top_from_pm has taken the statistics already
+      hipLaunchKernelGGL(bn_relu_bwd_top_stats_c_kernel, dim3(p >= 4 * BNB_THREADS ? 4 : 1, c, b), dim3(BNB_THREADS), 0,
+                         stream, c, e, p, dOut, arg, y, scale, shift, mean, invstd, seg_off, s1, s2);
     hipLaunchKernelGGL(bn_relu_bwd_top_sweep_c_kernel, grid, dim3(BNB_THREADS), 0, stream, c, e, count, y, scale, mean,
                        invstd, n_act, mult, s1, s2, dY);
     hipLaunchKernelGGL(bn_relu_bwd_top_fix_c_kernel, ggrid, dim3(BNB_THREADS), 0, stream, c, e, p, dOut, arg, y, scale,

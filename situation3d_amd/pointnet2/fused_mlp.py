@@ -282,14 +282,19 @@ class _FusedMLPMax(torch.autograd.Function):
         e = p * s
         dev = x.device
         stream = _lib.stream_ptr(dev)
-        if grad_out_pm is not None:
-            # the point-major output's gradient (the level above scattered rows into it / the Q-Former's token
-            # gradient) back to the channel-major rows the BatchNorm backward walks: the ONE transpose of the pair
+        top_from_pm = None
+        if grad_out_pm is not None and grad_out is None:
+            # the point-major output's gradient (rows scattered by the level above / the Q-Former's token gradient):
+            # turned to the channel-major rows the BatchNorm backward walks INSIDE the top layer's statistics pass
+            # (sig3d_bn_relu_bwd_top_from_pm, below) -- no transpose launch
+            top_from_pm = grad_out_pm.contiguous()
+            grad_out = torch.empty((b, top_from_pm.shape[2], p), dtype=torch.float32, device=dev)
+        elif grad_out_pm is not None:   # both layouts were consumed: one transpose, one add
             gp = grad_out_pm.contiguous()
             g_cm = torch.empty((b, gp.shape[2], p), dtype=torch.float32, device=dev)
             with torch.cuda.device(dev):
                 _lib.call("sig3d_transpose_cn", b, p, gp.shape[2], _lib.ptr(gp), _lib.ptr(g_cm), stream)
-            grad_out = g_cm if grad_out is None else grad_out + g_cm
+            grad_out = grad_out + g_cm
         grad_out = grad_out.contiguous()
         grads = [None] * (3 * nl)
         grad_x = None
@@ -326,18 +331,25 @@ class _FusedMLPMax(torch.autograd.Function):
                 scale, shift, mean, invstd = _aff_rows(affs[k])
                 sums = sums_all[k]
                 dY = torch.empty_like(ys[k])
+                acc = 1          # the accumulators were zeroed by the one fill above
+                if k == nl - 1 and top_from_pm is not None:
+                    _lib.call("sig3d_bn_relu_bwd_top_from_pm", b, cout, p, s, e, _lib.ptr(top_from_pm), _lib.ptr(arg),
+                              _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd),
+                              _lib.ptr(c_seg if compact is not None else None), _lib.ptr(grad_out), _lib.ptr(sums[0]),
+                              _lib.ptr(sums[1]), 1, stream)
+                    acc = 2      # statistics complete: the launch below skips its top-statistics pass
                 if compact is not None:
                     top = k == nl - 1
                     _lib.call("sig3d_bn_relu_bwd_compact", b, cout, e, p, _lib.ptr(None if top else dA),
                               _lib.ptr(grad_out if top else None), _lib.ptr(arg if top else None), _lib.ptr(ys[k]),
                               _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]),
-                              _lib.ptr(sums[1]), _lib.ptr(dY), 1, _lib.ptr(c_nact), _lib.ptr(c_mult),
+                              _lib.ptr(sums[1]), _lib.ptr(dY), acc, _lib.ptr(c_nact), _lib.ptr(c_mult),
                               _lib.ptr(c_cent), _lib.ptr(c_seg), stream)
                 elif k == nl - 1:
                     _lib.call("sig3d_bn_relu_bwd", b, cout, e, s, _lib.ptr(None), _lib.ptr(grad_out),
                               _lib.ptr(arg), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),
                               _lib.ptr(mean), _lib.ptr(invstd), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
-                              _lib.ptr(dY), 1, stream)
+                              _lib.ptr(dY), acc, stream)
                 else:
                     _lib.call("sig3d_bn_relu_bwd", b, cout, e, s, _lib.ptr(dA), _lib.ptr(None),
                               _lib.ptr(None), _lib.ptr(ys[k]), _lib.ptr(scale), _lib.ptr(shift),

@@ -395,7 +395,7 @@ def test_chained_levels_hand_features_over_point_major_without_transposes(second
     """Two stacked SA levels with emit_point_major: the first level's pooling kernel writes the (B, npoint, C) twin,
     the second level gathers from it (MFMA path: first layer gathering on load; small level: point-major grouping)
     and returns its feature gradient point-major -- same outputs bit for bit and the same gradients as the plain
-    chain, with NO transpose launch in the forward pass and ONE (the pair's) in the backward pass."""
+    chain, with NO transpose launch in either pass."""
     import copy
     from situation3d_amd.pointnet2 import fused_mlp
     from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
@@ -429,8 +429,10 @@ def test_chained_levels_hand_features_over_point_major_without_transposes(second
     monkeypatch.setattr(fused_mlp._lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
     out1, gf1, gp1 = run(l1, l2, True)
     assert calls.count("sig3d_bn_relu_maxpool_pm") == 2
-    # forward: none; backward: each level turns ITS point-major output gradient once
-    assert calls.count("sig3d_transpose_cn") == 2, calls
+    # no transpose launch in either direction: the point-major output gradient is turned inside the top layer's
+    # statistics pass of each level
+    assert calls.count("sig3d_transpose_cn") == 0, calls
+    assert calls.count("sig3d_bn_relu_bwd_top_from_pm") == 2
     calls.clear()
     out2, gf2, gp2 = run(r1, r2m, False)
     assert "sig3d_bn_relu_maxpool_pm" not in calls
@@ -438,3 +440,65 @@ def test_chained_levels_hand_features_over_point_major_without_transposes(second
     _close(gf1, gf2, "input feature gradient", tol=1e-4)
     for a, c in zip(gp1, gp2):
         _close(a, c, "parameter gradient", tol=1e-4)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_top_layer_backward_from_a_point_major_pool_gradient(compact):
+    """sig3d_bn_relu_bwd_top_from_pm: the point-major pool gradient -> its channel-major copy + the top layer's
+    statistics in one launch; followed by sig3d_bn_relu_bwd[_compact](accumulate = 2) it must give the dY and the
+    sums of the plain (channel-major gradient) call."""
+    from situation3d_amd import _lib as L
+    b, c, p, ns = 2, 70, 150, 16
+    g = torch.Generator().manual_seed(9 + compact)
+    e = p * ns
+    y = torch.randn(b, c, e, generator=g).to(DEV)
+    scale = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(c, generator=g) * 0.2).to(DEV)
+    mean = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    invstd = (torch.rand(c, generator=g) + 0.5).to(DEV)
+    dout = torch.randn(b, c, p, generator=g).to(DEV)
+    dout_pm = dout.transpose(1, 2).contiguous()
+    if compact:
+        counts = torch.randint(1, ns + 1, (b, p), generator=g)
+        seg = torch.zeros(b, p + 1, dtype=torch.int32)
+        seg[:, 1:] = counts.cumsum(1)
+        n_act = seg[:, -1].clone().to(DEV)
+        arg = (torch.rand(b, c, p, generator=g) * counts[:, None, :]).floor().to(torch.int32).to(DEV)
+        cent = torch.zeros(b, e, dtype=torch.int32)
+        mult = torch.ones(b, e)
+        for bi in range(b):
+            cent[bi, :int(seg[bi, -1])] = torch.repeat_interleave(torch.arange(p, dtype=torch.int32), counts[bi])
+            mult[bi, seg[bi, :-1].long()] = (ns - counts[bi] + 1).float()
+        seg, cent, mult = seg.to(DEV), cent.to(DEV), mult.to(DEV)
+    else:
+        arg = torch.randint(0, ns, (b, c, p), generator=g, dtype=torch.int32).to(DEV)
+
+    def run(from_pm):
+        sums = torch.zeros(2, c, dtype=torch.float64, device=DEV)
+        dY = torch.zeros(b, c, e, device=DEV)
+        d_cm, acc = dout, 1
+        if from_pm:
+            d_cm = torch.full((b, c, p), 7.0, device=DEV)
+            L.call("sig3d_bn_relu_bwd_top_from_pm", b, c, p, ns, e, L.ptr(dout_pm), L.ptr(arg), L.ptr(y), L.ptr(scale),
+                   L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(seg if compact else None), L.ptr(d_cm), L.ptr(sums[0]),
+                   L.ptr(sums[1]), 1, L.stream_ptr())
+            assert torch.equal(d_cm, dout)
+            acc = 2
+        if compact:
+            L.call("sig3d_bn_relu_bwd_compact", b, c, e, p, L.ptr(None), L.ptr(d_cm), L.ptr(arg), L.ptr(y), L.ptr(scale),
+                   L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(dY), acc, L.ptr(n_act),
+                   L.ptr(mult), L.ptr(cent), L.ptr(seg), L.stream_ptr())
+        else:
+            L.call("sig3d_bn_relu_bwd", b, c, e, ns, L.ptr(None), L.ptr(d_cm), L.ptr(arg), L.ptr(y), L.ptr(scale), L.ptr(shift),
+                   L.ptr(mean), L.ptr(invstd), L.ptr(sums[0]), L.ptr(sums[1]), L.ptr(dY), acc, L.stream_ptr())
+        return dY, sums
+
+    dY0, s0 = run(False)
+    dY1, s1 = run(True)
+    torch.testing.assert_close(s1, s0, rtol=1e-6, atol=1e-6)
+    if compact:   # positions beyond n_act are undefined in compact mode
+        for bi in range(b):
+            n = int(n_act[bi])
+            torch.testing.assert_close(dY1[bi, :, :n], dY0[bi, :, :n], rtol=1e-5, atol=1e-6)
+    else:
+        torch.testing.assert_close(dY1, dY0, rtol=1e-5, atol=1e-6)

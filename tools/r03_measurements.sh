@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r03 -o r -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants > $O/prof_r03.log 2>&1
 rm -f $O/prof_r03/r_kernel_trace.csv
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r03_F -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline > /dev/null 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_r03_W -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r03_F -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline --no-ops-roofline > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_r03_W -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline --no-ops-roofline > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_r03_att -o r -- python3 $R/tools/attn_bench.py 256 80000 > $O/pmc_r03_att.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r03_attF -o r -- python3 $R/tools/attn_bench.py 80000 > /dev/null 2>&1
 cd $R
