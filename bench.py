@@ -276,7 +276,8 @@ def cpu_baseline(model, seed):
 
 TIMED_ENTRY_POINTS = ["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
                       "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query",
-                      "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_furthest_point_sampling"]
+                      "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_furthest_point_sampling",
+                      "sig3d_sa_first_layer_fwd", "sig3d_sa_first_layer_dw"]
 KSTEPS = 3   # eager steps bracketed with HIP events after the timed region
 
 
@@ -618,7 +619,10 @@ def main():
                                     "query_group_compact": round(sum(cgrp) / KSTEPS, 4),
                                     "point_major_transposes": round(sum(tr) / KSTEPS, 4),
                                     "ball_query": round(sum(bq) / KSTEPS, 4),
-                                    "furthest_point_sampling": round(sum(fps) / KSTEPS, 4)},
+                                    "furthest_point_sampling": round(sum(fps) / KSTEPS, 4),
+                                    # SA1's first SharedMLP layer formed from the raw point-major scan (no grouping launch)
+                                    "sa_first_layer_fwd": round(sum(kernel_ms("sig3d_sa_first_layer_fwd")) / KSTEPS, 4),
+                                    "sa_first_layer_dw": round(sum(kernel_ms("sig3d_sa_first_layer_dw")) / KSTEPS, 4)},
             "compact_levels": head["compact_info"],
             "distinct_neighbour_fraction": head["distinct"],
             "launch_mode": "hipGraph replay" if head["use_graph"] else "eager",

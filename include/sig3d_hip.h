@@ -563,6 +563,24 @@ int sig3d_mlp_layer_dw_compact(int b, int cin, int cout, long e, const float *dY
 /* arg = offset of the first maximum inside the centre's segment */
 int sig3d_bn_relu_maxpool_compact(int b, int c, int p, long e, const float *y, const float *scale,
                                   const float *shift, const int *seg_off, float *out, int *arg, void *stream);
+/* The FIRST SharedMLP layer of a level whose neighbours come straight from the raw scan (SA1): QueryAndGroup's
+ * column -- (xyz[k] - new_xyz[j]) (/ radius), then the point's features, pointnet2_utils.py:348-359 -- formed in
+ * registers from POINT-MAJOR rows points_pm (b, n, cpt) = [x y z f0 f1 ...] (the layout a scan arrives in) and
+ * multiplied by w (cout, cin), cin = 3 + features used <= 8, cout a multiple of 64 (Conv2d 1x1 without bias,
+ * pytorch_utils.py:11-36): y (b, cout, m*nsample) raw + per-channel batch statistics (doubles; zeroed here unless
+ * accumulate; NULL: none).  No grouped tensor is written.  idx (b, m*nsample): ball-query lists (centre_of = n_act =
+ * mult = NULL) or the compact lists of sig3d_compact_neighbour_lists (statistics weighted by mult, positions
+ * [0, n_act[b]) only).  _dw: dW (cout, cin) (+)= sum over positions of dY[:, u] column(u)^T, the column gathered
+ * again (recompute in backward). */
+int sig3d_sa_first_layer_fwd(int b, int n, int m, int nsample, int cpt, int cin, int cout, int normalize_xyz,
+                             float radius, const float *points_pm, const float *new_xyz, const int *idx,
+                             const int *centre_of, const int *n_act, const float *mult, const float *w, float *y,
+                             double *stat_sum, double *stat_sq, int accumulate, void *stream);
+int sig3d_sa_first_layer_dw(int b, int n, int m, int nsample, int cpt, int cin, int cout, int normalize_xyz,
+                            float radius, const float *points_pm, const float *new_xyz, const int *idx,
+                            const int *centre_of, const int *n_act, const float *dY, float *dW, int accumulate,
+                            void *stream);
+
 /* sig3d_bn_relu_maxpool / _compact (seg_off != NULL: compact lists, e = row stride, s ignored) with a second,
  * POINT-MAJOR copy of the pooled features: out_pm (b,p,c) -- what the next level's gathers and the Q-Former's
  * scene tokens read (pointnet2_modules.py:259-262 followed by the `.transpose(1, 2)` of its callers), written

@@ -12,7 +12,7 @@ question tokens attend to them in a BLIP-2 Q-Former (cross-attention every 2nd l
 import torch
 import torch.nn as nn
 
-from .pointnet2.fused_mlp import point_major_of
+from .pointnet2.fused_mlp import attach_scan, point_major_of
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .qformer import init_Qformer
 from .situational import gaussian_localisation_target, situational_transform
@@ -97,7 +97,11 @@ class SIG3DQFormer(nn.Module):
     def forward(self, data_dict):
         pc = data_dict["point_clouds"]
         xyz = pc[..., :3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.shape[-1] > 3 else None
+        # a channel-major VIEW of the colours (no copy): SA1's first layer reads the raw point-major rows of the scan
+        # (fused_mlp.first_layer_scan); any other path makes its own contiguous copy
+        features = None
+        if pc.shape[-1] > 3:
+            features = attach_scan(pc[..., 3:].transpose(1, 2), pc) if pc.is_cuda else pc[..., 3:].transpose(1, 2).contiguous()
         tok_xyz, tok_feat = self.encoder(xyz, features, data_dict.get("geometry_plan"))
         tok_pm = point_major_of(tok_feat)                           # SA4's pooling kernel wrote (B,T,256) as well
         tok_feat = tok_pm if tok_pm is not None else tok_feat.transpose(1, 2).contiguous()

@@ -162,7 +162,10 @@ class _FusedMLPMax(torch.autograd.Function):
     separate ReLU / threshold / max-reduce / scatter launches."""
 
     @staticmethod
-    def forward(ctx, x, layers, library_gemm, compact, gather, want_pm, x_is_pm, *flat):
+    def forward(ctx, x, layers, library_gemm, compact, gather, want_pm, x_is_pm, first, *flat):
+        # first: None, or (new_xyz, idx, nsample, radius, normalize_xyz, cin): x is then the raw scan POINT-MAJOR
+        # (B, N, cpt) = [x y z f0 ...] and the first layer forms its 3 + c <= 8 channel column in registers
+        # (csrc/sa_first.hip: SA1) -- no grouped tensor in either direction, nothing differentiable below it
         # want_pm: also return the pooled features POINT-MAJOR (B, npoint, C) -- written by the pooling kernel
         # itself (sig3d_bn_relu_maxpool_pm), for the next level's gathers / the Q-Former's scene tokens
         # x_is_pm (gather mode): x is already the point-major feature copy (B, N, C) of the level below
@@ -180,7 +183,13 @@ class _FusedMLPMax(torch.autograd.Function):
         x = x.contiguous()
         stream = _lib.stream_ptr(dev)
         feat_pm = None
-        if gather is not None:
+        if first is not None:
+            assert not library_gemm and gather is None
+            f_new_xyz, f_idx, s, f_radius, f_norm, f_cin = first
+            b, n_src, cpt = x.shape
+            p = f_new_xyz.shape[1]
+            c0 = f_cin
+        elif gather is not None:
             assert not library_gemm
             g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
             p = g_new_xyz.shape[1]
@@ -216,6 +225,14 @@ class _FusedMLPMax(torch.autograd.Function):
                     y = torch.bmm(w.unsqueeze(0).expand(b, cout, cin), act.view(b, cin, e)).view(b, cout, p, s)
                     _lib.call("sig3d_channel_stats", b, cout, e, _lib.ptr(y), _lib.ptr(st[0]), _lib.ptr(st[1]),
                               1, stream)
+                elif first is not None and i == 0:
+                    y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_sa_first_layer_fwd", b, n_src, p, s, cpt, f_cin, cout, int(f_norm),
+                              ctypes.c_float(f_radius), _lib.ptr(x), _lib.ptr(f_new_xyz), _lib.ptr(f_idx),
+                              _lib.ptr(c_cent if compact is not None else None),
+                              _lib.ptr(c_nact if compact is not None else None),
+                              _lib.ptr(c_mult if compact is not None else None), _lib.ptr(w), _lib.ptr(y),
+                              _lib.ptr(st[0]), _lib.ptr(st[1]), 1, stream)
                 elif gather is not None and i == 0:
                     y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
                     _lib.call("sig3d_mlp_layer0_gather_fwd", b, n_src, p, s, c0, cout, int(g_norm),
@@ -264,6 +281,7 @@ class _FusedMLPMax(torch.autograd.Function):
         ctx.save_for_backward(feat_pm if gather is not None else x, arg, *ys, *affs, *ws)
         ctx.compact = compact
         ctx.gather = gather
+        ctx.first = first
         ctx.nl = len(layers)
         ctx.dims = (b, p, s)
         ctx.library_gemm = library_gemm
@@ -360,7 +378,13 @@ class _FusedMLPMax(torch.autograd.Function):
                 ppb = affs[k - 1][1] if k > 0 else None
                 dW = dw_all[dw_off:dw_off + cout * cin].view(cout, cin)
                 dw_off += cout * cin
-                if gather is not None and k == 0 and regroup is None:
+                if ctx.first is not None and k == 0:
+                    f_new_xyz, f_idx, _, f_radius, f_norm, f_cin = ctx.first
+                    _lib.call("sig3d_sa_first_layer_dw", b, x.shape[1], p, s, x.shape[2], f_cin, cout, int(f_norm),
+                              ctypes.c_float(f_radius), _lib.ptr(x), _lib.ptr(f_new_xyz), _lib.ptr(f_idx),
+                              _lib.ptr(c_cent if compact is not None else None),
+                              _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dY), _lib.ptr(dW), 1, stream)
+                elif gather is not None and k == 0 and regroup is None:
                     _lib.call("sig3d_mlp_layer0_gather_dw", b, n_src, p, s, c_src, cout, int(g_norm),
                               ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(x),
                               _lib.ptr(g_idx), _lib.ptr(dY), _lib.ptr(dW), 1,
@@ -373,7 +397,9 @@ class _FusedMLPMax(torch.autograd.Function):
                     _lib.call("sig3d_mlp_layer_dw", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
                               _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, stream)
                 grads[3 * k] = dW.view(cout, cin, 1, 1)
-                if k == 0 and regroup is not None:
+                if k == 0 and ctx.first is not None:
+                    pass          # the raw scan is not differentiable
+                elif k == 0 and regroup is not None:
                     if ctx.needs_input_grad[0]:
                         wt = ws[0].t().contiguous()
                         dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
@@ -421,7 +447,7 @@ class _FusedMLPMax(torch.autograd.Function):
                 cout = ws[k].shape[0]
                 grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma
                 grads[3 * k + 2] = sums32[k, 0, :cout]         # d beta
-        return (grad_x, None, None, None, None, None, None) + tuple(grads)
+        return (grad_x, None, None, None, None, None, None, None) + tuple(grads)
 
 
 def _with_pm(out, out_pm):
@@ -442,7 +468,7 @@ def point_major_of(features):
     return None
 
 
-def _fused_mlp_max_eval(layers, x, compact=None, gather=None, want_pm=False, x_is_pm=False):
+def _fused_mlp_max_eval(layers, x, compact=None, gather=None, want_pm=False, x_is_pm=False, first=None):
     """Inference: BatchNorm2d.eval() is the affine map scale = gamma / sqrt(running_var + eps),
     shift = beta - running_mean * scale, so a layer is one sig3d_mlp_layer_fwd (previous layer's
     BN+ReLU on operand load, no statistics) and the stack ends in sig3d_bn_relu_maxpool.
@@ -450,7 +476,11 @@ def _fused_mlp_max_eval(layers, x, compact=None, gather=None, want_pm=False, x_i
     dev = x.device
     x = x.contiguous()
     stream = _lib.stream_ptr(dev)
-    if gather is not None:   # x: the level's input features (B, C, N); first layer gathers on load
+    if first is not None:    # x: the raw scan point-major (B, N, cpt); first layer forms its column in registers
+        f_new_xyz, f_idx, s, f_radius, f_norm, f_cin = first
+        b, n_src, cpt = x.shape
+        p = f_new_xyz.shape[1]
+    elif gather is not None:   # x: the level's input features (B, C, N); first layer gathers on load
         g_xyz, g_new_xyz, g_idx, s, g_radius, g_norm = gather
         p = g_new_xyz.shape[1]
         if x_is_pm:
@@ -470,7 +500,13 @@ def _fused_mlp_max_eval(layers, x, compact=None, gather=None, want_pm=False, x_i
             w = conv.weight.reshape(conv.out_channels, conv.in_channels).contiguous()
             cout, cin = w.shape
             y = torch.empty((b, cout, p, s), dtype=torch.float32, device=dev)
-            if gather is not None and li == 0:
+            if first is not None and li == 0:
+                _lib.call("sig3d_sa_first_layer_fwd", b, n_src, p, s, cpt, f_cin, cout, int(f_norm), ctypes.c_float(f_radius),
+                          _lib.ptr(x), _lib.ptr(f_new_xyz), _lib.ptr(f_idx),
+                          _lib.ptr(compact[1] if compact is not None else None),
+                          _lib.ptr(compact[4] if compact is not None else None), _lib.ptr(None), _lib.ptr(w), _lib.ptr(y),
+                          _lib.ptr(None), _lib.ptr(None), 0, stream)
+            elif gather is not None and li == 0:
                 _lib.call("sig3d_mlp_layer0_gather_fwd", b, n_src, p, s, c0, cout, int(g_norm), ctypes.c_float(g_radius),
                           _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(feat_pm), _lib.ptr(g_idx), _lib.ptr(w),
                           _lib.ptr(y), _lib.ptr(None), _lib.ptr(None), 0,
@@ -516,7 +552,7 @@ def fused_mlp_max(mlp, x, library_gemm=None, want_pm=False):
         flat += [conv.weight, bn.weight, bn.bias]
     if library_gemm is None:
         library_gemm = x.shape[0] * x.shape[2] * x.shape[3] < MIN_POSITIONS
-    return _with_pm(*_FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, bool(want_pm), False, *flat))
+    return _with_pm(*_FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, bool(want_pm), False, None, *flat))
 
 
 # SIG3D_GATHER_L0=0: always store the grouped tensor (A/B timing; same results up to f32 summation order)
@@ -530,16 +566,52 @@ def gather_applies(features, use_xyz):
             and features.shape[1] % 32 == 0 and features.is_cuda and features.dtype == torch.float32)
 
 
+FIRST_L0 = os.environ.get("SIG3D_FIRST_L0", "1") != "0"   # 0: SA1 keeps the stored grouped tensor (A/B timing)
+
+
+def attach_scan(features, point_clouds):
+    """features: the (B, C, N) channel-major VIEW of point_clouds (B, N, 3 + C)[..., 3:] (no copy made);
+    the raw point-major scan rides along so that a first SA level can read whole rows (first_layer_scan)."""
+    if point_clouds.is_contiguous() and point_clouds.dtype == torch.float32:
+        features._points_pm = point_clouds
+    return features
+
+
+def first_layer_scan(mlp, xyz, features, use_xyz):
+    """The point-major scan (B, N, 3 + C) behind `features` when the first SharedMLP layer can form its column from it
+    in registers (csrc/sa_first.hip): 3 + C <= 8 input channels, 64 | output channels, xyz concatenated, nothing
+    differentiable below -- else None."""
+    if not (FIRST_L0 and features is not None and use_xyz and features.dim() == 3 and features.is_cuda):
+        return None
+    pts = getattr(features, "_points_pm", None)
+    layers = _layers(mlp)
+    if pts is None or layers is None:
+        return None
+    b, c, n = features.shape
+    conv = layers[0][0]
+    if not (pts.dim() == 3 and tuple(pts.shape[:2]) == (b, n) and pts.shape[2] == 3 + c and pts.is_contiguous()
+            and pts.dtype == torch.float32 and pts.device == features.device and 3 + c <= 8
+            and conv.in_channels == 3 + c and conv.out_channels % 64 == 0):
+        return None
+    if torch.is_grad_enabled() and (features.requires_grad or pts.requires_grad or xyz.requires_grad):
+        return None
+    return pts
+
+
 def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_xyz, normalize_xyz, want_pm=False):
     """One set-abstraction level over the distinct neighbours only (training mode, MFMA path):
     grouped tensor -> SharedMLP -> max over the neighbourhood, same result as the dense path up to
     floating-point summation order.  compact: CompactLists of this level's ball-query result."""
     layers = _layers(mlp)
     cidx, centre_of, mult, seg_off, n_act = compact.tensors()
-    feats = None if features is None else features.contiguous()
     lists = (cidx, centre_of, mult, seg_off, n_act)
-    gather, x_is_pm = None, False
-    if gather_applies(feats, use_xyz):
+    gather, x_is_pm, first = None, False, None
+    pts = first_layer_scan(mlp, xyz, features, use_xyz)
+    feats = None if (features is None or pts is not None) else features.contiguous()
+    if pts is not None:
+        first = (new_xyz.contiguous(), cidx, int(nsample), float(radius), bool(normalize_xyz), pts.shape[2])
+        x = pts
+    elif gather_applies(feats, use_xyz):
         gather = (xyz.contiguous(), new_xyz.contiguous(), cidx, int(nsample), float(radius), bool(normalize_xyz))
         x = point_major_of(features)       # written by the level below's pooling kernel: no transpose launch
         x_is_pm = x is not None
@@ -549,16 +621,19 @@ def fused_sa_compact(mlp, xyz, new_xyz, features, compact, nsample, radius, use_
         x = _QueryGroupCompact.apply(xyz.contiguous(), new_xyz.contiguous(), feats, cidx, centre_of, n_act, int(nsample),
                                      float(radius), bool(use_xyz) or features is None, bool(normalize_xyz))
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, x, lists, gather, want_pm, x_is_pm)
+        return _fused_mlp_max_eval(layers, x, lists, gather, want_pm, x_is_pm, first)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _with_pm(*_FusedMLPMax.apply(x, layers, False, lists, gather, bool(want_pm), x_is_pm, *flat))
+    return _with_pm(*_FusedMLPMax.apply(x, layers, False, lists, gather, bool(want_pm), x_is_pm, first, *flat))
 
 
 def dense_gather_applies(mlp, xyz, features, npoint, nsample, use_xyz):
-    """Dense (full-list) levels on the MFMA path whose first layer can gather on load."""
-    if not (gather_applies(features, use_xyz) and xyz.is_cuda and _layers(mlp) is not None):
+    """Dense (full-list) levels on the MFMA path whose first layer can gather on load (wide feature rows), or
+    form its column from the raw scan (first_layer_scan)."""
+    if not xyz.is_cuda or _layers(mlp) is None:
+        return False
+    if not gather_applies(features, use_xyz) and first_layer_scan(mlp, xyz, features, use_xyz) is None:
         return False
     if xyz.shape[0] * npoint * nsample < MIN_POSITIONS:
         return False          # small levels: library-GEMM hybrid on the stored tensor
@@ -576,18 +651,24 @@ def fused_sa_dense(mlp, xyz, new_xyz, features, ball_idx, nsample, radius, norma
     (pointnet2_modules.py:242-262) with the first layer gathering its operand from (xyz, features) through the
     ball-query lists, the weight gradient gathering it again, and the input gradient scattered by the dX product."""
     layers = _layers(mlp)
-    gather = (xyz.contiguous(), new_xyz.contiguous(), ball_idx.contiguous().view(ball_idx.shape[0], -1), int(nsample),
-              float(radius), bool(normalize_xyz))
-    x = point_major_of(features)
-    x_is_pm = x is not None
-    if x is None:
-        x = features.contiguous()
+    idx2 = ball_idx.contiguous().view(ball_idx.shape[0], -1)
+    gather, first, x_is_pm = None, None, False
+    pts = first_layer_scan(mlp, xyz, features, True)
+    if pts is not None:
+        first = (new_xyz.contiguous(), idx2, int(nsample), float(radius), bool(normalize_xyz), pts.shape[2])
+        x = pts
+    else:
+        gather = (xyz.contiguous(), new_xyz.contiguous(), idx2, int(nsample), float(radius), bool(normalize_xyz))
+        x = point_major_of(features)
+        x_is_pm = x is not None
+        if x is None:
+            x = features.contiguous()
     if not mlp.training:
-        return _fused_mlp_max_eval(layers, x, None, gather, want_pm, x_is_pm)
+        return _fused_mlp_max_eval(layers, x, None, gather, want_pm, x_is_pm, first)
     flat = []
     for conv, bn in layers:
         flat += [conv.weight, bn.weight, bn.bias]
-    return _with_pm(*_FusedMLPMax.apply(x, layers, False, None, gather, bool(want_pm), x_is_pm, *flat))
+    return _with_pm(*_FusedMLPMax.apply(x, layers, False, None, gather, bool(want_pm), x_is_pm, first, *flat))
 
 
 def compact_applies(mlp, xyz, features, npoint, nsample):

@@ -4,6 +4,7 @@ lib/pointnet2/pytorch_utils.py:11-36, pointnet2_modules.py:251-262): outputs, in
 every parameter gradient and the BatchNorm running statistics.  fp32 within 1e-4 (scaled).
 """
 import copy
+import ctypes
 
 import pytest
 import torch
@@ -502,3 +503,117 @@ def test_top_layer_backward_from_a_point_major_pool_gradient(compact):
             torch.testing.assert_close(dY1[bi, :, :n], dY0[bi, :, :n], rtol=1e-5, atol=1e-6)
     else:
         torch.testing.assert_close(dY1, dY0, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("c,cout,normalize", [(3, 64, True), (1, 128, False), (5, 64, True)])
+def test_first_layer_from_the_raw_scan_matches_group_then_conv(compact, c, cout, normalize):
+    """sig3d_sa_first_layer_fwd / _dw (SA1: the column of QueryAndGroup formed in registers from point-major scan
+    rows) against sig3d_query_group_fused + a torch 1x1 convolution: pre-activations, batch statistics (weighted by
+    the multiplicity on compact lists) and the weight gradient."""
+    from situation3d_amd import _lib as L
+    from situation3d_amd.pointnet2 import _ext, fused_mlp
+    from util import scene
+    b, n, m, ns, radius = 2, 3000, 300, 16, 0.35
+    g = torch.Generator().manual_seed(c * 10 + cout)
+    pts = torch.cat([scene(b, n, seed=4), torch.rand(b, n, c, generator=g)], -1).to(DEV).contiguous()
+    xyz = pts[..., :3].contiguous()
+    feats = pts[..., 3:].transpose(1, 2).contiguous()
+    inds = _ext.furthest_point_sampling(xyz, m)
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = _ext.ball_query(new_xyz, xyz, radius, ns)
+    w = (torch.randn(cout, 3 + c, generator=g) * 0.3).to(DEV)
+    e = m * ns
+    grouped = torch.empty(b, 3 + c, m, ns, device=DEV)
+    L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, int(normalize), ctypes.c_float(radius), L.ptr(xyz), L.ptr(new_xyz),
+           L.ptr(feats), L.ptr(idx), L.ptr(grouped), L.stream_ptr())
+    ref_y = torch.einsum("oc,bce->boe", w.double(), grouped.view(b, 3 + c, e).double())
+    dY = torch.randn(b, cout, e, generator=g).to(DEV)
+    if compact:
+        cl = fused_mlp.compact_lists(idx)
+        cidx, cent, mult, seg, nact = cl.tensors()
+        lists, cptr, nptr, mptr = cidx, L.ptr(cent), L.ptr(nact), L.ptr(mult)
+    else:
+        lists, cptr, nptr, mptr = idx.view(b, e), L.ptr(None), L.ptr(None), L.ptr(None)
+    y = torch.full((b, cout, e), float("nan"), device=DEV)
+    st = torch.zeros(2, cout, dtype=torch.float64, device=DEV)
+    L.call("sig3d_sa_first_layer_fwd", b, n, m, ns, 3 + c, 3 + c, cout, int(normalize), ctypes.c_float(radius), L.ptr(pts),
+           L.ptr(new_xyz), L.ptr(lists), cptr, nptr, mptr, L.ptr(w), L.ptr(y), L.ptr(st[0]), L.ptr(st[1]), 0, L.stream_ptr())
+    dW = torch.full((cout, 3 + c), float("nan"), device=DEV)
+    L.call("sig3d_sa_first_layer_dw", b, n, m, ns, 3 + c, 3 + c, cout, int(normalize), ctypes.c_float(radius), L.ptr(pts),
+           L.ptr(new_xyz), L.ptr(lists), cptr, nptr, L.ptr(dY), L.ptr(dW), 0, L.stream_ptr())
+    if not compact:
+        torch.testing.assert_close(y.double(), ref_y, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(st[0], ref_y.sum((0, 2)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(st[1], (ref_y ** 2).sum((0, 2)), rtol=1e-5, atol=1e-3)
+        ref_dw = torch.einsum("boe,bce->oc", dY.double(), grouped.view(b, 3 + c, e).double())
+        torch.testing.assert_close(dW.double(), ref_dw, rtol=1e-4, atol=1e-3)
+    else:
+        # position u of the compact lists = column (centre_of[u], first occurrence of cidx[u]) of the dense tensor
+        ref_dw = torch.zeros(cout, 3 + c, dtype=torch.float64, device=DEV)
+        s1 = torch.zeros(cout, dtype=torch.float64, device=DEV)
+        s2 = torch.zeros(cout, dtype=torch.float64, device=DEV)
+        for bi in range(b):
+            na = int(nact[bi])
+            cols = torch.empty(na, dtype=torch.long, device=DEV)
+            row_idx = idx[bi][cent[bi, :na].long()]                         # (na, ns) lists of the positions' centres
+            first = (row_idx == cidx[bi, :na, None]).float().argmax(1)      # first sample holding that neighbour
+            cols = cent[bi, :na].long() * ns + first
+            ry = ref_y[bi][:, cols]
+            torch.testing.assert_close(y[bi, :, :na].double(), ry, rtol=1e-5, atol=1e-5)
+            s1 += (ry * mult[bi, :na].double()).sum(1)
+            s2 += (ry ** 2 * mult[bi, :na].double()).sum(1)
+            ref_dw += dY[bi, :, :na].double() @ grouped.view(b, 3 + c, e)[bi][:, cols].double().t()
+        torch.testing.assert_close(st[0], s1, rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(st[1], s2, rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(dW.double(), ref_dw, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("mode", ["compact", "dense", "dense-eval"])
+def test_sa1_reading_the_raw_scan_matches_the_stored_grouped_tensor(mode, monkeypatch):
+    """PointnetSAModuleVotes on a (B, N, 6) scan: the first SharedMLP layer formed from point-major rows
+    (fused_mlp.attach_scan / first_layer_scan; no colour transpose, no grouped tensor) against the stored form
+    (SIG3D_FIRST_L0=0): pooled features, every parameter gradient, BatchNorm running statistics."""
+    import copy
+    from situation3d_amd.pointnet2 import fused_mlp
+    from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from util import scene
+    torch.manual_seed(3)
+    b, n = 2, 9000
+    pc = torch.cat([scene(b, n, seed=5), torch.rand(b, n, 3)], -1).to(DEV).contiguous()
+    xyz = pc[..., :3].contiguous()
+    monkeypatch.setattr(fused_mlp, "COMPACT", mode == "compact")
+    sa = PointnetSAModuleVotes(npoint=1024, radius=0.25 if mode == "compact" else 0.6, nsample=64, mlp=[3, 64, 64, 128],
+                               use_xyz=True, normalize_xyz=True).to(DEV)
+    ref = copy.deepcopy(sa)
+    if mode == "dense-eval":
+        sa.eval(); ref.eval()
+    G = torch.randn(b, 128, 1024, device=DEV)
+    calls = []
+    orig = fused_mlp._lib.call
+    monkeypatch.setattr(fused_mlp._lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+
+    def run(m, scan):
+        monkeypatch.setattr(fused_mlp, "FIRST_L0", scan)
+        f = fused_mlp.attach_scan(pc[..., 3:].transpose(1, 2), pc)
+        with torch.set_grad_enabled(mode != "dense-eval"):
+            _, out, inds = m(xyz, f)
+            if mode != "dense-eval":
+                (out * G).sum().backward()
+        return out.detach(), inds
+
+    o1, i1 = run(sa, True)
+    assert "sig3d_sa_first_layer_fwd" in calls and not any(nm.startswith("sig3d_query_group") for nm in calls)
+    if mode != "dense-eval":
+        assert "sig3d_sa_first_layer_dw" in calls
+    calls.clear()
+    o2, i2 = run(ref, False)
+    assert "sig3d_sa_first_layer_fwd" not in calls and any(nm.startswith("sig3d_query_group") for nm in calls)
+    assert torch.equal(i1, i2)
+    _close(o1, o2, "pooled features", tol=2e-5)
+    if mode != "dense-eval":
+        for (n1, p1), (_, p2) in zip(sa.named_parameters(), ref.named_parameters()):
+            rel = float((p1.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-12))
+            assert rel < 1e-3, (n1, rel)      # a max-pool winner that leads by an ulp may change (see the gather test)
+        for (n1, b1), (_, b2) in zip(sa.named_buffers(), ref.named_buffers()):
+            _close(b1.float(), b2.float(), n1, tol=1e-5)
