@@ -109,6 +109,7 @@ constexpr int BQC_MAXM = 4096;     // centres per table: 64 KB of records + 32 K
 constexpr int BQC_THREADS = 512;   // scatter kernel
 constexpr int BQC_CPT = BQC_MAXM / BQC_THREADS;
 constexpr int BQC_MAXLV = 16;      // problems (levels x centre blocks) per launch
+constexpr int BQC_HITS = 2048;      // hits a cell-role workgroup notes in LDS (8 KB) before it falls back to a second pass
 constexpr int BQC_PPT = 2;          // points per thread of a cell-role workgroup (1024 points per workgroup)
 constexpr int BQC_SCAN_MAXN = 4096; // scenes up to this size take the ordered scan from an LDS copy (48 KB)
 constexpr int BQC_RANK_CENTRES = 16;   // per rank workgroup: 4 waves x 4 groups of 16 lanes
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
                                                                   int *__restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) int bqc_smem[];
   __shared__ int s_wave[BQC_THREADS / 64];
+  __shared__ int s_nhit;
   int li = 0;
   for (int i = 1; i < P.nlevels; ++i)
     if ((int)blockIdx.x >= P.lv[i].wg_begin) li = i;
@@ -222,10 +224,13 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
   __syncthreads();
   BQ_MARK(2);
   {  // exclusive prefix of the H counts, in place: a contiguous run per thread, wave scan, wave offsets
-    const int per = (H + BQC_THREADS - 1) / BQC_THREADS;
+    const int per = (H + BQC_THREADS - 1) / BQC_THREADS;   // <= 16 (H <= 8192)
     const int e0 = min(tid * per, H), e1 = min(e0 + per, H);
-    int tot = 0;
-    for (int e = e0; e < e1; ++e) tot += s_end[e];
+    int tot = 0, cv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cv[i] = s_end[min(e0 + i, H - 1)];   // unconditional: sixteen reads in flight
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += (e0 + i < e1) ? cv[i] : 0;
     int incl = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -236,10 +241,10 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
     __syncthreads();
     int run = incl - tot;
     for (int w = 0; w < wave; ++w) run += s_wave[w];
-    for (int e = e0; e < e1; ++e) {
-      const int v = s_end[e];
-      s_end[e] = run;
-      run += v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (e0 + i < e1) s_end[e0 + i] = run;
+      run += (e0 + i < e1) ? cv[i] : 0;
     }
   }
   __syncthreads();
@@ -283,20 +288,34 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
       for (int p = 0; p < q; ++p) ok[q] = ok[q] && !(ok[p] && hh[p] == hh[q]);   // a bucket is walked once
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {   // all range reads in flight together
-      p1[t][q] = ok[q] ? s_end[hh[q]] : 0;
-      p0[t][q] = ok[q] ? (hh[q] ? s_end[hh[q] - 1] : 0) : 0;
+    for (int q = 0; q < 8; ++q) {   // unconditional reads (a read under `ok ?` is a branch and a wait each), masked after
+      const int e1v = s_end[hh[q]], e0v = s_end[hh[q] ? hh[q] - 1 : 0];
+      p1[t][q] = ok[q] ? e1v : 0;
+      p0[t][q] = ok[q] ? (hh[q] ? e0v : 0) : 0;
     }
   }
   __syncthreads();
   BQ_MARK(5);
-  // The points against their candidates, TWICE.  A returning global atomic per hit inside these divergent loops
-  // made every loop trip a memory round trip (measured: 105 us at the SA3 shape).  Pass A only counts a
-  // centre's hits in LDS; then ONE global atomic per centre reserves this workgroup's range of the centre's
-  // list (issued by m threads at once: one round trip); pass B repeats the tests and places every hit with a
-  // returning LDS atomic.  The distance tests are a few VALU instructions per candidate.
+  // The points against their candidates.  A returning global atomic per hit inside these divergent loops made every
+  // loop trip a memory round trip (measured: 105 us at the SA3 shape).  So the pass only counts a centre's hits in
+  // LDS and notes every hit (centre, point) in a workgroup list; then ONE global atomic per centre reserves this
+  // workgroup's range of the centre's list (issued by m threads at once: one round trip) and the noted hits are
+  // placed by a dense loop (a returning LDS atomic each).  A workgroup with more than BQC_HITS hits (dense
+  // clusters) repeats the tests instead of reading the list.
+  int *s_list = s_base + m;                // [BQC_HITS] centre << 10 | point of the chunk
+  if (tid == 0) s_nhit = 0;
+  __syncthreads();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && s_nhit <= BQC_HITS) {   // uniform: every hit is in the list
+      const int nh = s_nhit;
+      for (int hq = tid; hq < nh; hq += BQC_THREADS) {
+        const int ent = s_list[hq], j = ent >> 10, pl = ent & 1023;
+        const int slot = s_base[j] + atomicAdd(&s_hits[j], 1);
+        if (slot < BQC_CAP) list_l[(size_t)j * BQC_CAP + slot] = chunk * (BQC_PPT * BQC_THREADS) + pl;
+      }
+      break;
+    }
 #pragma unroll
     for (int t = 0; t < BQC_PPT; ++t) {
 #pragma unroll
@@ -307,6 +326,13 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
             const int j = __builtin_bit_cast(int, C.w);
             if (pass == 0) {
               atomicAdd(&s_hits[j], 1);
+              // one list-cursor atomic per wave and loop trip (the lanes that hit right now), not one per hit
+              const unsigned long long act = __ballot(1);
+              const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0));
+              int base = 0;
+              if (rank == 0) base = atomicAdd(&s_nhit, __builtin_popcountll(act));
+              const int hq = __builtin_amdgcn_readfirstlane(base) + rank;
+              if (hq < BQC_HITS) s_list[hq] = (j << 10) | (t * BQC_THREADS + tid);
             } else {
               const int slot = s_base[j] + atomicAdd(&s_hits[j], 1);
               if (slot < BQC_CAP) list_l[(size_t)j * BQC_CAP + slot] = pk[t];
@@ -327,6 +353,7 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
       BQ_MARK(7);
     }
   }
+  BQ_MARK(8);
 }
 
 __global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, const int *__restrict__ cnt,
@@ -441,7 +468,7 @@ static long bqc_plan(int b, int nlevels, const sig3d_bq_level *levels, BqcParams
       rwg += ranked ? sig3d_ceil_div((long)b * L.m, BQC_RANK_CENTRES) : 0;
       slots += ranked ? (long)b * L.m : 0;
       const size_t need = L.kind == 1 ? sizeof(float) * 3 * (size_t)q.n
-                                      : sizeof(int) * ((size_t)h + 2 * (size_t)L.m) + sizeof(float4) * (size_t)L.m;
+                                      : sizeof(int) * ((size_t)h + 2 * (size_t)L.m + BQC_HITS) + sizeof(float4) * (size_t)L.m;
       if (need > lds) lds = need;
     }
   }
