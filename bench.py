@@ -559,11 +559,18 @@ def main():
         fps = kernel_ms("sig3d_furthest_point_sampling")
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
-        traffic, traffic_commit = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_group_pair.json")
+        traffic, traffic_commit, traffic_stale = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_group_pair.json")
         if os.path.exists(pmc):
             j = json.load(open(pmc))
             traffic, traffic_commit = round(j["traffic_bytes_per_step"]), j.get("commit")
+            # true when a kernel source changed after the commit the counters were read at (null: no git here)
+            try:
+                diff = subprocess.run(["git", "-C", ROOT, "diff", "--name-only", str(traffic_commit), "HEAD", "--",
+                                       "situation3d_amd/csrc"], capture_output=True, text=True, timeout=20)
+                traffic_stale = bool(diff.stdout.strip()) if diff.returncode == 0 else None
+            except Exception:
+                traffic_stale = None
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -587,7 +594,7 @@ def main():
                          "frac": round(pair_gbs / HBM_PEAK_GBS, 4),
                          # HBM bytes of the same kernels per step (PMC, FETCH_SIZE x 2 + WRITE_SIZE) and the commit
                          # they were measured at; per step like algorithmic_bytes_per_step
-                         "traffic": traffic, "traffic_commit": traffic_commit,
+                         "traffic": traffic, "traffic_commit": traffic_commit, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_step": round(pair_bytes / KSTEPS),
                          "launches_per_step": pair_launches // KSTEPS, "ms_per_step": round(pair_ms / KSTEPS, 4),
                          # per C-ABI entry point and step: launches, event-bracketed ms, algorithmic bytes
