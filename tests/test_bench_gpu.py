@@ -36,9 +36,18 @@ def test_default_line_carries_the_contract():
     assert out["fps_timeouts"] == 0
     # beside the headline: every level dense, and surface-shaped scenes (both slower or equal, both finite)
     v = out["variants"]
-    assert len(v) == 2 and all(x["ms_per_step"] > 0 for x in v.values())
+    steps = {k: x for k, x in v.items() if "ms_per_step" in x}
+    assert len(steps) == 2 and all(x["ms_per_step"] > 0 for x in steps.values())
     dense = [x for k, x in v.items() if k.startswith("dense")][0]
     assert dense["compact_levels"] == {} and out["compact_levels"]              # headline compact, variant dense
+    fwd = v["config 2: forward only, B=4"]                                       # BASELINE config 2, driver-timed
+    assert fwd["batch"] == 4 and 0 < fwd["pipelined_ms_per_batch"] <= fwd["single_batch_latency_ms"] * 1.05
+    # the pair's own launches, its floor model, PMC traffic and the op-level pair beside it
+    assert r["launches_per_step"] <= 4 and r["floor_model"]["floor_ms"] > 0 and r["traffic"] > 0
+    assert "sig3d_transpose_cn" not in r["parts"]                                # no transpose launch left in the step
+    ops = out["roofline_ops"]
+    assert ops["bound"] == "hbm" and 0 < ops["frac"] < 1 and ops["algorithmic_bytes"] > 3e8
+    assert out["rccl_ranks"] == 1 and out["dist_backend"] is None
 
 
 def test_data_parallel_path_over_real_rccl_group_of_one():
