@@ -577,11 +577,18 @@ def attach_scan(features, point_clouds):
     return features
 
 
-def first_layer_scan(mlp, xyz, features, use_xyz):
+# dense (full) lists: the stored grouped tensor + MFMA layer is faster (13 + 76 us against 114 us at SA1, B = 8:
+# the scan kernel writes its 64 output rows as 64 separate 256-byte stores per wave); 1 forces the scan path anyway
+FIRST_L0_DENSE = os.environ.get("SIG3D_FIRST_L0_DENSE", "0") != "0"
+
+
+def first_layer_scan(mlp, xyz, features, use_xyz, dense=False):
     """The point-major scan (B, N, 3 + C) behind `features` when the first SharedMLP layer can form its column from it
     in registers (csrc/sa_first.hip): 3 + C <= 8 input channels, 64 | output channels, xyz concatenated, nothing
-    differentiable below -- else None."""
+    differentiable below -- else None.  Used on compact lists (dense ones: FIRST_L0_DENSE)."""
     if not (FIRST_L0 and features is not None and use_xyz and features.dim() == 3 and features.is_cuda):
+        return None
+    if dense and not FIRST_L0_DENSE:
         return None
     pts = getattr(features, "_points_pm", None)
     layers = _layers(mlp)
@@ -633,7 +640,7 @@ def dense_gather_applies(mlp, xyz, features, npoint, nsample, use_xyz):
     form its column from the raw scan (first_layer_scan)."""
     if not xyz.is_cuda or _layers(mlp) is None:
         return False
-    if not gather_applies(features, use_xyz) and first_layer_scan(mlp, xyz, features, use_xyz) is None:
+    if not gather_applies(features, use_xyz) and first_layer_scan(mlp, xyz, features, use_xyz, dense=True) is None:
         return False
     if xyz.shape[0] * npoint * nsample < MIN_POSITIONS:
         return False          # small levels: library-GEMM hybrid on the stored tensor
@@ -653,7 +660,7 @@ def fused_sa_dense(mlp, xyz, new_xyz, features, ball_idx, nsample, radius, norma
     layers = _layers(mlp)
     idx2 = ball_idx.contiguous().view(ball_idx.shape[0], -1)
     gather, first, x_is_pm = None, None, False
-    pts = first_layer_scan(mlp, xyz, features, True)
+    pts = first_layer_scan(mlp, xyz, features, True, dense=True)
     if pts is not None:
         first = (new_xyz.contiguous(), idx2, int(nsample), float(radius), bool(normalize_xyz), pts.shape[2])
         x = pts

@@ -595,6 +595,7 @@ def test_sa1_reading_the_raw_scan_matches_the_stored_grouped_tensor(mode, monkey
 
     def run(m, scan):
         monkeypatch.setattr(fused_mlp, "FIRST_L0", scan)
+        monkeypatch.setattr(fused_mlp, "FIRST_L0_DENSE", scan)     # dense lists take the scan path on request only
         f = fused_mlp.attach_scan(pc[..., 3:].transpose(1, 2), pc)
         with torch.set_grad_enabled(mode != "dense-eval"):
             _, out, inds = m(xyz, f)
