@@ -185,3 +185,50 @@ def test_qformer_state_dict_keys_match_reference():
     kept = [k for k in model.bert.state_dict() if "word_embeddings" in k or ".intermediate." in k
             or ".output." in k and "attention" not in k]
     assert kept == []
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirrors of the C-ABI structs (sig3d_bq_level, sig3d_gemm_problem) must agree with what a C compiler
+    makes of include/sig3d_hip.h: size and every field offset, checked by compiling a probe with gcc."""
+    import ctypes
+    import subprocess
+    from situation3d_amd import _lib
+    structs = {"sig3d_bq_level": _lib.BqLevel, "sig3d_gemm_problem": _lib.GemmProblem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sig3d_hip.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        cname, fname, val = ln.split()
+        got[(cname, fname)] = int(val)
+    for cname, cls in structs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_point_major_twins_and_scan_attachment_are_validated():
+    """fused_mlp.point_major_of / first_layer_scan hand out the side-channel tensors only when they really describe
+    the features they ride on (shape, layout, device); anything else falls back to the reference behaviour."""
+    from situation3d_amd.pointnet2 import fused_mlp
+    f = torch.zeros(2, 8, 5)
+    assert fused_mlp.point_major_of(f) is None
+    f._pm = torch.zeros(2, 5, 8)
+    assert fused_mlp.point_major_of(f) is f._pm
+    f._pm = torch.zeros(2, 5, 7)                      # wrong width
+    assert fused_mlp.point_major_of(f) is None
+    f._pm = torch.zeros(2, 8, 5).transpose(1, 2)      # right shape, not contiguous
+    assert fused_mlp.point_major_of(f) is None
+    g = f * 2                                         # a new tensor carries no twin
+    assert fused_mlp.point_major_of(g) is None
+    pc = torch.rand(2, 9, 6)
+    feats = fused_mlp.attach_scan(pc[..., 3:].transpose(1, 2), pc)
+    assert feats._points_pm is pc and not feats.is_contiguous()
+    assert fused_mlp.first_layer_scan(None, pc[..., :3], feats, True) is None      # CPU: never the HIP path
