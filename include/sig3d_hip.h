@@ -501,6 +501,19 @@ int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,
                         const unsigned *rng_counter, void *stream);
 
+/* ---- small dense layers around the Q-Former as single launches (csrc/small_mlp.hip) ----------------------
+ * The positional MLP of the scene tokens (situation3d/models/sqa_module.py:274-278, applied at :319-321):
+ *   out (rows,cout) = residual + Linear(hid,cout)(GELU_erf(Linear(cin,hid)(x)))      cin <= 4, hid <= 128 (4 | hid)
+ * x (rows,cin), w1 (hid,cin), b1 (hid), w2 (cout,hid), b2 (cout), residual (rows,cout) or NULL;
+ * pre (rows,hid) receives the first layer's pre-activation (kept for the backward pass).
+ * _bwd: dy (rows,cout) -> dpre (rows,hid) = (dy w2) * gelu'(pre) [dX = dpre w1 is the caller's, when needed],
+ * grads = ONE buffer [dw1 (hid*cin) | db1 (hid) | dw2 (cout*hid) | db2 (cout)]: OVERWRITTEN (zeroed here with one
+ * memset, filled with float atomics).  The residual's gradient is dy itself. */
+int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const float *x, const float *w1, const float *b1,
+                      const float *w2, const float *b2, const float *residual, float *pre, float *out, void *stream);
+int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
+                      const float *dy, float *dpre, float *grads, void *stream);
+
 /* ---- compact mode: set abstraction over the DISTINCT neighbours only ------------------------------------
  * ball_query pads a short list by repeating its first hit (ball_query_gpu.cu:30-40); every padded entry is
  * an identical column of the grouped tensor, of each SharedMLP layer above it (pytorch_utils.py:11-36) and of

@@ -58,6 +58,8 @@ SIGNATURES = {
     "sig3d_bn_relu_bwd_top_from_pm": [_I, _I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_sa_first_layer_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_sa_first_layer_dw": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "sig3d_pos_mlp_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_pos_mlp_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_bn_relu_maxpool_pm": [_I, _I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_channel_stats": [_I, _I, ctypes.c_long, _P, _P, _P, _I, _P],
     "sig3d_bn_relu_apply": [_I, _I, ctypes.c_long, _P, _P, _P, _P, _P],

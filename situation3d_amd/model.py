@@ -16,6 +16,7 @@ from .pointnet2.fused_mlp import attach_scan, point_major_of
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .qformer import init_Qformer
 from .situational import gaussian_localisation_target, situational_transform
+from .small_mlp import pos_embed_add
 
 
 class PointNet2Encoder(nn.Module):
@@ -113,7 +114,8 @@ class SIG3DQFormer(nn.Module):
         sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
         data_dict["situational_positions"] = sit_xyz
         data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose)   # reads pose[:, :2]
-        tokens = tok_feat + self.pos_embed(sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2])
+        # tok_feat + Linear(GELU(Linear(position))): one launch (small_mlp.pos_embed_add; torch path off the GPU)
+        tokens = pos_embed_add(self.pos_embed, sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2], tok_feat)
         if data_dict.get("_split_backward"):
             # data-parallel step (graph_step.py): the backward pass is cut at the visual tokens (and, with
             # `_qf_cut`, once more inside the Q-Former) so that the gradient all-reduce of everything

@@ -1,0 +1,72 @@
+"""Host side of csrc/small_mlp.hip: the small dense layers around the Q-Former as single launches.
+
+`pos_embed_add(seq, x, residual)`: residual + seq(x) for seq = nn.Sequential(Linear(cin, hid), GELU(), Linear(hid, cout))
+-- the positional MLP of the scene tokens (situation3d/models/sqa_module.py:274-278, applied at :319-321) -- as one
+forward launch and two backward launches instead of torch's 4 + ~12.  The module's own parameters are used (same
+state_dict); anything the kernels do not cover (CPU tensors, other shapes, a tanh GELU) takes the torch path.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _PosMLPFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2):
+        rows, cin = x.shape
+        hid, cout = w1.shape[0], w2.shape[0]
+        dev = x.device
+        pre = torch.empty((rows, hid), dtype=torch.float32, device=dev)
+        out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_pos_mlp_fwd", rows, cin, hid, cout, _lib.ptr(x), _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                      _lib.ptr(b2), _lib.ptr(residual), _lib.ptr(pre), _lib.ptr(out), _lib.stream_ptr(dev))
+        ctx.save_for_backward(x, w1, w2, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, pre = ctx.saved_tensors
+        rows, cin = x.shape
+        hid, cout = w1.shape[0], w2.shape[0]
+        dev = x.device
+        dy = dy.contiguous()
+        dpre = torch.empty((rows, hid), dtype=torch.float32, device=dev)
+        grads = torch.empty(hid * cin + hid + cout * hid + cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_pos_mlp_bwd", rows, cin, hid, cout, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(pre), _lib.ptr(dy),
+                      _lib.ptr(dpre), _lib.ptr(grads), _lib.stream_ptr(dev))
+        o = 0
+        dw1 = grads[o:o + hid * cin].view(hid, cin); o += hid * cin
+        db1 = grads[o:o + hid]; o += hid
+        dw2 = grads[o:o + cout * hid].view(cout, hid); o += cout * hid
+        db2 = grads[o:o + cout]
+        dx = dpre.mm(w1) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.needs_input_grad[1] else None), dw1, db1, dw2, db2
+
+
+def _covered(seq, x, residual):
+    if not (isinstance(seq, nn.Sequential) and len(seq) == 3):
+        return False
+    l1, act, l2 = seq[0], seq[1], seq[2]
+    if not (isinstance(l1, nn.Linear) and isinstance(l2, nn.Linear) and isinstance(act, nn.GELU)):
+        return False
+    if getattr(act, "approximate", "none") != "none" or l1.bias is None or l2.bias is None:
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and residual.is_cuda and residual.dtype == torch.float32):
+        return False
+    hid, cin = l1.weight.shape
+    return cin <= 4 and hid <= 128 and hid % 4 == 0 and l2.weight.shape[1] == hid and l2.weight.shape[0] <= 1024 \
+        and x.shape[-1] == cin and residual.shape[-1] == l2.weight.shape[0] and residual.shape[:-1] == x.shape[:-1]
+
+
+def pos_embed_add(seq, x, residual):
+    """residual + seq(x); x (..., cin), residual (..., cout)."""
+    if not _covered(seq, x, residual):
+        return residual + seq(x)
+    l1, l2 = seq[0], seq[2]
+    shape = residual.shape
+    out = _PosMLPFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), residual.reshape(-1, shape[-1]).contiguous(),
+                          l1.weight, l1.bias, l2.weight, l2.bias)
+    return out.view(shape)

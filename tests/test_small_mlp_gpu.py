@@ -1,0 +1,53 @@
+"""csrc/small_mlp.hip: the small dense layers around the Q-Former as single launches, against the torch modules they
+stand for (same parameters): outputs and every gradient."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rows_shape,cin,hid,cout,x_grad", [((8, 256), 3, 128, 256, False), ((8, 256), 2, 128, 256, True),
+                                                          ((37,), 3, 128, 256, True), ((3, 5), 4, 64, 96, False)])
+def test_pos_embed_add_matches_the_sequential(rows_shape, cin, hid, cout, x_grad):
+    """tok_feat + Linear(GELU(Linear(pos))) (sqa_module.py:274-278, :319-321) as one forward and two backward launches."""
+    from situation3d_amd.model import build_pos_embed
+    from situation3d_amd.small_mlp import _covered, pos_embed_add
+    torch.manual_seed(cin * 7 + hid)
+    seq = nn.Sequential(nn.Linear(cin, hid), nn.GELU(), nn.Linear(hid, cout)).to(DEV)
+    ref = copy.deepcopy(seq)
+    if (cin, hid, cout) == (3, 128, 256):
+        assert [tuple(p.shape) for p in build_pos_embed(3, 256).parameters()] == [tuple(p.shape) for p in seq.parameters()]
+    x = (torch.randn(*rows_shape, cin, device=DEV) * 2).requires_grad_(x_grad)
+    xr = x.detach().clone().requires_grad_(x_grad)
+    res = torch.randn(*rows_shape, cout, device=DEV, requires_grad=True)
+    rr = res.detach().clone().requires_grad_(True)
+    G = torch.randn(*rows_shape, cout, device=DEV)
+    assert _covered(seq, x, res)
+    out = pos_embed_add(seq, x, res)
+    want = rr + ref(xr)
+    # 1e-5 relative to the tensor's scale: f32 dot products of 128 terms in a different order
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5 * float(want.detach().abs().max()))
+    (out * G).sum().backward()
+    (want * G).sum().backward()
+    torch.testing.assert_close(res.grad, rr.grad, rtol=0, atol=0)
+    for (n, p), q in zip(seq.named_parameters(), ref.parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(q.grad.abs().max())), msg=lambda m: n + ": " + m)
+    if x_grad:
+        torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(xr.grad.abs().max())))
+
+
+def test_pos_embed_add_falls_back_for_what_the_kernels_do_not_cover():
+    from situation3d_amd.small_mlp import _covered, pos_embed_add
+    seq = nn.Sequential(nn.Linear(3, 128), nn.GELU(approximate="tanh"), nn.Linear(128, 256)).to(DEV)
+    x, res = torch.randn(4, 3, device=DEV), torch.randn(4, 256, device=DEV)
+    assert not _covered(seq, x, res)
+    torch.testing.assert_close(pos_embed_add(seq, x, res), res + seq(x))
+    wide = nn.Sequential(nn.Linear(3, 256), nn.GELU(), nn.Linear(256, 256)).to(DEV)
+    assert not _covered(wide, x, res)
+    cpu = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, 256))
+    assert not _covered(cpu, x.cpu(), res.cpu())
+    torch.testing.assert_close(pos_embed_add(cpu, x.cpu(), res.cpu()), res.cpu() + cpu(x.cpu()))
