@@ -5,10 +5,15 @@
 forward launch and two backward launches instead of torch's 4 + ~12.  The module's own parameters are used (same
 state_dict); anything the kernels do not cover (CPU tensors, other shapes, a tanh GELU) takes the torch path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+# SIG3D_SMALL_MLP=0: the torch modules (A/B timing; same results up to f32 summation order)
+ENABLED = os.environ.get("SIG3D_SMALL_MLP", "1") != "0"
 
 
 class _PosMLPFn(torch.autograd.Function):
@@ -47,7 +52,7 @@ class _PosMLPFn(torch.autograd.Function):
 
 
 def _covered(seq, x, residual):
-    if not (isinstance(seq, nn.Sequential) and len(seq) == 3):
+    if not (ENABLED and isinstance(seq, nn.Sequential) and len(seq) == 3):
         return False
     l1, act, l2 = seq[0], seq[1], seq[2]
     if not (isinstance(l1, nn.Linear) and isinstance(l2, nn.Linear) and isinstance(act, nn.GELU)):
