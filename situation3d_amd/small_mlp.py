@@ -62,7 +62,7 @@ def _covered(seq, x, residual):
     if not (x.is_cuda and x.dtype == torch.float32 and residual.is_cuda and residual.dtype == torch.float32):
         return False
     hid, cin = l1.weight.shape
-    return cin <= 4 and hid <= 128 and hid % 4 == 0 and l2.weight.shape[1] == hid and l2.weight.shape[0] <= 1024 \
+    return cin <= 4 and hid <= 128 and hid % 4 == 0 and l2.weight.shape[1] == hid and l2.weight.shape[0] % 4 == 0 \
         and x.shape[-1] == cin and residual.shape[-1] == l2.weight.shape[0] and residual.shape[:-1] == x.shape[:-1]
 
 
