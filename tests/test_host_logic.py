@@ -232,3 +232,24 @@ def test_point_major_twins_and_scan_attachment_are_validated():
     feats = fused_mlp.attach_scan(pc[..., 3:].transpose(1, 2), pc)
     assert feats._points_pm is pc and not feats.is_contiguous()
     assert fused_mlp.first_layer_scan(None, pc[..., :3], feats, True) is None      # CPU: never the HIP path
+
+
+def test_ball_query_levels_workspace_is_host_arithmetic():
+    """sig3d_ball_query_levels_workspace_bytes plans a multi-level launch on the host (no GPU call): scenes of at most
+    4096 points take the in-LDS ordered scan and need no scratch; larger ones a counter + 256 list slots per centre;
+    more than 16 blocks of 4096 centres do not fit one launch (-1)."""
+    from situation3d_amd import _lib
+    lib = _lib.load()
+
+    def levels(specs):
+        arr = (_lib.BqLevel * len(specs))()
+        for q, (n, m, ns, r) in zip(arr, specs):
+            q.n, q.m, q.nsample, q.radius = n, m, ns, r
+        return arr
+
+    stack = levels([(40000, 2048, 64, 0.2), (2048, 1024, 32, 0.4), (1024, 512, 16, 0.8), (512, 256, 16, 1.2)])
+    assert lib.sig3d_ball_query_levels_workspace_bytes(8, 4, stack) == 8 * 2048 * 4 * 257      # SA1 only
+    assert lib.sig3d_ball_query_levels_workspace_bytes(8, 3, levels([(2048, 1024, 32, 0.4)] * 3)) == 0
+    assert lib.sig3d_ball_query_levels_workspace_bytes(2, 1, levels([(50000, 5000, 8, 0.3)])) == 2 * 5000 * 4 * 257
+    assert lib.sig3d_ball_query_levels_workspace_bytes(1, 1, levels([(50000, 17 * 4096, 8, 0.3)])) == -1
+    assert lib.sig3d_ball_query_levels_workspace_bytes(0, 1, stack) == 0
