@@ -276,7 +276,8 @@ def cpu_baseline(model, seed):
 
 TIMED_ENTRY_POINTS = ["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
                       "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query",
-                      "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_furthest_point_sampling",
+                      "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_ball_query_levels_ex",
+                      "sig3d_furthest_point_sampling",
                       "sig3d_sa_first_layer_fwd", "sig3d_sa_first_layer_dw"]
 KSTEPS = 3   # eager steps bracketed with HIP events after the timed region
 
@@ -393,7 +394,7 @@ def pair_roofline(recs, distinct):
     for name in ("sig3d_ball_query", "sig3d_ball_query_grid"):
         for s_ev, e_ev, ints in recs[name]:
             add(name, s_ev.elapsed_time(e_ev), ball_query_algorithmic_bytes(ints[0], ints[1], ints[2], ints[3]))
-    for s_ev, e_ev, ints in recs["sig3d_ball_query_levels"]:   # all four levels of the stack in one launch pair
+    for s_ev, e_ev, ints in recs["sig3d_ball_query_levels"] + recs["sig3d_ball_query_levels_ex"]:   # SA1-4 in one launch pair
         add("sig3d_ball_query_levels", s_ev.elapsed_time(e_ev),
             sum(ball_query_algorithmic_bytes(ints[0], n, m, ns) for n, m, ns, _ in SA_LEVELS))
     for name, pm in (("sig3d_query_group_fused", False), ("sig3d_query_group_fused_pm", True)):
@@ -555,7 +556,8 @@ def main():
         adam_gbs = 28.0 * n_params * KSTEPS / (sum(adam) * 1e-3) / 1e9 if adam else 0.0
         tr = kernel_ms("sig3d_transpose_cn")
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
-        bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid") + kernel_ms("sig3d_ball_query_levels")
+        bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid") + kernel_ms("sig3d_ball_query_levels") \
+            + kernel_ms("sig3d_ball_query_levels_ex")
         fps = kernel_ms("sig3d_furthest_point_sampling")
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)

@@ -108,6 +108,12 @@ typedef struct {
 long sig3d_ball_query_levels_workspace_bytes(int b, int nlevels, const sig3d_bq_level *levels);
 int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                             long workspace_bytes, void *stream);
+/* flags: SIG3D_BQ_CLEAN = the caller vouches that `workspace` has been through a completed call with the SAME
+ * (b, levels sizes) since it was last written by anyone else: the per-centre counters are then zero (the rank kernel
+ * zeroes each one it reads) and the memset in front of the launch pair is skipped.  flags = 0 is always safe. */
+#define SIG3D_BQ_CLEAN 1
+int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
+                               long workspace_bytes, int flags, void *stream);
 
 /* One problem through sig3d_ball_query_levels (the round-1 name: it was a hashed grid over the points).
  * workspace: 1028 * b * m bytes.  n < 256, radius <= 0 or more than 65536 centres are forwarded to

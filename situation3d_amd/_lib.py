@@ -136,6 +136,8 @@ class BqLevel(ctypes.Structure):
 
 
 SIGNATURES["sig3d_ball_query_levels"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _P]
+SIGNATURES["sig3d_ball_query_levels_ex"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P]
+BQ_CLEAN = 1
 
 
 def bq_levels(problems):

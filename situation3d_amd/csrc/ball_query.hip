@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
   BQ_MARK(8);
 }
 
-__global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, const int *__restrict__ cnt,
+__global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, int *__restrict__ cnt,
                                                        const int *__restrict__ list) {
   __shared__ int s_list[BQC_RANK_CENTRES][BQC_CAP];
   int li = 0;
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, const int *_
   const bool valid = slot < P.b * m;
   const int bi = valid ? slot / m : 0, j = valid ? slot % m : 0;
   const int c = valid ? cnt[L.ctr_begin + slot] : 0;
+  if (valid && l16 == 0) cnt[L.ctr_begin + slot] = 0;   // the counters leave as they must arrive: zero (SIG3D_BQ_CLEAN)
   int *row = L.idx + ((size_t)bi * L.m_total + L.c_off + j) * nsample;
   const int *lst = list + ((size_t)L.ctr_begin + slot) * BQC_CAP;
   int *s = s_list[grp];
@@ -527,6 +528,11 @@ extern "C" long sig3d_ball_query_levels_workspace_bytes(int b, int nlevels, cons
 
 extern "C" int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                                        long workspace_bytes, void *stream_) {
+  return sig3d_ball_query_levels_ex(b, nlevels, levels, workspace, workspace_bytes, 0, stream_);
+}
+
+extern "C" int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
+                                          long workspace_bytes, int flags, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && nlevels >= 0 && (nlevels == 0 || levels != nullptr), "bad arguments");
   if (b == 0 || nlevels == 0) return 0;
@@ -547,7 +553,9 @@ extern "C" int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level 
   const long slots = need / (long)(sizeof(int) * (1 + BQC_CAP));
   int *cnt = (int *)workspace;
   int *list = cnt + slots;
-  if (slots > 0) SIG3D_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)slots, stream));
+  // the rank kernel zeroes every counter it reads, so a workspace that has been through one call (same problem
+  // list) is clean: SIG3D_BQ_CLEAN lets the caller vouch for that and saves the memset node
+  if (slots > 0 && !(flags & SIG3D_BQ_CLEAN)) SIG3D_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)slots, stream));
   if (wgs > 0) {
     if (lds > 48 * 1024)
       SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)bqc_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

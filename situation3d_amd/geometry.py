@@ -34,6 +34,7 @@ class GeometryPlan:
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
         self._bq_work = None    # scratch of the multi-level ball query (allocated once: static under hipGraph)
+        self._bq_clean = False  # True once the workspace has been through a call (counters zero again)
         self._bq_levels = None  # its level table (ctypes array of sig3d_bq_level: raw pointers of the plan's buffers)
         n = n_points
         for npoint, radius, nsample in self.levels:
@@ -85,8 +86,11 @@ class GeometryPlan:
                 if self._bq_work is None or self._bq_work.numel() < need:
                     self._bq_work = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
                 self._bq_srcs = ptrs
-            _lib.call("sig3d_ball_query_levels", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
-                      self._bq_work.numel(), s)
+                self._bq_clean = False   # a new workspace / problem list: the next call zeroes the counters itself
+            # after one completed call the workspace's counters are zero again (the rank kernel cleans up): no memset
+            _lib.call("sig3d_ball_query_levels_ex", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
+                      self._bq_work.numel(), _lib.BQ_CLEAN if self._bq_clean else 0, s)
+            self._bq_clean = True
             for lvl in range(len(self.levels)):
                 if self.compact[lvl] is not None:
                     self.compact[lvl].compute(self.ball_idx[lvl])

@@ -259,19 +259,28 @@ def test_gather_xyz_matches_reference_spelling(hip_ext):
 
 
 def test_geometry_plan_equals_inline_ops(hip_ext):
+    """... for several scenes through the SAME plan: from the second call on the multi-level ball query runs without
+    its memset (SIG3D_BQ_CLEAN: the rank kernel left the counters zero), the lists must still be exact -- dense
+    clusters (more hits than list slots) and a changed input buffer included."""
     from situation3d_amd.geometry import GeometryPlan
     from util import scene
-    xyz = scene(2, 6000, seed=8).to(DEV)
     levels = [(512, 0.3, 16), (128, 0.6, 8)]
-    plan = GeometryPlan(2, 6000, levels, DEV).compute(xyz)
-    cur = xyz
-    for i, (m, r, ns) in enumerate(levels):
-        inds = hip_ext.furthest_point_sampling(cur, m)
-        new = hip_ext.gather_points(cur.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
-        idx = hip_ext.ball_query(new, cur, r, ns)
-        assert torch.equal(plan.inds[i], inds) and torch.equal(plan.new_xyz[i], new)
-        assert torch.equal(plan.ball_idx[i], idx)
-        cur = new
+    plan = GeometryPlan(2, 6000, levels, DEV)
+    for seed in (8, 9, 10, 11):
+        xyz = scene(2, 6000, seed=seed, dup=500 if seed == 9 else 0)
+        if seed == 10:
+            xyz[:, 1000:1700] = xyz[:, 999:1000]        # 700 coincident points: counters far beyond the 256 slots
+        xyz = xyz.to(DEV)
+        plan.compute(xyz)
+        assert plan._bq_clean
+        cur = xyz
+        for i, (m, r, ns) in enumerate(levels):
+            inds = hip_ext.furthest_point_sampling(cur, m)
+            new = hip_ext.gather_points(cur.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+            idx = hip_ext.ball_query(new, cur, r, ns)
+            assert torch.equal(plan.inds[i], inds) and torch.equal(plan.new_xyz[i], new)
+            assert torch.equal(plan.ball_idx[i], idx), (seed, i)
+            cur = new
 
 
 @pytest.mark.parametrize("prefetch", [False, True])
