@@ -47,6 +47,8 @@ def parse_args(argv=None):
                     help="skip the stand-alone dense op-level pair (roofline_ops); for --pmc passes over the step's own kernels")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute FPS/ball-query geometry inline instead of one batch ahead")
+    ap.add_argument("--geo-depth", type=int, default=int(os.environ.get("SIG3D_GEO_DEPTH", "1")),
+                    help="geometry chains in flight beside the step (geometry.GeometryPipeline; 1 = round 2's one-ahead)")
     return ap.parse_args(argv)
 
 
@@ -308,11 +310,12 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
         with torch.cuda.stream(work):
             use_graph = not args.no_graph
             if use_graph:
-                graphed = GraphedTrainStep(model, optimizer, batches[0],
-                                           prefetch_geometry=not args.no_prefetch, reducer=reducer)
+                graphed = GraphedTrainStep(model, optimizer, batches[0], prefetch_geometry=not args.no_prefetch,
+                                           reducer=reducer, prefetch_depth=args.geo_depth)
+                depth = graphed.prefetch_depth
 
                 def step(i):
-                    return graphed(batches[i % n_batches], batches[(i + 1) % n_batches])
+                    return graphed(batches[i % n_batches], upcoming=[batches[(i + 1 + k) % n_batches] for k in range(depth)])
             else:
                 def step(i):
                     return train_step(model, optimizer, dict(batches[i % n_batches]), reducer=reducer)
@@ -587,7 +590,8 @@ def main():
                                    "SA1-4 -> 256 tokens -> situational re-encode -> Q-Former "
                                    "(32 queries + 20 question tokens, 12 layers)",
                        "global_batch": world * BATCH, "points_per_scene": N_POINTS,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world,
+                       "geometry_chains_in_flight": 0 if args.no_prefetch or args.no_graph else args.geo_depth},
             # the pair the north star names, all four levels of a step, compact launches at their own bytes;
             # dense-equivalent = SURVEY.md 8d's 314.8 MB per step over the same time
             "roofline": {"bound": "hbm", "kernel": "ball_query (all levels, cell-binned centres) + query_group (fused / point-major / "

@@ -35,6 +35,19 @@ const char *sig3d_last_error(void);       /* thread-local message of the last fa
 int sig3d_timestamp(unsigned long long *slot, void *stream);
 int sig3d_timestamp_rate(int device, long long *hz);
 
+/* Device-side handshake between two streams of one device (no reference counterpart: the reference runs one stream).
+ * sig3d_ticket_signal: *ticket += 1 (release, agent scope) as a one-lane kernel on `stream`.
+ * sig3d_ticket_wait: a one-lane kernel on `stream` that spins until *ticket has passed *consumed, then sets
+ * *consumed += 1; after `timeout_us` it sets *error = 1 and returns anyway.  ticket / consumed / error are device
+ * words the caller zeroes once.  Replaces hipStreamWaitEvent where the waiting stream would otherwise hold a blocked
+ * barrier packet for milliseconds (see csrc/capi.hip). */
+int sig3d_stream_create_with_cu_mask(int words, const unsigned int *mask, void **stream);
+int sig3d_stream_destroy(void *stream);
+int sig3d_whereami(unsigned int *slots, int blocks, int threads, int hold_us, void *stream);
+int sig3d_ticket_signal(unsigned int *ticket, void *stream);
+int sig3d_ticket_wait(const unsigned int *ticket, unsigned int *consumed, long long timeout_us, int *error,
+                      void *stream);
+
 /* ---- PointNet++ ops: lib/pointnet2/_ext_src ------------------------------------------ */
 
 /* replaces furthest_point_sampling_kernel_wrapper(b,n,m,dataset,temp,idxs)
@@ -407,6 +420,11 @@ int sig3d_adamw_flat(long n, float *p, float *g, float *m, float *v, const float
 int sig3d_adamw_table(int nchunks, const void *table, const float *step, float lr,
                       const float *lr_device, float beta1, float beta2, float eps, float clip_value,
                       void *stream);
+/* The same launch with at most `max_workgroups` workgroups walking the table: an update issued beside another
+ * stream's kernels (a forked hipGraph branch) leaves them CU slots instead of filling the chip. */
+int sig3d_adamw_table_bounded(int nchunks, const void *table, const float *step, float lr,
+                              const float *lr_device, float beta1, float beta2, float eps, float clip_value,
+                              int max_workgroups, void *stream);
 int sig3d_gather_table(int nchunks, const void *table, void *stream);
 
 /* ---- Q-Former dense layers -------------------------------------------------------------- */

@@ -82,7 +82,13 @@ SIGNATURES = {
     "sig3d_counter_increment": [_P, _P],
     "sig3d_step_increment": [_P, _P],
     "sig3d_adamw_flat": [ctypes.c_long, _P, _P, _P, _P, _P, _F, _P, _F, _F, _F, _F, _F, _I, _P],
+    "sig3d_stream_create_with_cu_mask": [_I, _P, _P],
+    "sig3d_stream_destroy": [_P],
+    "sig3d_whereami": [_P, _I, _I, _I, _P],
+    "sig3d_ticket_signal": [_P, _P],
+    "sig3d_ticket_wait": [_P, _P, ctypes.c_longlong, _P, _P],
     "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],
+    "sig3d_adamw_table_bounded": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _I, _P],
     "sig3d_gather_table": [_I, _P, _P],
     "sig3d_gemm": [_I, _I, _I, _I, _I, _I, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long,
                    _P, ctypes.c_long, _I, _P, _I, _P, ctypes.c_long, _I, _I, _P],

@@ -49,3 +49,94 @@ extern "C" int sig3d_timestamp_rate(int device, long long *hz) {
   *hz = (long long)khz * 1000;
   return 0;
 }
+
+// ---- device-side stream handshake ---------------------------------------------------------------
+// "Stream B starts after stream A reaches this point" is normally hipStreamWaitEvent: a barrier packet at the head
+// of B's hardware queue.  While that barrier is BLOCKED the command processor polls it between the packets of every
+// other queue: measured on this runtime, each kernel of the busy stream then costs ~1.7 us more
+// (tools/probes/fork_penalty.py: a 450-node graph 5.85 -> 6.65 ms with nothing but a blocked barrier on a second
+// stream).  A host that runs a step ahead keeps such a barrier blocked for milliseconds.  These two one-lane kernels
+// move the wait onto a CU: A bumps a ticket counter, B's first kernel spins (agent-scope loads, s_sleep) until the
+// ticket passes the count it has consumed.  Both are ordinary graph nodes.  The waiter gives up after `timeout_ticks`
+// of the 100 MHz wall clock and raises *error (a crashed producer must not hang the device).
+namespace {
+__global__ void ticket_signal_kernel(unsigned int *ticket) {
+  __threadfence();
+  __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void ticket_wait_kernel(const unsigned int *ticket, unsigned int *consumed, unsigned long long timeout_ticks,
+                                   int *error) {
+  const unsigned int want = *consumed + 1u;
+  const unsigned long long t0 = wall_clock64();
+  // signed distance: tickets wrap after 2^32 steps
+  while ((int)(__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      *error = 1;
+      break;
+    }
+  }
+  *consumed = want;
+  __threadfence();
+}
+}  // namespace
+
+extern "C" int sig3d_ticket_signal(unsigned int *ticket, void *stream_) {
+  SIG3D_REQUIRE(ticket != nullptr, "ticket must not be null");
+  hipLaunchKernelGGL(ticket_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, ticket);
+  SIG3D_LAUNCH_CHECK("ticket_signal_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_ticket_wait(const unsigned int *ticket, unsigned int *consumed, long long timeout_us, int *error,
+                                 void *stream_) {
+  SIG3D_REQUIRE(ticket != nullptr && consumed != nullptr && error != nullptr, "null pointer");
+  SIG3D_REQUIRE(timeout_us > 0, "timeout must be positive");
+  hipLaunchKernelGGL(ticket_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, ticket, consumed,
+                     (unsigned long long)timeout_us * 100ull, error);
+  SIG3D_LAUNCH_CHECK("ticket_wait_kernel");
+  return 0;
+}
+
+// ---- CU-masked streams ---------------------------------------------------------------------------
+// The geometry chain (cooperative FPS: 64 workgroups that sleep and poll for ~7 ms) shares the chip with the
+// training step.  A step kernel's duration is that of its SLOWEST workgroup, so 64 CUs that also host an FPS
+// workgroup stretch every chip-wide launch of the step.  A stream created with a CU mask confines the chain to a
+// few CUs (and, optionally, the step to the others).  Mask bit k addresses XCD k % 8, CU slot k / 8 of that XCD
+// (verified with sig3d_whereami, tools/probes/cu_mask_probe.py).
+extern "C" int sig3d_stream_create_with_cu_mask(int words, const unsigned int *mask, void **stream) {
+  SIG3D_REQUIRE(words > 0 && mask != nullptr && stream != nullptr, "bad arguments");
+  hipStream_t s = nullptr;
+  SIG3D_HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream = (void *)s;
+  return 0;
+}
+
+extern "C" int sig3d_stream_destroy(void *stream) {
+  if (stream) SIG3D_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+__global__ void whereami_kernel(unsigned int *slots, unsigned long long hold_ticks) {
+  unsigned int hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) {
+    slots[2 * blockIdx.x + 0] = hw;
+    slots[2 * blockIdx.x + 1] = xcc;
+  }
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);   // keep the CU so the grid spreads out
+}
+}  // namespace
+
+// Diagnostic: workgroup i of `blocks` x `threads` stores {HW_ID, XCC_ID} into slots[2i..2i+1] and holds its CU for
+// hold_us microseconds.  HW_ID: cu_id bits 11:8, sh_id bit 12, se_id bits 15:13; XCC_ID: bits 3:0.
+extern "C" int sig3d_whereami(unsigned int *slots, int blocks, int threads, int hold_us, void *stream_) {
+  SIG3D_REQUIRE(slots != nullptr && blocks > 0 && threads > 0 && threads <= 1024, "bad arguments");
+  hipLaunchKernelGGL(whereami_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream_, slots,
+                     (unsigned long long)hold_us * 100ull);
+  SIG3D_LAUNCH_CHECK("whereami_kernel");
+  return 0;
+}

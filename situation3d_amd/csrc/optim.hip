@@ -82,16 +82,9 @@ struct OptChunk {
   float pad;
 };
 
-__global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__restrict__ table,
-                                                          const float *__restrict__ step, float lr,
-                                                          const float *__restrict__ lr_device,
-                                                          float b1, float b2, float eps, float clip) {
-  const OptChunk c = table[blockIdx.x];
+__device__ __forceinline__ void adamw_chunk(const OptChunk c, float lr, float b1, float b2, float eps, float clip,
+                                            float step_size, float inv_sqrt_bc2) {
   if (c.n <= 0) return;            // a parameter without a gradient this step: untouched (torch skips it)
-  if (lr_device) lr = *lr_device;  // a scheduler's value, read at execution time (hipGraph replays)
-  const float t = *step;
-  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
-  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   const bool vec = ((((size_t)c.p | (size_t)c.g | (size_t)c.m | (size_t)c.v) & 15) == 0);
   const long n4 = vec ? (c.n >> 2) : 0;
   // streaming update: nothing here is re-read before it falls out of the 256 MB Infinity Cache
@@ -141,6 +134,20 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__rest
   }
 }
 
+// gridDim.x == nchunks: one workgroup per chunk (the whole chip streams).  gridDim.x < nchunks: a bounded set of
+// workgroups walks the table (an update that shares the chip with another stream's kernels leaves them CU slots).
+__global__ __launch_bounds__(256) void adamw_table_kernel(const OptChunk *__restrict__ table, int nchunks,
+                                                          const float *__restrict__ step, float lr,
+                                                          const float *__restrict__ lr_device,
+                                                          float b1, float b2, float eps, float clip) {
+  if (lr_device) lr = *lr_device;  // a scheduler's value, read at execution time (hipGraph replays)
+  const float t = *step;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (int k = blockIdx.x; k < nchunks; k += gridDim.x)
+    adamw_chunk(table[k], lr, b1, b2, eps, clip, step_size, inv_sqrt_bc2);
+}
+
 // dst (chunk.m field reused as destination) <- src (chunk.g): gather scattered gradients into
 // flat storage for the data-parallel all-reduce
 __global__ __launch_bounds__(256) void gather_table_kernel(const OptChunk *__restrict__ table) {
@@ -160,7 +167,19 @@ extern "C" int sig3d_adamw_table(int nchunks, const void *table, const float *st
   SIG3D_REQUIRE(nchunks >= 0, "negative size");
   if (nchunks == 0) return 0;
   hipLaunchKernelGGL(adamw_table_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream_,
-                     (const OptChunk *)table, step, lr, lr_device, beta1, beta2, eps, clip_value);
+                     (const OptChunk *)table, nchunks, step, lr, lr_device, beta1, beta2, eps, clip_value);
+  SIG3D_LAUNCH_CHECK("adamw_table_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_adamw_table_bounded(int nchunks, const void *table, const float *step, float lr,
+                                         const float *lr_device, float beta1, float beta2, float eps,
+                                         float clip_value, int max_workgroups, void *stream_) {
+  SIG3D_REQUIRE(nchunks >= 0 && max_workgroups >= 1, "bad size");
+  if (nchunks == 0) return 0;
+  const int grid = nchunks < max_workgroups ? nchunks : max_workgroups;
+  hipLaunchKernelGGL(adamw_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_,
+                     (const OptChunk *)table, nchunks, step, lr, lr_device, beta1, beta2, eps, clip_value);
   SIG3D_LAUNCH_CHECK("adamw_table_kernel");
   return 0;
 }

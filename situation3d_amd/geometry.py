@@ -25,6 +25,27 @@ from .pointnet2 import _ext, fused_mlp
 NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
 
 
+class Announced:
+    """Identity of the batch whose geometry the forked branch computed during the previous replay.
+    A device address is NOT an identity (the caching allocator recycles addresses; a loader that refills one
+    staging buffer in place passes the same address every step), so the hand-over is keyed on
+      * an explicit `token` (step / sequence id) when the caller passes one, else
+      * the announced tensor OBJECT (kept referenced here, so its storage cannot be recycled) together with
+        its autograd version counter, which every in-place write through any view of it advances.
+    Anything else -- a different object, a refilled buffer, a missing token -- recomputes the geometry inline."""
+
+    def __init__(self):
+        self.tensor = self.version = self.token = None
+
+    def set(self, tensor, token=None):
+        self.tensor, self.version, self.token = tensor, tensor._version, token
+
+    def matches(self, tensor, token=None):
+        if token is not None or self.token is not None:
+            return token is not None and token == self.token
+        return tensor is self.tensor and tensor._version == self.version
+
+
 class GeometryPlan:
     """levels: list of (npoint, radius, nsample) from the first SA layer down."""
 
@@ -111,3 +132,88 @@ class GeometryPlan:
             from .table_copy import TableCopy
             self._table_copy = TableCopy(self.inds[0].device)
         self._table_copy(pairs)
+
+
+_HANDSHAKE_TIMEOUT_US = 30 * 1000 * 1000   # sig3d_ticket_wait gives up (and raises its error word) after this long
+
+
+class GeometryPipeline:
+    """The geometry chains of the next `depth` batches in flight, each a hipGraph of its own on a stream of its own,
+    beside a consumer (training step / forward) that stays ONE linear graph on the caller's stream.
+
+    Every in-flight batch has a slot {plan, coordinate buffer, stream, graph}.  `advance(batch i)`:
+      1. waits for the chain of batch i (launched `depth` calls ago) and hands its plan over to `plan_cur`, the plan
+         the consumer's graph reads (one table copy) -- or computes it inline when the caller broke the announced
+         order (graph_step.Announced: tokens, or tensor object + version; never a device address);
+      2. stages the coordinates of batch i + depth and launches its chain on the slot that has just become free.
+    depth 1 is round 2's "geometry of batch i+1 under step i".  With the step at ~7.4 ms and ONE chain taking ~7.5 ms
+    beside it (3.6 ms alone: the FPS rounds wait on a loaded memory system), the chain had become the critical path
+    again; two chains in flight give each of them two steps.
+
+    The chains start behind a device-side handshake (sig3d_ticket_signal on the consumer's stream once the
+    coordinates are staged, sig3d_ticket_wait as the slot graph's first node) instead of slot.stream.wait_stream():
+    the host runs ahead, so that barrier packet would sit blocked at the head of the slot's hardware queue, and the
+    command processor's polling of a blocked barrier costs every kernel the consumer dispatches meanwhile ~1.7 us
+    (tools/probes/fork_penalty.py).  `handshake=False` restores the stream wait."""
+
+    def __init__(self, batch, n_points, levels, device, stream, depth=1, handshake=True, stream_priority=0):
+        assert depth >= 1
+        self.depth, self.stream, self.device, self.handshake = int(depth), stream, device, bool(handshake)
+        self.plan_cur = GeometryPlan(batch, n_points, levels, device)
+        self.slots = []
+        self._words = torch.zeros(4 * self.depth, dtype=torch.int32, device=device)   # per slot: ticket, consumed, error
+        example = torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device)
+        for k in range(self.depth):
+            self.slots.append(dict(plan=GeometryPlan(batch, n_points, levels, device), xyz=example.clone(),
+                                   stream=torch.cuda.Stream(device, priority=stream_priority), graph=torch.cuda.CUDAGraph(),
+                                   announced=Announced(), words=self._words[4 * k:4 * k + 4]))
+        for slot in self.slots:                       # scratch allocations and copy tables, outside any capture
+            slot["plan"].compute(slot["xyz"])
+            self.plan_cur.copy_from(slot["plan"])
+        self.calls = 0
+        self.inline_chains = 0    # batches whose geometry had to be computed on the consumer's stream
+
+    def capture(self, pool=None, capture_error_mode="global"):
+        """Capture the slot graphs (after the consumer's graph, whose memory pool they may share: a chain allocates
+        nothing)."""
+        for slot in self.slots:
+            w = slot["words"]
+            slot["stream"].wait_stream(self.stream)
+            kw = dict(pool=pool) if pool is not None else {}
+            with torch.cuda.graph(slot["graph"], stream=slot["stream"], capture_error_mode=capture_error_mode, **kw):
+                if self.handshake:
+                    _lib.call("sig3d_ticket_wait", _lib.ptr(w[0:1]), _lib.ptr(w[1:2]), _HANDSHAKE_TIMEOUT_US,
+                              _lib.ptr(w[2:3]), _lib.stream_ptr(self.device))
+                slot["plan"].compute(slot["xyz"])
+            self.stream.wait_stream(slot["stream"])
+
+    def advance(self, point_clouds, upcoming, token=None, upcoming_tokens=None):
+        """`point_clouds`: (B,N,3+C) of the batch the consumer is about to run; `upcoming`: those of the next `depth`
+        calls, in order (upcoming[-1] is the one whose chain starts now).  Call on the consumer's stream, BEFORE
+        replaying its graph."""
+        if len(upcoming) != self.depth:
+            raise ValueError("a geometry pipeline of depth %d needs the next %d batches" % (self.depth, self.depth))
+        toks = list(upcoming_tokens) if upcoming_tokens is not None else [None] * self.depth
+        slot = self.slots[self.calls % self.depth]
+        self.stream.wait_stream(slot["stream"])              # the chain launched `depth` calls ago (any chain: its
+        if slot["announced"].matches(point_clouds, token):   # coordinate buffer is about to be overwritten)
+            self.plan_cur.copy_from(slot["plan"])
+        else:                                                # prologue, or the caller broke the announced order
+            self.plan_cur.compute(point_clouds[..., :3].contiguous())
+            self.inline_chains += 1
+        far = upcoming[-1]
+        slot["xyz"].copy_(far[..., :3], non_blocking=True)
+        slot["announced"].set(far, toks[-1])
+        if self.handshake:                                   # coordinates staged, plan handed over: the slot may start
+            with torch.cuda.device(self.device):
+                _lib.call("sig3d_ticket_signal", _lib.ptr(slot["words"][0:1]), self.stream.cuda_stream)
+        else:
+            slot["stream"].wait_stream(self.stream)
+        with torch.cuda.stream(slot["stream"]):
+            slot["graph"].replay()
+        self.calls += 1
+
+    def timed_out(self):
+        """True when a chain ever gave up waiting for its ticket (it then ran anyway: a plan may be stale).
+        Synchronises; meant for the end of a run or a logging interval."""
+        return bool(self._words.view(self.depth, 4)[:, 2].any().item())

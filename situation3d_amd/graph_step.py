@@ -1,4 +1,4 @@
-"""hipGraph capture of the training step (+ geometry prefetch on a forked branch).
+"""hipGraph capture of the training step (+ the geometry chain of the next batch beside it).
 
 One step of the composed hot path is ~2000 kernel launches (12 Q-Former layers x ~40 small
 kernels forward, twice that backward, 4 SA levels, the optimizer).  Issued eagerly from Python
@@ -11,12 +11,14 @@ nodes, no entry point synchronises or allocates, and the optimizer runs in `capt
 
 Geometry prefetch.  FPS / centre gather / ball query depend on xyz only (geometry.py) and FPS is
 a latency-bound chain that keeps a handful of CUs busy for milliseconds.  With
-`prefetch_geometry=True` the graph has TWO branches: the training step of batch i (reading the
-geometry plan computed during the previous replay) and, forked onto a second stream, the
-geometry plan of batch i+1.  The branches join at the end of the graph, where the freshly
-computed plan is handed over.  Every step still performs the full work of one batch (one
-geometry chain + one training pass); only the order is pipelined, like a data loader running one
-batch ahead.  The plan is bit-identical to computing it inline.
+`prefetch_geometry=True` the geometry plan of batch i+1 is computed while the training step of
+batch i (reading the plan computed during the previous call) runs: the chain is a hipGraph of its
+own on a stream of its own (geometry.GeometryPipeline) beside the step's graph, which stays ONE
+linear chain, and the fresh plan is handed over at the start of the next call.  (Rounds 1-2 forked
+the chain inside the step's graph and joined it at the end: SIG3D_GEO_FORK=inline, slower, see
+DESIGN.md section 4e.)  Every step still performs the full work of one batch (one geometry chain +
+one training pass); only the order is pipelined, like a data loader running one batch ahead.  The
+plan is bit-identical to computing it inline.
 
 Stream discipline: warm-up, capture, replay and any eager steps of the same model must all run
 on ONE non-default stream (`with torch.cuda.stream(work): ...`).  Autograd's AccumulateGrad
@@ -35,7 +37,7 @@ import torch
 import torch.nn as nn
 
 from . import gemm_tuning, timeline
-from .geometry import GeometryPlan
+from .geometry import Announced, GeometryPipeline, GeometryPlan  # noqa: F401  (Announced: re-exported)
 from .trainer import get_loss
 
 
@@ -83,27 +85,6 @@ def _flush_deferred(model):
         enc.flush_weight_grads()
 
 
-class Announced:
-    """Identity of the batch whose geometry the forked branch computed during the previous replay.
-    A device address is NOT an identity (the caching allocator recycles addresses; a loader that refills one
-    staging buffer in place passes the same address every step), so the hand-over is keyed on
-      * an explicit `token` (step / sequence id) when the caller passes one, else
-      * the announced tensor OBJECT (kept referenced here, so its storage cannot be recycled) together with
-        its autograd version counter, which every in-place write through any view of it advances.
-    Anything else -- a different object, a refilled buffer, a missing token -- recomputes the geometry inline."""
-
-    def __init__(self):
-        self.tensor = self.version = self.token = None
-
-    def set(self, tensor, token=None):
-        self.tensor, self.version, self.token = tensor, tensor._version, token
-
-    def matches(self, tensor, token=None):
-        if token is not None or self.token is not None:
-            return token is not None and token == self.token
-        return tensor is self.tensor and tensor._version == self.version
-
-
 def _bn_momenta(model):
     return [m.momentum for m in model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
 
@@ -113,7 +94,8 @@ class GraphedTrainStep:
     (lib/solver.py:374-402, 618-627) for one fixed batch shape, on the CURRENT stream."""
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
-                 prefetch_geometry=False, geometry_levels=None, reducer=None, split_backward=True):
+                 prefetch_geometry=False, geometry_levels=None, reducer=None, split_backward=True,
+                 prefetch_depth=None):
         """`reducer` (ddp.GradBucketReducer, data parallel): the step becomes graph A (forward +
         backward, gradients accumulated into the reducer's flat buckets) -> eager bucketed RCCL
         all-reduce -> graph B (value clip + AdamW).  No collective is ever captured."""
@@ -131,6 +113,14 @@ class GraphedTrainStep:
         if reducer is not None:
             reducer.hooks_enabled = False
         self.prefetch = bool(prefetch_geometry)
+        # Where the geometry chains run.  Default: geometry.GeometryPipeline -- the chains of the next
+        # `prefetch_depth` batches (default 1; bench.py runs 2) as graphs of their own on streams of their own, beside
+        # the step's graph, which stays ONE linear chain.  SIG3D_GEO_FORK=inline (single GPU only): rounds 1-2's
+        # branch forked inside the step's graph and joined at its end -- every kernel node enqueued while another
+        # queue holds a blocked barrier costs ~1.7 us extra on this runtime (tools/probes/fork_penalty.py).
+        self._geo_inline = bool(self.prefetch and reducer is None and os.environ.get("SIG3D_GEO_FORK", "graph") == "inline")
+        self.prefetch_depth = 1 if self._geo_inline or not self.prefetch else max(1, int(prefetch_depth or 1))
+        self._pipe = None
         self._primed = False
         self._announced = Announced()
         params =[p for p in model.parameters() if p.requires_grad]
@@ -139,12 +129,17 @@ class GraphedTrainStep:
             pc = self.static_batch["point_clouds"]
             b, n = pc.shape[0], pc.shape[1]
             levels = geometry_levels or model.encoder.LEVELS
-            self.plan_cur = GeometryPlan(b, n, levels, pc.device)
-            self.plan_next = GeometryPlan(b, n, levels, pc.device)
-            self.static_next_xyz = pc[..., :3].contiguous()
-            self.side = torch.cuda.Stream(pc.device)
-            self.plan_cur.copy_from(self.plan_next)      # builds the hand-over's copy table OUTSIDE any capture
-            self.plan_cur.compute(self.static_next_xyz)  # geometry of the example batch
+            if self._geo_inline:
+                self.plan_cur = GeometryPlan(b, n, levels, pc.device)
+                self.plan_next = GeometryPlan(b, n, levels, pc.device)
+                self.static_next_xyz = pc[..., :3].contiguous()
+                self.side = torch.cuda.Stream(pc.device)
+                self.plan_cur.copy_from(self.plan_next)      # builds the hand-over's copy table OUTSIDE any capture
+            else:
+                self._pipe = GeometryPipeline(b, n, levels, pc.device, stream, depth=self.prefetch_depth,
+                                              handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0")
+                self.plan_cur = self._pipe.plan_cur
+            self.plan_cur.compute(pc[..., :3].contiguous())  # geometry of the example batch
 
         def fwd_bwd():
             batch = dict(self.static_batch)
@@ -290,7 +285,7 @@ class GraphedTrainStep:
         with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
             # data parallel: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
             # encoder's backward / the exchange / the update -- it gets its own graph on the side stream (below)
-            if self.prefetch and reducer is None:
+            if self._geo_inline:
                 self.side.wait_stream(stream)                    # fork
                 with torch.cuda.stream(self.side):
                     self.plan_next.compute(self.static_next_xyz)
@@ -302,7 +297,7 @@ class GraphedTrainStep:
             if reducer is None:
                 update()
             timeline.mark("main:update done")
-            if self.prefetch and reducer is None:
+            if self._geo_inline:
                 stream.wait_stream(self.side)                    # join
                 self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
             timeline.mark("main:end")
@@ -313,19 +308,12 @@ class GraphedTrainStep:
                     bwd_lower()
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(), capture_error_mode=cap_mode):
                 bwd_encoder()
-        if self.prefetch and reducer is not None:
-            # The geometry of batch i+1 as a graph of its own, replayed on the side stream under ALL the graphs
-            # and collectives of step i.  A branch forked inside the first graph has to finish with that graph:
-            # +1.1 ms per step in the split form (the chain runs ~7 ms beside the main branch), and with RCCL's
-            # stream on a high-priority queue (ddp._pg_options) a graph with an internal fork replays
-            # pathologically slowly (26 ms per step measured with a process group of one).  The hand-over is an
-            # eager table copy after the last graph that reads plan_cur.
-            self.graph_geo = torch.cuda.CUDAGraph()
-            self.side.wait_stream(stream)
-            with torch.cuda.graph(self.graph_geo, stream=self.side, pool=self.graph.pool(),
-                                  capture_error_mode=cap_mode):
-                self.plan_next.compute(self.static_next_xyz)
-            stream.wait_stream(self.side)
+        if self._pipe is not None:
+            # The geometry chains as graphs of their own, replayed on their streams under ALL the graphs and
+            # collectives of a step.  (A branch forked inside the first graph has to finish with that graph:
+            # +1.1 ms per step in the split form, and with RCCL's stream on a high-priority queue (ddp._pg_options)
+            # a graph with an internal fork replays pathologically slowly: 26 ms per step with a group of one.)
+            self._pipe.capture(pool=self.graph.pool(), capture_error_mode=cap_mode)
         if reducer is not None:
             with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_opt, stream=stream,
                                                            pool=self.graph.pool(),
@@ -338,24 +326,23 @@ class GraphedTrainStep:
         # device scalar (optim.FlatAdamW.sync_lr) and follows a scheduler across replays.
         self._captured_bn_momenta = _bn_momenta(model)
 
-    def _hand_over(self):
-        """Data-parallel forms: join the geometry graph of batch i+1 and make its plan the current one (eager
-        table copy; the last graph that reads plan_cur has been enqueued)."""
-        if self.prefetch:
-            self.stream.wait_stream(self.side)
-            self.plan_cur.copy_from(self.plan_next)
+    def handshake_timed_out(self):
+        """True when a geometry chain ever gave up waiting for its ticket (geometry.GeometryPipeline.timed_out)."""
+        return self._pipe is not None and self._pipe.timed_out()
 
     def prime(self, batch):
-        """Prefetch mode: compute the geometry of the FIRST batch (pipeline prologue)."""
-        if self.prefetch:
+        """Inline-fork form: compute the geometry of the FIRST batch (pipeline prologue).  The pipeline form does
+        this by itself (an unannounced batch gets an inline chain)."""
+        if self._geo_inline:
             self.plan_cur.compute(batch["point_clouds"][..., :3].contiguous())
         self._primed = True
 
-    def __call__(self, batch, next_batch=None, token=None, next_token=None):
-        """`token` / `next_token` (optional): the caller's ids of `batch` / `next_batch` (step or sequence
-        numbers).  Without them the hand-over is keyed on tensor identity + version (see Announced); a caller
-        that refills ONE buffer in place must pass tokens to keep the prefetch, or pays an inline geometry
-        chain per step -- never a wrong plan."""
+    def __call__(self, batch, next_batch=None, token=None, next_token=None, upcoming=None, upcoming_tokens=None):
+        """`upcoming`: the batches of the next `prefetch_depth` calls, in order (the chain of upcoming[-1] starts
+        under this step; `next_batch` alone is accepted at depth 1).  `token` / `next_token` / `upcoming_tokens`
+        (optional): the caller's ids of those batches (step or sequence numbers).  Without them the hand-over is
+        keyed on tensor identity + version (geometry.Announced); a caller that refills ONE buffer in place must pass
+        tokens to keep the prefetch, or pays an inline geometry chain per step -- never a wrong plan."""
         if _bn_momenta(self.model) != self._captured_bn_momenta:
             raise RuntimeError("BatchNorm momentum changed since capture (BNMomentumScheduler): the captured "
                                "sig3d_bn_finalize launches hold the old value -- build a new GraphedTrainStep")
@@ -363,17 +350,23 @@ class GraphedTrainStep:
         if sync_lr is not None:
             sync_lr()   # a scheduler's new learning rate -> the device scalar the captured AdamW reads
         if self.prefetch:
-            if next_batch is None:
-                raise ValueError("prefetch_geometry=True needs the batch of the NEXT step")
+            if upcoming is None:
+                if next_batch is None:
+                    raise ValueError("prefetch_geometry=True needs the batch(es) of the NEXT step(s)")
+                upcoming, upcoming_tokens = [next_batch], [next_token]
+            if len(upcoming) != self.prefetch_depth:
+                raise ValueError("prefetch depth %d: pass upcoming=[the next %d batches]"
+                                 % (self.prefetch_depth, self.prefetch_depth))
+        if self._pipe is not None:
+            # hand over the plan of `batch`, start the chain of upcoming[-1] -- under everything below
+            self._pipe.advance(batch["point_clouds"], [u["point_clouds"] for u in upcoming], token, upcoming_tokens)
+        elif self.prefetch:
+            next_batch, next_token = upcoming[0], (upcoming_tokens[0] if upcoming_tokens else None)
             if not self._primed or not self._announced.matches(batch["point_clouds"], token):
                 self.prime(batch)  # pipeline prologue, or the caller broke the announced order
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
             self._announced.set(next_batch["point_clouds"], next_token)
         _copy_into(self.static_batch, batch)
-        if self.prefetch and self.reducer is not None:
-            self.side.wait_stream(self.stream)   # next coordinates staged; last step's hand-over done
-            with torch.cuda.stream(self.side):
-                self.graph_geo.replay()          # geometry of batch i+1 under everything below
         self.graph.replay()
         if self.reducer is not None:
             if self._split:
@@ -384,7 +377,6 @@ class GraphedTrainStep:
                 if self._emb_sink is not None:
                     self._emb_sink.launch()      # word-embedding rows (the embeddings' backward has just run)
                 self.graph_enc.replay()          # ... under the point encoder's backward
-                self._hand_over()
                 self._red_enc.launch_all()
                 self.optimizer.mark_gathered()
                 self.optimizer.begin_bucketed_step()
@@ -397,12 +389,10 @@ class GraphedTrainStep:
                 self.optimizer.update_buckets(self._red_enc)
                 self.optimizer.end_bucketed_step()
             elif self._bucketed_update:
-                self._hand_over()
                 # all-reduce per bucket, AdamW per bucket right behind it (eager launches, ~12 per step)
                 self.optimizer.mark_gathered()   # the replayed graph filled the flat gradient buffers
                 self.optimizer.step_after(self.reducer)
             else:
-                self._hand_over()
                 self.reducer.reduce_all()
                 self.graph_opt.replay()
         return self.static_loss

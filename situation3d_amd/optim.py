@@ -38,7 +38,7 @@ _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8")
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 clip_value=0.0, storage_order=None):
+                 clip_value=0.0, storage_order=None, max_workgroups=None):
         """storage_order: optional, one list per parameter group -- the SAME trainable parameters in the order
         they are to lie in the flat buffers (trainer.build_optimizer keeps operands the Q-Former stacks into one
         GEMM adjacent).  `param_groups[*]["params"]` -- the order state_dict() / load_state_dict() index by, like
@@ -46,6 +46,10 @@ class FlatAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.clip_value = float(clip_value)
+        # None: one workgroup per 64 Ki-element chunk.  k: at most k workgroups walk the chunk table
+        # (sig3d_adamw_table_bounded) -- for an update that shares the chip with another stream's kernels; 256 (one
+        # per CU) streams as fast as the full grid (tools/adamw_overlap.py: 0.91 vs 0.93 ms)
+        self.max_workgroups = None if max_workgroups is None else max(1, int(max_workgroups))
         self._groups = []
         dev = None
         recs, owners = [], []   # static part of the chunk table; owners[i] = index into self._params
@@ -360,9 +364,17 @@ class FlatAdamW(torch.optim.Optimizer):
         table, n = self._flat_table(ranges)
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
-        _lib.call("sig3d_adamw_table", n, _lib.ptr(table), _lib.ptr(self._step), ctypes.c_float(g0["lr"]),
-                  _lib.ptr(self._lr_dev), ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
-                  ctypes.c_float(self.clip_value), stream)
+        self._launch_table(n, table, stream)
+
+    def _launch_table(self, n, table, stream):
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        args = [n, _lib.ptr(table), _lib.ptr(self._step), ctypes.c_float(g0["lr"]), _lib.ptr(self._lr_dev),
+                ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]), ctypes.c_float(self.clip_value)]
+        if self.max_workgroups is None:
+            _lib.call("sig3d_adamw_table", *args, stream)
+        else:
+            _lib.call("sig3d_adamw_table_bounded", *args, self.max_workgroups, stream)
 
     @torch.no_grad()
     def update_buckets(self, reducer):
@@ -413,10 +425,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._gathered = False
             else:
                 self._upload()
-                _lib.call("sig3d_adamw_table", len(self._static), _lib.ptr(self._table),
-                          _lib.ptr(self._step), ctypes.c_float(g0["lr"]), _lib.ptr(self._lr_dev),
-                          ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]),
-                          ctypes.c_float(self.clip_value), stream)
+                self._launch_table(len(self._static), self._table, stream)
                 for p, _, _ in self._params:
                     p.grad = None
         return loss

@@ -250,3 +250,61 @@ def test_attention_fwd_key_splits_match_single_pass(b, h, nq, nk, splits):
         outs.append((out, lse))
     torch.testing.assert_close(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-5, atol=1e-5)
+
+
+def test_ticket_handshake_orders_two_streams():
+    """sig3d_ticket_signal / sig3d_ticket_wait (csrc/capi.hip): stream B's work starts after stream A's signal without
+    a barrier packet between them.  B copies a buffer A fills just before each signal; 40 rounds, enqueued B first."""
+    from situation3d_amd import _lib
+    dev = torch.device(DEV)
+    a_s, b_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    words = torch.zeros(4, dtype=torch.int32, device=dev)
+    src = torch.zeros(1 << 20, device=dev)
+    got = torch.zeros(40, device=dev)
+    torch.cuda.synchronize()
+    for k in range(40):
+        with torch.cuda.stream(b_s):                        # the waiter is enqueued FIRST: it must spin, not race
+            _lib.call("sig3d_ticket_wait", _lib.ptr(words[0:1]), _lib.ptr(words[1:2]), 5000000, _lib.ptr(words[2:3]),
+                      _lib.stream_ptr(dev))
+            got[k:k + 1].copy_(src[-1:])
+            done = torch.cuda.Event(); done.record(b_s)
+        with torch.cuda.stream(a_s):
+            src.fill_(float(k + 1))
+            _lib.call("sig3d_ticket_signal", _lib.ptr(words[0:1]), _lib.stream_ptr(dev))
+            # the NEXT fill must not overtake this round's copy: A waits for B's copy (an ordinary event)
+            a_s.wait_event(done)
+    torch.cuda.synchronize()
+    assert words[:3].tolist() == [40, 40, 0]
+    assert got.tolist() == [float(k + 1) for k in range(40)]
+
+
+def test_ticket_wait_times_out_instead_of_hanging():
+    from situation3d_amd import _lib
+    dev = torch.device(DEV)
+    words = torch.zeros(4, dtype=torch.int32, device=dev)
+    _lib.call("sig3d_ticket_wait", _lib.ptr(words[0:1]), _lib.ptr(words[1:2]), 2000, _lib.ptr(words[2:3]),
+              _lib.stream_ptr(dev))                        # nobody signals: gives up after 2 ms
+    torch.cuda.synchronize()
+    assert words[:3].tolist() == [0, 1, 1]
+
+
+def test_cu_masked_stream_confines_workgroups():
+    """sig3d_stream_create_with_cu_mask + sig3d_whereami: mask bit k = XCD k % 8, CU slot k / 8; two disjoint masks
+    run on disjoint CUs (situation3d_amd/streams.py)."""
+    from situation3d_amd import _lib, streams
+    dev = torch.device(DEV)
+
+    def where(stream, blocks=512):
+        slots = torch.zeros(2 * blocks, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(stream):
+            _lib.call("sig3d_whereami", _lib.ptr(slots), blocks, 256, 100, _lib.stream_ptr(dev))
+        torch.cuda.synchronize()
+        v = slots.cpu().view(blocks, 2)
+        return {(int(x) & 0xF, (int(h) >> 8) & 0xFF) for h, x in v.tolist()}
+
+    a = streams.MaskedStream(dev, streams.cu_mask(0, 2))
+    b = streams.MaskedStream(dev, streams.cu_mask(2, 32))
+    ca, cb = where(a.stream), where(b.stream)
+    assert len(ca) == 16 and {x for x, _ in ca} == set(range(8))
+    assert len(cb) == 240 and not (ca & cb)
+    a.close(); b.close()

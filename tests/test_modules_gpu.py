@@ -283,10 +283,20 @@ def test_geometry_plan_equals_inline_ops(hip_ext):
             cur = new
 
 
-@pytest.mark.parametrize("prefetch", [False, True])
-def test_graphed_step_matches_eager(prefetch):
-    """hipGraph replay (with and without the forked geometry-prefetch branch) reproduces the eager
-    training trajectory: same losses for the same batches."""
+@pytest.mark.parametrize("prefetch", [False, True, "depth2", "depth3", "depth2-streamwait", "inline-fork", "tokens",
+                                      "broken-order"])
+def test_graphed_step_matches_eager(prefetch, monkeypatch):
+    """hipGraph replay (without prefetch; with the geometry chains of the next 1 / 2 / 3 batches in flight as graphs of
+    their own -- geometry.GeometryPipeline, behind the device-side handshake or a stream wait; with rounds 1-2's
+    branch forked inside the step's graph) reproduces the eager training trajectory: same losses for the same
+    batches.  "tokens": the hand-over keyed on the caller's ids; "broken-order": a caller that announces one batch
+    and runs another pays inline chains and still gets the right plans."""
+    depth = {"depth2": 2, "depth3": 3, "depth2-streamwait": 2, "tokens": 2, "broken-order": 2}.get(prefetch, 1)
+    if prefetch == "depth2-streamwait":
+        monkeypatch.setenv("SIG3D_GEO_HANDSHAKE", "0")
+    if prefetch == "inline-fork":
+        monkeypatch.setenv("SIG3D_GEO_FORK", "inline")
+    mode, prefetch = prefetch, bool(prefetch)
     from situation3d_amd.graph_step import GraphedTrainStep
     from situation3d_amd.model import SIG3DQFormer
     from situation3d_amd.trainer import build_optimizer, train_step
@@ -321,11 +331,28 @@ def test_graphed_step_matches_eager(prefetch):
             train_step(m1, o1, dict(batches[0]))
         eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(5)]
         m2, o2 = make()
-        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=prefetch)
+        gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=prefetch, prefetch_depth=depth)
+        assert gs.prefetch_depth == depth
         graph = []
         for i in range(5):
-            loss = gs(batches[i % 3], batches[(i + 1) % 3])
+            up = [batches[(i + 1 + k) % 3] for k in range(depth)]
+            if mode == "broken-order":
+                up = [batches[(i + k) % 3] for k in range(depth)]          # announces the wrong batches
+            if mode == "tokens":
+                loss = gs(batches[i % 3], upcoming=up, token=i, upcoming_tokens=[i + 1 + k for k in range(depth)])
+            elif depth == 1:
+                loss = gs(batches[i % 3], up[0])
+            else:
+                loss = gs(batches[i % 3], upcoming=up)
             graph.append(float(loss.item()))
+        if prefetch and mode != "inline-fork":
+            assert not gs.handshake_timed_out()
+            # the prologue pays `depth` inline chains, an honest caller none after it
+            want = 5 if mode == "broken-order" else depth
+            assert gs._pipe.inline_chains == want, (gs._pipe.inline_chains, want)
+        if prefetch and depth == 2 and mode == "depth2":
+            with pytest.raises(ValueError):
+                gs(batches[0], batches[1])                                  # depth 2 needs two upcoming batches
     torch.cuda.synchronize()
     # float atomics in the scatter-add gradients make runs differ in the last bits only
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)

@@ -293,3 +293,24 @@ def test_flat_adamw_load_state_dict_rejects_a_differently_ordered_checkpoint():
     sd["state"][0], sd["state"][2] = sd["state"][2], sd["state"][0]     # (300, 37) <-> (300, 300) moments swapped
     with pytest.raises(ValueError, match="orders its parameters differently"):
         opt.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("gather", [False, True])
+def test_flat_adamw_with_a_bounded_grid_matches_the_full_grid(gather):
+    """sig3d_adamw_table_bounded: k workgroups walking the chunk table produce the same bits as one workgroup per
+    chunk (k = 1: a single workgroup does the whole model; k = 3: chunks interleave)."""
+    from situation3d_amd.optim import FlatAdamW
+    nets = [_net() for _ in range(3)]
+    opts = [FlatAdamW(_groups(m, 0.05), lr=1e-2, clip_value=0.05, max_workgroups=k) for m, k in zip(nets, (None, 1, 3))]
+    g = torch.Generator().manual_seed(5)
+    for step in range(6):
+        x = torch.randn(16, 37, generator=g).to(DEV)
+        y = torch.randn(16, 5, generator=g).to(DEV)
+        for m, o in zip(nets, opts):
+            (10 * (m(x) - y).pow(2).mean()).backward()
+            if gather:
+                o.gather_grads()
+            o.step()
+    for m in nets[1:]:
+        for p, q in zip(nets[0].parameters(), m.parameters()):
+            assert torch.equal(p, q)

@@ -52,7 +52,7 @@ def instrument(model):
         mod.register_forward_hook(hook)
 
 
-def run(prefetch, steps):
+def run(prefetch, steps, depth=1):
     dev = torch.device("cuda:0")
     torch.manual_seed(1234)
     model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS).to(dev).train()
@@ -62,13 +62,14 @@ def run(prefetch, steps):
     instrument(model)
     work = torch.cuda.Stream(dev)
     with torch.cuda.stream(work):
-        g = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=prefetch)
+        g = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=prefetch, prefetch_depth=depth)
+        up = lambda i: [batches[(i + 1 + k) % 4] for k in range(g.prefetch_depth)]
         for i in range(5):
-            g(batches[i % 4], batches[(i + 1) % 4])
+            g(batches[i % 4], upcoming=up(i))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            g(batches[i % 4], batches[(i + 1) % 4])
+            g(batches[i % 4], upcoming=up(i))
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
     marks = tl.read()
@@ -80,8 +81,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--depth", type=int, default=1, help="geometry chains in flight")
     a = ap.parse_args()
-    ms, marks = run(not a.no_prefetch, a.steps)
+    ms, marks = run(not a.no_prefetch, a.steps, a.depth)
     print("prefetch=%s  %.3f ms/step (marks included)" % (not a.no_prefetch, ms))
     base = dict(marks).get("main:start", 0.0)
     prev = {"main": base, "geo": base}
