@@ -163,9 +163,19 @@ class GeometryPipeline:
         self.slots = []
         self._words = torch.zeros(4 * self.depth, dtype=torch.int32, device=device)   # per slot: ticket, consumed, error
         example = torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device)
+        # HIP multiplexes streams onto 4 hardware queues per priority, and which queue a new stream gets is not under
+        # the caller's control (tools/probes/queue_map_probe.py: two fresh streams share one in ~1 of 4 cases).  A
+        # chain on the consumer's queue is simply served in order with it (step 8.1 -> 11.8 ms): every slot stream is
+        # checked to run concurrently with the consumer's stream and with the other slots' (streams.stream_beside).
+        from . import streams
+        beside = [stream]
+        self.shared_queues = 0      # slots that found no free hardware queue (depth > 3): they serialise with another
         for k in range(self.depth):
+            st, ok = streams.stream_beside(beside, device, priority=stream_priority)
+            beside.append(st)
+            self.shared_queues += 0 if ok else 1
             self.slots.append(dict(plan=GeometryPlan(batch, n_points, levels, device), xyz=example.clone(),
-                                   stream=torch.cuda.Stream(device, priority=stream_priority), graph=torch.cuda.CUDAGraph(),
+                                   stream=st, graph=torch.cuda.CUDAGraph(),
                                    announced=Announced(), words=self._words[4 * k:4 * k + 4]))
         for slot in self.slots:                       # scratch allocations and copy tables, outside any capture
             slot["plan"].compute(slot["xyz"])

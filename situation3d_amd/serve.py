@@ -30,11 +30,11 @@ class PipelinedForward:
       3. replays the forward graph of batch i.
     Outputs are those of the inline forward, bit for bit; a caller that breaks the announced order pays one inline
     chain for that batch (geometry.Announced: tokens, or tensor object + version).
-    Measured (tools/infer_bench.py, 40 000 points, round 2, chains behind stream waits): B = 4: 5.2 ms per batch one
-    chain ahead -> 2.97 ms with two chains in flight (1345 samples/s); B = 8: 5.9 -> 4.0 ms with three
-    (2000 samples/s).  The best depth depends on how HIP maps the streams onto its four hardware queues per priority
-    (B = 4 / three chains: 4.5 ms; B = 8 / two: 5.65 ms), and high-priority geometry streams are pathological with two
-    chains (13 ms) -- measure before changing `depth` / `high_priority`."""
+    Measured (tools/infer_bench.py, 40 000 points): B = 4: 5.1 ms per batch one chain ahead -> 2.92 ms with two chains in
+    flight (1369 samples/s), 2.88 with three; B = 8: 5.8 -> 3.75 ms with two or three (2135 samples/s).  (Round 2,
+    with streams as HIP handed them out and chains behind stream waits, was erratic in the depth -- B = 8 / two chains
+    5.65 ms, B = 4 / three 4.5 ms: chains that shared a hardware queue; GeometryPipeline now picks streams that do not.)
+    High-priority geometry streams stay pathological (12-13 ms per batch with two chains): leave `high_priority` off."""
 
     def __init__(self, model, example_batch, depth=2, warmup=2, geometry_levels=None, high_priority=False):
         stream = torch.cuda.current_stream()

@@ -3,6 +3,7 @@
 Mask bit k addresses XCD k % 8, CU slot k / 8 of that XCD (MI355X: 8 XCDs x 32 CUs; tools/probes/cu_mask_probe.py
 prints the map measured on the box).  `cu_mask(per_xcd_lo, per_xcd_hi)` selects CU slots [lo, hi) of EVERY XCD."""
 import ctypes
+import time
 
 import torch
 
@@ -39,3 +40,33 @@ class MaskedStream:
             with torch.cuda.device(self.device):
                 _lib.call("sig3d_stream_destroy", ctypes.c_void_p(self.handle))
             self.handle = None
+
+
+def run_concurrently(a, b, device, hold_us=1000):
+    """Do kernels on streams `a` and `b` overlap in time?  HIP multiplexes its streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 per priority): two streams that landed on the SAME queue are served in order, however
+    independent their work is.  Measured: a one-workgroup kernel that holds its CU for `hold_us` on each stream;
+    ~hold_us in total = concurrent, ~2 x hold_us = one queue.  Synchronises the device (construction-time check)."""
+    dev = torch.device(device)
+    slots = torch.zeros(8, dtype=torch.int32, device=dev)
+    best = None
+    for _ in range(2):                      # first pass warms the kernel and the queues up
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k, st in enumerate((a, b)):
+            with torch.cuda.stream(st):
+                _lib.call("sig3d_whereami", _lib.ptr(slots[4 * k:]), 1, 64, int(hold_us), _lib.stream_ptr(dev))
+        torch.cuda.synchronize(dev)
+        best = time.perf_counter() - t0
+    return best < 1.6e-6 * hold_us
+
+
+def stream_beside(others, device, priority=0, tries=12):
+    """A new torch stream that runs concurrently with every stream in `others` (see run_concurrently); falls back
+    to the last candidate when none of `tries` does (the chains then serialise: slower, never wrong)."""
+    cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device, priority=priority)
+        if all(run_concurrently(o, cand, device) for o in others):
+            return cand, True
+    return cand, False

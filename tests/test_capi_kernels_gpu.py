@@ -308,3 +308,19 @@ def test_cu_masked_stream_confines_workgroups():
     assert len(ca) == 16 and {x for x, _ in ca} == set(range(8))
     assert len(cb) == 240 and not (ca & cb)
     a.close(); b.close()
+
+
+def test_stream_beside_finds_a_free_hardware_queue():
+    """streams.run_concurrently / stream_beside: of a dozen fresh streams some pairs share a hardware queue (served in
+    order); stream_beside returns one that overlaps with every stream it is given."""
+    from situation3d_amd import streams
+    dev = torch.device(DEV)
+    main = torch.cuda.Stream(dev)
+    assert not streams.run_concurrently(main, main, dev)          # one stream: in order by definition
+    picked = [main]
+    for _ in range(3):                                            # 1 + 3 streams: the four queues of one priority
+        st, ok = streams.stream_beside(picked, dev)
+        assert ok
+        for o in picked:
+            assert streams.run_concurrently(o, st, dev)
+        picked.append(st)
