@@ -22,14 +22,20 @@ RESULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "ge
 _state = {"enabled": False}
 
 
-def enable(tune_missing=True, results=RESULTS):
-    """Turn TunableOp on for this process.  Call before the first GEMM, after the device is set."""
+def enable(tune_missing=True, results=RESULTS, rotating_buffer_mb=None):
+    """Turn TunableOp on for this process.  Call before the first GEMM, after the device is set.
+    `rotating_buffer_mb`: candidates are timed on operands rotated through this much memory (cold caches, like the
+    weights of a step that streams 700 MB of them); None keeps TunableOp's default (one L2's worth)."""
+    if results == RESULTS and os.environ.get("SIG3D_GEMM_TABLE"):
+        results = os.environ["SIG3D_GEMM_TABLE"]
     if not torch.cuda.is_available():
         raise RuntimeError("GEMM tuning needs the GPU (there is no CPU path)")
     import torch.cuda.tunable as tunable
     tunable.enable(True)
     tunable.set_max_tuning_duration(30)     # ms per candidate
     tunable.set_max_tuning_iterations(20)
+    if rotating_buffer_mb is not None:
+        tunable.set_rotating_buffer_size(int(rotating_buffer_mb))
     # TunableOp streams what it tunes to its file: point that at scratch, read the committed winners
     scratch = os.path.join(tempfile.gettempdir(), "sig3d_tunableop_%d.csv" % os.getpid())
     tunable.set_filename(scratch, insert_device_ordinal=False)

@@ -166,3 +166,12 @@ with torch.cuda.stream(main):
     print("  ... and joined with a stream wait at the end                  %.3f ms" % timed(handshake_join))
     torch.cuda.synchronize()
     print("handshake words (ticket, consumed, error):", words[:3].tolist())
+    # the same blocked barrier on a HIGH-priority stream (RCCL's stream in the data-parallel step: ddp._pg_options)
+    side_hi = torch.cuda.Stream(dev, priority=-1)
+    def fill_forkonly_hi():
+        side_hi.wait_stream(main)
+        with torch.cuda.stream(side_hi):
+            scratch.fill_(1.0)
+        g.replay()
+    print("fill on a HIGH-priority side stream, fork wait only             %.3f ms" % timed(fill_forkonly_hi))
+    print("graph alone again                                               %.3f ms" % timed(g.replay))

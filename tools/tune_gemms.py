@@ -17,7 +17,11 @@ from situation3d_amd.trainer import build_optimizer, train_step  # noqa: E402
 out = sys.argv[1] if len(sys.argv) > 1 else gemm_tuning.RESULTS
 device = torch.device("cuda", 0)
 torch.cuda.set_device(device)
-gemm_tuning.enable(tune_missing=True, results=None)   # tune from scratch
+# SIG3D_TUNE_ROTATE_MB: time the candidates on operands rotated through that much memory (cold caches)
+rot = os.environ.get("SIG3D_TUNE_ROTATE_MB")
+gemm_tuning.enable(tune_missing=True, results=None, rotating_buffer_mb=int(rot) if rot else None)   # tune from scratch
+import torch.cuda.tunable as _t  # noqa: E402
+print("rotating buffer: %s MB" % _t.get_rotating_buffer_size())
 torch.manual_seed(1234)
 with torch.cuda.stream(torch.cuda.Stream(device)):
     model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS).to(device).train()
