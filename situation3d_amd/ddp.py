@@ -33,6 +33,24 @@ def _single_rank_rehearsal():
     return bool(os.environ.get("SIG3D_SINGLE_RANK_PG")) and dist.is_initialized()
 
 
+def _own_stream_collectives():
+    return os.environ.get("SIG3D_DDP_COMM") == "own"
+
+
+_OWN = {}           # device -> {comm stream, handshake words} of the own-stream collectives
+_OWN_BESIDE = []    # streams the communication stream must not share a hardware queue with (geometry chains)
+
+
+class _EventHandle:
+    """wait(): the current stream waits for an event (the join of an own-stream collective)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 # SIG3D_BUCKET_MB: size of one all-reduce (default 64 MiB)
 BUCKET_BYTES = int(os.environ.get("SIG3D_BUCKET_MB", "64")) << 20
 
@@ -164,10 +182,41 @@ class GradBucketReducer:
 
     def launch_all(self):
         """Launch every bucket's all-reduce asynchronously (no join): pair with wait(bucket)."""
+        if _own_stream_collectives() and (self.world > 1 or _single_rank_rehearsal()) and self.buckets[0]["flat"].is_cuda:
+            return self._launch_all_on_own_stream()
         for b in self.buckets:
             b["launched"] = False
             b["handle"] = None
             self._launch(b)
+
+    def _launch_all_on_own_stream(self):
+        """SIG3D_DDP_COMM=own: the collectives as SYNCHRONOUS ops issued under a communication stream of this
+        process's own, which starts behind a device-side ticket handshake (sig3d_ticket_signal on the compute stream,
+        sig3d_ticket_wait on the communication stream) instead of an event wait: a blocked barrier packet on the
+        communication queue taxes every kernel the compute stream dispatches meanwhile, and
+        the host enqueues these waits a whole graph ahead.  Joined per bucket by wait()."""
+        from . import _lib, streams
+        main = torch.cuda.current_stream()
+        dev = self.buckets[0]["flat"].device
+        st = _OWN.get(dev)
+        if st is None:
+            comm, _ = streams.stream_beside([main] + list(_OWN_BESIDE), dev)
+            st = _OWN[dev] = dict(comm=comm, words=torch.zeros(4, dtype=torch.int32, device=dev))
+        comm, w = st["comm"], st["words"]
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_ticket_signal", _lib.ptr(w[0:1]), main.cuda_stream)
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        with torch.cuda.stream(comm):
+            _lib.call("sig3d_ticket_wait", _lib.ptr(w[0:1]), _lib.ptr(w[1:2]), 30 * 1000 * 1000, _lib.ptr(w[2:3]),
+                      comm.cuda_stream)
+            for b in self.buckets:
+                b["launched"] = True
+                dist.all_reduce(b["flat"], op=op, group=self.group, async_op=False)
+                ev = b.get("done")
+                if ev is None:
+                    ev = b["done"] = torch.cuda.Event()
+                ev.record(comm)
+                b["handle"] = _EventHandle(ev)
 
     def wait(self, b):
         """Make the current stream wait for ONE bucket's collective (and apply the mean for backends

@@ -139,6 +139,9 @@ class GraphedTrainStep:
                 self._pipe = GeometryPipeline(b, n, levels, pc.device, stream, depth=self.prefetch_depth,
                                               handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0")
                 self.plan_cur = self._pipe.plan_cur
+                if reducer is not None:
+                    from . import ddp
+                    ddp._OWN_BESIDE.extend(sl["stream"] for sl in self._pipe.slots)   # own-stream collectives: other queues
             self.plan_cur.compute(pc[..., :3].contiguous())  # geometry of the example batch
 
         def fwd_bwd():
