@@ -370,6 +370,33 @@ int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, int live_
                                     const unsigned short *mask, float *dx, float *dres, float *dparams,
                                     float *workspace, void *stream);
 
+/* BertEmbeddings.forward (Qformer.py:70-98) as one row kernel each way (csrc/qformer_embed.hip):
+ *   x = cat(query_embeds, word[ids] + pos[pos_off + t]) ; out = dropout(LayerNorm(x) * gamma + beta)
+ * b scenes, q query tokens, t text tokens, cols <= 1024.  query (.., q, cols) with batch stride query_bstride
+ * ELEMENTS (0: one (q, cols) block shared by the batch, i.e. query_tokens.expand(b, -1, -1)); ids (b, t) int64
+ * (clamped into the table); word (vocab, cols); pos (pos_rows, cols).
+ * seg_rows == 0: out rows in (b, q + t) order.  seg_rows = P > 0: the two-segment row layout, 2P rows
+ * [b*q query rows, zero padding | b*t text rows, zero padding].  out / v are (rows, cols), mean / rstd (rows),
+ * mask (rows*64 uint16, p_drop > 0) as in sig3d_dropout_add_ln_fwd; dropout bits from (*rng_counter, call_id,
+ * element index).
+ * Backward: dy (rows, cols) -> dquery ((q, cols) summed over the batch when query_shared, else (b, q, cols)),
+ * dpos (pos_rows, cols: every row written), the word rows either ADDED to dword (vocab, cols; zeroed by the caller;
+ * float atomics; row pad_id gets nothing, like nn.Embedding(padding_idx)) or, rows_out != NULL, stored as (b*t, cols)
+ * rows in (b, t) order for a row exchange; dgamma_dbeta (2*cols); workspace (q + t) * 2 * cols floats. */
+int sig3d_qformer_embed_fwd(int b, int q, int t, int cols, int seg_rows, const float *query, long query_bstride,
+                            const long long *ids, const float *word, int vocab, const float *pos, int pos_rows,
+                            int pos_off, const float *gamma, const float *beta, float eps, float p_drop,
+                            unsigned call_id, const unsigned *rng_counter, float *out, float *v, float *mean,
+                            float *rstd, unsigned short *mask, void *stream);
+int sig3d_qformer_embed_bwd(int b, int q, int t, int cols, int seg_rows, int query_shared, const long long *ids,
+                            int vocab, int pos_rows, int pos_off, int pad_id, const float *dy, const float *v,
+                            const float *mean, const float *rstd, const float *gamma, const unsigned short *mask,
+                            float p_drop, float *dquery, float *dpos, float *dword, float *rows_out,
+                            float *dgamma_dbeta, float *workspace, void *stream);
+/* out[i] = (1 - mask[i]) * -10000 (Qformer.py:729-731, invert_attention_mask) for a 0/1 mask of
+ * kind 0: f32, 1: i64, 2: i32, 3: u8 / bool. */
+int sig3d_additive_mask(long n, const void *mask, int kind, float *out, void *stream);
+
 /* *counter += 1 (uint32) on the stream: the per-forward seed of the dropout hash. */
 int sig3d_counter_increment(unsigned *counter, void *stream);
 

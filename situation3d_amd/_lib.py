@@ -85,6 +85,11 @@ SIGNATURES = {
     "sig3d_stream_create_with_cu_mask": [_I, _P, _P],
     "sig3d_stream_destroy": [_P],
     "sig3d_whereami": [_P, _I, _I, _I, _P],
+    "sig3d_qformer_embed_fwd": [_I, _I, _I, _I, _I, _P, ctypes.c_long, _P, _P, _I, _P, _I, _I, _P, _P, _F, _F,
+                                ctypes.c_uint, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_qformer_embed_bwd": [_I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
+                                _P, _P, _P],
+    "sig3d_additive_mask": [ctypes.c_long, _P, _I, _P, _P],
     "sig3d_ticket_signal": [_P, _P],
     "sig3d_ticket_wait": [_P, _P, ctypes.c_longlong, _P, _P],
     "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],

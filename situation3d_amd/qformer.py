@@ -960,6 +960,77 @@ def _key_mask(mask, batch, nk):
     return mask.expand(batch, nk).to(torch.float32)
 
 
+FUSED_EMBED = os.environ.get("SIG3D_FUSED_EMBED", "1") != "0"   # 0: BertEmbeddings / masks through torch ops
+
+
+class _EmbeddingsFn(torch.autograd.Function):
+    """dropout(LayerNorm(cat(query_embeds, word[ids] + pos[off + t]))) as ONE launch each way
+    (sig3d_qformer_embed_fwd / _bwd, csrc/qformer_embed.hip) instead of ~22 + 13 torch launches.
+    `query`: the (1, Q, C) block the batch shares (shared=True: query_tokens itself, its gradient comes back summed
+    over the batch) or a contiguous (B, Q, C) tensor.  seg_rows > 0: output in the two-segment row layout (2P, C).
+    sink: ddp.SparseRowExchange -- the word rows' gradients go there as rows, the table gets no dense gradient."""
+
+    @staticmethod
+    def forward(ctx, query, shared, b, ids, word, pos, pos_off, gamma, beta, eps, p_drop, call_id, seg_rows, pad_id,
+                sink):
+        dev = word.device
+        q, cols = query.shape[-2], query.shape[-1]
+        t = ids.shape[1]
+        rows = 2 * seg_rows if seg_rows else b * (q + t)
+        ids = ids.contiguous()
+        out = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+        v = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
+        mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
+        if sink is not None:
+            sink.ids.copy_(ids.reshape(-1))
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_qformer_embed_fwd", b, q, t, cols, seg_rows, _lib.ptr(query), 0 if shared else q * cols,
+                      _lib.ptr(ids), _lib.ptr(word), word.shape[0], _lib.ptr(pos), pos.shape[0], pos_off,
+                      _lib.ptr(gamma), _lib.ptr(beta), ctypes.c_float(eps), ctypes.c_float(p_drop),
+                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(out), _lib.ptr(v),
+                      _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(mask), _lib.stream_ptr(dev))
+        ctx.save_for_backward(ids, v, stats, gamma, mask)
+        ctx.cfg = (b, q, t, cols, seg_rows, bool(shared), word.shape, pos.shape[0], pos_off, p_drop, pad_id, sink,
+                   tuple(query.shape))
+        return out if seg_rows else out.view(b, q + t, cols)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, v, stats, gamma, mask = ctx.saved_tensors
+        b, q, t, cols, seg_rows, shared, wshape, pos_rows, pos_off, p_drop, pad_id, sink, qshape = ctx.cfg
+        dev = v.device
+        dy = dy.contiguous()
+        dquery = torch.empty(qshape, dtype=torch.float32, device=dev)
+        dpos = torch.empty((pos_rows, cols), dtype=torch.float32, device=dev)
+        dparams = torch.empty((2, cols), dtype=torch.float32, device=dev)
+        work = torch.empty((q + t, 2 * cols), dtype=torch.float32, device=dev)
+        dword = rows_out = None
+        if sink is not None:
+            rows_out = sink.rows
+        else:
+            dword = torch.zeros(wshape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.call("sig3d_qformer_embed_bwd", b, q, t, cols, seg_rows, int(shared), _lib.ptr(ids), wshape[0],
+                      pos_rows, pos_off, -1 if pad_id is None else int(pad_id), _lib.ptr(dy), _lib.ptr(v),
+                      _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma), _lib.ptr(mask), ctypes.c_float(p_drop),
+                      _lib.ptr(dquery), _lib.ptr(dpos), _lib.ptr(dword), _lib.ptr(rows_out), _lib.ptr(dparams),
+                      _lib.ptr(work), _lib.stream_ptr(dev))
+        return (dquery, None, None, None, dword, dpos, None, dparams[0], dparams[1], None, None, None, None, None,
+                None)
+
+
+def _shared_query_block(query_embeds):
+    """query_tokens.expand(B, -1, -1) -> the (1, Q, C) block itself (its gradient is then summed over the batch
+    inside the embedding kernel); anything else -> None."""
+    base = query_embeds._base if query_embeds._is_view() else None
+    if (base is not None and query_embeds.dim() == 3 and query_embeds.stride(0) == 0 and base.dim() == 3
+            and base.shape[0] == 1 and base.shape[1:] == query_embeds.shape[1:] and base.is_contiguous()
+            and base.data_ptr() == query_embeds.data_ptr() and query_embeds.stride()[1:] == base.stride()[1:]):
+        return base
+    return None
+
+
 class BertEmbeddings(nn.Module):
     """Qformer.py:51-98"""
 
@@ -978,9 +1049,28 @@ class BertEmbeddings(nn.Module):
     def forward(self, input_ids=None, position_ids=None, query_embeds=None,
                 past_key_values_length=0, segmented=0):
         seq_length = input_ids.size()[1] if input_ids is not None else 0
-        if position_ids is None:
-            position_ids = self.position_ids[
-                :, past_key_values_length: seq_length + past_key_values_length].clone()
+        if position_ids is None:   # a view; the torch path below indexes with it (the reference clones, :80-83)
+            position_ids = self.position_ids[:, past_key_values_length: seq_length + past_key_values_length]
+        if (FUSED_EMBED and input_ids is not None and query_embeds is not None and query_embeds.is_cuda
+                and query_embeds.dtype == torch.float32 and self.position_embedding_type == "absolute"
+                and input_ids.dim() == 2 and input_ids.shape[1] > 0 and input_ids.dtype == torch.int64
+                and query_embeds.shape[-1] <= 1024
+                and past_key_values_length + seq_length <= self.position_embeddings.weight.shape[0]
+                and position_ids.shape[1] == seq_length
+                and position_ids.data_ptr() == self.position_ids.data_ptr() + 8 * past_key_values_length):
+            sink = getattr(self, "row_grad_sink", None) if torch.is_grad_enabled() else None
+            if sink is not None and sink.ids.numel() != input_ids.numel():
+                raise RuntimeError("word-embedding row exchange was set up for %d token positions per step, "
+                                   "this batch has %d" % (sink.ids.numel(), input_ids.numel()))
+            if not hasattr(self, "_call_id"):
+                self._call_id = next(_call_ids)
+            block = _shared_query_block(query_embeds)
+            query = block if block is not None else query_embeds.contiguous()
+            return _EmbeddingsFn.apply(
+                query, block is not None, query_embeds.shape[0], input_ids, self.word_embeddings.weight,
+                self.position_embeddings.weight, int(past_key_values_length), self.LayerNorm.weight,
+                self.LayerNorm.bias, float(self.LayerNorm.eps), self.dropout.p if self.training else 0.0,
+                self._call_id, int(segmented), self.word_embeddings.padding_idx, sink)
         if input_ids is not None:
             sink = getattr(self, "row_grad_sink", None)
             if sink is not None and torch.is_grad_enabled():
@@ -1414,6 +1504,14 @@ class BertModel(nn.Module):
     @staticmethod
     def _additive(mask_2d, dtype):
         """(1 - mask) * -10000 on a (B,N) 0/1 mask (Qformer.py:729-731, invert_attention_mask)."""
+        kind = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}.get(mask_2d.dtype)
+        if (FUSED_EMBED and mask_2d.is_cuda and dtype == torch.float32 and kind is not None
+                and mask_2d.is_contiguous() and not mask_2d.requires_grad):
+            out = torch.empty(mask_2d.shape, dtype=torch.float32, device=mask_2d.device)
+            with torch.cuda.device(mask_2d.device):     # one launch instead of three
+                _lib.call("sig3d_additive_mask", mask_2d.numel(), _lib.ptr(mask_2d), kind, _lib.ptr(out),
+                          _lib.stream_ptr(mask_2d.device))
+            return out
         return (1.0 - mask_2d.to(dtype)) * -10000.0
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None,
@@ -1451,7 +1549,9 @@ class BertModel(nn.Module):
             raise NotImplementedError("only (B, N) padding masks are on the hot path")
         extended_attention_mask = self._additive(attention_mask, embedding_output.dtype)
         encoder_extended_attention_mask = None
-        if encoder_hidden_states is not None:
+        if encoder_hidden_states is not None and not (encoder_attention_mask is None and segments is not None):
+            # (no encoder mask on the hot path: the reference builds ones -> an additive mask of zeros, :843-850;
+            # the attention kernels take "no mask" instead -- x + 0.0 == x)
             if encoder_attention_mask is None:
                 encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2], device=device)
             encoder_extended_attention_mask = self._additive(encoder_attention_mask,

@@ -50,8 +50,14 @@ def test_default_line_carries_the_contract():
     assert out["rccl_ranks"] == 1 and out["dist_backend"] is None
 
 
-def test_data_parallel_path_over_real_rccl_group_of_one():
-    out = _run(["--force-reducer", "--no-variants"], {"SIG3D_SINGLE_RANK_PG": "1", "MASTER_PORT": "29533"})
+@pytest.mark.parametrize("comm", ["pg", "own"])
+def test_data_parallel_path_over_real_rccl_group_of_one(comm):
+    """comm = "own": the buckets' all-reduces as synchronous ops on the process's own communication stream behind the
+    ticket handshake (SIG3D_DDP_COMM=own, ddp.GradBucketReducer._launch_all_on_own_stream)."""
+    env = {"SIG3D_SINGLE_RANK_PG": "1", "MASTER_PORT": "29533" if comm == "pg" else "29535"}
+    if comm == "own":
+        env["SIG3D_DDP_COMM"] = "own"
+    out = _run(["--force-reducer", "--no-variants"], env)
     assert out["value"] > 0 and out["n_gpus"] == 1
     ref = _run(["--no-variants"], {})
     # same seeds, same batches, mean over one rank == identity: the loss after 6 steps must agree

@@ -698,3 +698,100 @@ def test_tensor_hook_on_a_parameter_switches_deferred_weight_gradients_off():
     out.query_hidden_state.sum().backward()
     assert len(seen) == 1 and seen[0] > 0
     handle.remove()
+
+
+@pytest.mark.parametrize("segmented", [False, True])
+@pytest.mark.parametrize("shared", [False, True])
+def test_fused_bert_embeddings_match_the_torch_spelling(segmented, shared, monkeypatch):
+    """sig3d_qformer_embed_fwd / _bwd (one launch each way) against BertEmbeddings spelled with torch ops
+    (Qformer.py:70-98): output, and the gradients of the query block (per scene, or summed over the batch when the
+    batch shares query_tokens.expand), both tables (padding row: none) and the LayerNorm -- plain and two-segment
+    row layouts; and the additive masks."""
+    from situation3d_amd import qformer
+    from situation3d_amd.qformer import BertEmbeddings, QFormerConfig
+    torch.manual_seed(11)
+    cfg = QFormerConfig(vocab_size=300, hidden_size=192, num_hidden_layers=1, num_attention_heads=2,
+                        intermediate_size=256, max_position_embeddings=40, encoder_width=96,
+                        cross_attention_freq=2, query_length=6, hidden_dropout_prob=0.0)
+    emb = BertEmbeddings(cfg).to(DEV).train()
+    with torch.no_grad():
+        emb.LayerNorm.weight.uniform_(0.5, 1.5)
+        emb.LayerNorm.bias.uniform_(-0.5, 0.5)
+    b, q, t = 3, 6, 9
+    ids = torch.randint(0, 300, (b, t), device=DEV)
+    ids[0, :3] = 0                                   # padding id: no gradient for that row
+    ids[1, 4] = ids[2, 5]                            # a duplicate: gradients add up
+    seg = 32 if segmented else 0
+    base = (torch.randn(1 if shared else b, q, 192, generator=torch.Generator().manual_seed(2)) * 0.3).to(DEV)
+    rows = (lambda o: torch.cat([o[:b * q], o[seg:seg + b * t]])) if segmented else (lambda o: o.reshape(-1, 192))
+    G = torch.randn(b * (q + t), 192, device=DEV)
+    res = []
+    for fused in (False, True):
+        monkeypatch.setattr(qformer, "FUSED_EMBED", fused)
+        emb.zero_grad(set_to_none=True)
+        leaf = base.clone().requires_grad_(True)
+        out = emb(input_ids=ids, query_embeds=leaf.expand(b, -1, -1) if shared else leaf, segmented=seg)
+        live = rows(out)
+        if segmented and not fused:                  # torch path: plain rows in [q rows | t rows] order already
+            pass
+        (live * (G if segmented else G.view(b, q + t, 192).reshape(-1, 192))).sum().backward()
+        res.append((live.detach(), leaf.grad, {n: p.grad for n, p in emb.named_parameters()}))
+    (o0, q0, g0), (o1, q1, g1) = res
+    torch.testing.assert_close(o1, o0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(q1, q0, rtol=1e-4, atol=1e-5)
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=1e-4, atol=2e-5, msg=lambda m: n + ": " + m)
+    assert g1["word_embeddings.weight"][0].abs().max() == 0
+    # additive masks of every dtype a caller passes
+    from situation3d_amd.qformer import BertModel
+    m = (torch.rand(4, 17, device=DEV) > 0.3)
+    for mm in (m, m.to(torch.int64), m.to(torch.int32), m.to(torch.uint8), m.to(torch.float32)):
+        monkeypatch.setattr(qformer, "FUSED_EMBED", True)
+        got = BertModel._additive(mm, torch.float32)
+        assert torch.equal(got, (1.0 - m.to(torch.float32)) * -10000.0)
+
+
+def test_fused_bert_embeddings_dropout_and_row_sink():
+    """Training-mode dropout of the fused embeddings: keep rate, 1/(1-p) scaling, zero gradient where dropped; and the
+    data-parallel row sink: the word rows' gradients arrive as (B*T, C) rows in (b, t) order, pad-id rows zero, the
+    table itself gets no dense gradient."""
+    from situation3d_amd.ddp import SparseRowExchange
+    from situation3d_amd.qformer import BertEmbeddings, QFormerConfig, advance_dropout_seed
+    torch.manual_seed(12)
+    cfg = QFormerConfig(vocab_size=100, hidden_size=768, num_hidden_layers=1, num_attention_heads=12,
+                        intermediate_size=256, max_position_embeddings=64, encoder_width=96,
+                        cross_attention_freq=2, query_length=32, hidden_dropout_prob=0.25)
+    emb = BertEmbeddings(cfg).to(DEV).train()
+    b, q, t = 8, 32, 20
+    ids = torch.randint(0, 100, (b, t), device=DEV)
+    query = torch.randn(1, q, 768, device=DEV, requires_grad=True)
+    advance_dropout_seed(torch.device(DEV))
+    out = emb(input_ids=ids, query_embeds=query.expand(b, -1, -1))
+    emb.eval()
+    ref = emb(input_ids=ids, query_embeds=query.expand(b, -1, -1)).detach()
+    emb.train()
+    kept = out != 0
+    assert abs(kept.float().mean().item() - 0.75) < 0.01
+    torch.testing.assert_close(out[kept], (ref / 0.75)[kept], rtol=1e-5, atol=1e-6)
+    advance_dropout_seed(torch.device(DEV))
+    out2 = emb(input_ids=ids, query_embeds=query.expand(b, -1, -1))
+    assert ((out2 != 0) != kept).float().mean().item() > 0.2          # a fresh mask per forward pass
+    # row sink
+    sink = SparseRowExchange(b * t, 768, torch.device(DEV), padding_idx=0)
+    emb.row_grad_sink = sink
+    emb.zero_grad(set_to_none=True)
+    out3 = emb(input_ids=ids, query_embeds=query.expand(b, -1, -1))
+    out3.square().sum().backward()
+    assert emb.word_embeddings.weight.grad is None
+    assert torch.equal(sink.ids, ids.reshape(-1))
+    rows = sink.rows.clone()
+    assert rows[ids.reshape(-1) == 0].abs().max() == 0
+    del emb.row_grad_sink
+    emb.zero_grad(set_to_none=True)
+    # same dropout mask (same counter, same call id): the dense gradient must be the scatter of those rows
+    out4 = emb(input_ids=ids, query_embeds=query.expand(b, -1, -1))
+    assert torch.equal(out4, out3)
+    out4.square().sum().backward()
+    dense = torch.zeros_like(emb.word_embeddings.weight).index_add_(0, ids.reshape(-1), rows)
+    torch.testing.assert_close(emb.word_embeddings.weight.grad, dense, rtol=1e-5, atol=1e-5)
