@@ -18,4 +18,4 @@ for (name, grid), a in sorted(acc.items()):
     n = max(a["n"], 1)
     gui, busy = a.get("GRBM_GUI_ACTIVE", 0.0) / n, a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n
     frac = busy / (gui / 8.0 * 1024.0) if gui else 0.0
-    print("| `%s` | %s | %d | %.4g | %.4g | %.1f %% |" % (name, grid, n, gui, busy, 100.0 * frac))
+    print("| `%s` | %s | %d | %.4g | %.4g | %.1f %% |" % (name[:72], grid, n, gui, busy, 100.0 * frac))
