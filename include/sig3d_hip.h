@@ -44,6 +44,9 @@ int sig3d_timestamp_rate(int device, long long *hz);
 int sig3d_stream_create_with_cu_mask(int words, const unsigned int *mask, void **stream);
 int sig3d_stream_destroy(void *stream);
 int sig3d_whereami(unsigned int *slots, int blocks, int threads, int hold_us, void *stream);
+/* Diagnostic: blocks x threads workgroups that keep ~vgprs (0 / 100 / 220) registers per lane and lds_bytes of LDS
+ * while they sleep for hold_us: the cost of a resident footprint to another stream's kernels. */
+int sig3d_hold(float *sink, int blocks, int threads, int hold_us, int vgprs, int lds_bytes, void *stream);
 int sig3d_ticket_signal(unsigned int *ticket, void *stream);
 int sig3d_ticket_wait(const unsigned int *ticket, unsigned int *consumed, long long timeout_us, int *error,
                       void *stream);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sig3d_qformer_embed_bwd": [_I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                 _P, _P, _P],
     "sig3d_additive_mask": [ctypes.c_long, _P, _I, _P, _P],
+    "sig3d_hold": [_P, _I, _I, _I, _I, _I, _P],
     "sig3d_ticket_signal": [_P, _P],
     "sig3d_ticket_wait": [_P, _P, ctypes.c_longlong, _P, _P],
     "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],

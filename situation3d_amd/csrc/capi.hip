@@ -140,3 +140,43 @@ extern "C" int sig3d_whereami(unsigned int *slots, int blocks, int threads, int 
   SIG3D_LAUNCH_CHECK("whereami_kernel");
   return 0;
 }
+
+// Diagnostic: `blocks` x `threads` workgroups that hold NV live VGPRs per lane and `lds` bytes of LDS while they
+// sleep for hold_us -- what does a RESIDENT kernel of a given footprint cost the kernels of another stream?
+// (tools/ab_step.py with SIG3D_PROBE_SPIN_US / SIG3D_PROBE_SPIN_SHAPE)
+namespace {
+template <int NV>
+__global__ void hold_kernel(float *sink, unsigned long long hold_ticks) {
+  extern __shared__ float hold_lds[];
+  float v[NV > 0 ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x * (i + 1));
+  if (threadIdx.x == 0) hold_lds[0] = 1.f;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < hold_ticks) {
+    __builtin_amdgcn_s_sleep(16);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));   // keep every register live across the loop
+  }
+  float acc = hold_lds[0];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc += v[i];
+  if (acc == -1.f) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" int sig3d_hold(float *sink, int blocks, int threads, int hold_us, int vgprs, int lds_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(sink != nullptr && blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 4, "bad arguments");
+  const unsigned long long ticks = (unsigned long long)hold_us * 100ull;
+  if (lds_bytes > 48 * 1024) {
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)hold_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)hold_kernel<100>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)hold_kernel<220>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  }
+  if (vgprs >= 200) hipLaunchKernelGGL(hold_kernel<220>, dim3(blocks), dim3(threads), lds_bytes, stream, sink, ticks);
+  else if (vgprs >= 90) hipLaunchKernelGGL(hold_kernel<100>, dim3(blocks), dim3(threads), lds_bytes, stream, sink, ticks);
+  else hipLaunchKernelGGL(hold_kernel<0>, dim3(blocks), dim3(threads), lds_bytes, stream, sink, ticks);
+  SIG3D_LAUNCH_CHECK("hold_kernel");
+  return 0;
+}

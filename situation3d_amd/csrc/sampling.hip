@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
-constexpr int FPS_SLOT_U64 = 64;  // per scene: 2 parities x W <= 16 workgroups x {val,key}
+constexpr int FPS_SLOT_U64 = 128;  // per scene: 2 parities x W <= 32 workgroups x {val,key}
 
 // scenes whose cooperative FPS gave up waiting for a peer workgroup (see the poison path below)
 __device__ unsigned g_fps_timeouts = 0;
@@ -267,12 +267,16 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   gu64 *slots = (gu64 *)(slots_all + (size_t)scene * FPS_SLOT_U64);
   const unsigned bsmask = (1u << L) - 1u;
 
-  // thread's points: k = tid + NT*(s*W + w); NT is a multiple of the reference block size, so
-  // ascending slot s == ascending key inside a thread (see fps_kernel)
+  // thread's points: k = r + 512*(s*G + grp) with g = w*NT + tid the thread's number in its scene, r = g mod 512,
+  // grp = g div 512, G = NT*W/512 (NT = 512: k = tid + NT*(s*W + w)).  All points of a thread share the reference's
+  // thread slot r = k mod 512, so ascending s == ascending tie key inside a thread (see fps_kernel) for ANY NT
+  static_assert((NT * W) % 512 == 0, "a scene's threads must tile the reference block size");
+  constexpr int G = NT * W / 512;
+  const int g_id = w * NT + tid, r_slot = g_id & 511, grp = g_id >> 9;
   float px[PPT], py[PPT], pz[PPT], pt[PPT];
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
-    const int k = tid + NT * (s * W + w);
+    const int k = r_slot + 512 * (s * G + grp);
     float x = 0.f, y = 0.f, z = 0.f, t = -1.f;
     if (k < n) {
       x = dataset[3 * k + 0];
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
       best = gt ? t : best;
       bslot = gt ? s : bslot;
     }
-    const int bk = tid + NT * (bslot * W + w);
+    const int bk = r_slot + 512 * (bslot * G + grp);
     const int myv = __builtin_bit_cast(int, best);
     const int wv = wave_allreduce_max_i32(myv);
     const unsigned mykey = (myv == wv) ? fps_key((unsigned)bk, L, bsmask) : 0xFFFFFFFFu;
@@ -345,8 +349,9 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
         }
       }
       if (lane >= W) { pv = (int)0x80000000; pk = 0xFFFFFFFFu; }
-      const int gv = row_allreduce_max_i32(pv);
-      const unsigned gk = row_allreduce_min_u32(pv == gv ? pk : 0xFFFFFFFFu);
+      const int gv = W <= 16 ? row_allreduce_max_i32(pv) : wave_allreduce_max_i32(pv);
+      const unsigned gk = W <= 16 ? row_allreduce_min_u32(pv == gv ? pk : 0xFFFFFFFFu)
+                                  : wave_allreduce_min_u32(pv == gv ? pk : 0xFFFFFFFFu);
       if (lane == 0) {
         s_win[par][0] = dead ? (int)0x80000001 : gv;
         s_win[par][1] = (int)gk;
@@ -462,7 +467,17 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
       int rc;
       if (n <= 16384) rc = launch_fps_coop<512, 4, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 24576) rc = launch_fps_coop<512, 6, 8>(bc, n, m, L, ds, tp, ix, stream);
-      else if (n <= 40960) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
+      else if (n <= 40960) {
+        // 8 x 256 threads x 20 points since round 3: alone 1.71 us/round against 1.76 for 8 x 512 x 10, and half the
+        // waves beside the training step (-0.06 ms per step, tools/ab_step.py); 16 x 256 x 10: 2.29 us/round alone and
+        // +1.4 ms per step, 32 x 128 x 10: 3.03 (more peers per hop).  SIG3D_FPS_SHAPE = 0 / 1 / 2 selects those.
+        const char *shape = getenv("SIG3D_FPS_SHAPE");
+        const int sh = shape ? atoi(shape) : 3;
+        if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 2) rc = launch_fps_coop<128, 10, 32>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 0) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
+        else rc = launch_fps_coop<256, 20, 8>(bc, n, m, L, ds, tp, ix, stream);
+      }
       else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 98304) rc = launch_fps_coop<512, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
       else rc = launch_fps_coop<1024, 24, 8>(bc, n, m, L, ds, tp, ix, stream);

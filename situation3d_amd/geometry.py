@@ -92,6 +92,8 @@ class GeometryPlan:
                               _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]),
                               _lib.ptr(self.fps_proven[lvl]), s)
                 timeline.mark("geo:L%d fps" % (lvl + 1))
+                if lvl == 0 and os.environ.get("SIG3D_PROBE_FPS_ONLY") == "1" and torch.cuda.is_current_stream_capturing():
+                    return self     # probe (tools/ab_step.py): what the FPS kernel alone costs the step beside it
                 _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
                           _lib.ptr(self.new_xyz[lvl]), s)
                 srcs.append(cur)
@@ -156,13 +158,19 @@ class GeometryPipeline:
     command processor's polling of a blocked barrier costs every kernel the consumer dispatches meanwhile ~1.7 us
     (tools/probes/fork_penalty.py).  `handshake=False` restores the stream wait."""
 
-    def __init__(self, batch, n_points, levels, device, stream, depth=1, handshake=True, stream_priority=0):
+    def __init__(self, batch, n_points, levels, device, stream, depth=1, handshake=True, stream_priority=0,
+                 example_xyz=None):
         assert depth >= 1
         self.depth, self.stream, self.device, self.handshake = int(depth), stream, device, bool(handshake)
         self.plan_cur = GeometryPlan(batch, n_points, levels, device)
         self.slots = []
         self._words = torch.zeros(4 * self.depth, dtype=torch.int32, device=device)   # per slot: ticket, consumed, error
-        example = torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device)
+        # the slots' buffers start from real coordinates when the caller has some (a plan of all-zero points is valid
+        # but degenerate: every ball holds the same 64 points)
+        example = (example_xyz.detach().to(device=device, dtype=torch.float32).contiguous() if example_xyz is not None
+                   else torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device))
+        self._probe_sink = torch.zeros(16, dtype=torch.float32, device=device)
+        self._probe_skip = os.environ.get("SIG3D_PROBE_SKIP_CHAIN") == "1"   # tools/ab_step.py: what the chain costs the step
         # HIP multiplexes streams onto 4 hardware queues per priority, and which queue a new stream gets is not under
         # the caller's control (tools/probes/queue_map_probe.py: two fresh streams share one in ~1 of 4 cases).  A
         # chain on the consumer's queue is simply served in order with it (step 8.1 -> 11.8 ms): every slot stream is
@@ -194,7 +202,15 @@ class GeometryPipeline:
                 if self.handshake:
                     _lib.call("sig3d_ticket_wait", _lib.ptr(w[0:1]), _lib.ptr(w[1:2]), _HANDSHAKE_TIMEOUT_US,
                               _lib.ptr(w[2:3]), _lib.stream_ptr(self.device))
-                slot["plan"].compute(slot["xyz"])
+                spin = os.environ.get("SIG3D_PROBE_SPIN_US")   # probe: one idle thread instead of the chain
+                if spin:
+                    blocks, threads, vg, lds = [int(x) for x in os.environ.get("SIG3D_PROBE_SPIN_SHAPE", "1,64,0,4").split(",")]
+                    if not hasattr(self, "_probe_sink"):
+                        raise RuntimeError("probe sink missing")
+                    _lib.call("sig3d_hold", _lib.ptr(self._probe_sink), blocks, threads, int(spin), vg, lds,
+                              _lib.stream_ptr(self.device))
+                else:
+                    slot["plan"].compute(slot["xyz"])
             self.stream.wait_stream(slot["stream"])
 
     def advance(self, point_clouds, upcoming, token=None, upcoming_tokens=None):
@@ -214,13 +230,16 @@ class GeometryPipeline:
         far = upcoming[-1]
         slot["xyz"].copy_(far[..., :3], non_blocking=True)
         slot["announced"].set(far, toks[-1])
-        if self.handshake:                                   # coordinates staged, plan handed over: the slot may start
+        if self._probe_skip:
+            pass
+        elif self.handshake:                                 # coordinates staged, plan handed over: the slot may start
             with torch.cuda.device(self.device):
                 _lib.call("sig3d_ticket_signal", _lib.ptr(slot["words"][0:1]), self.stream.cuda_stream)
         else:
             slot["stream"].wait_stream(self.stream)
-        with torch.cuda.stream(slot["stream"]):
-            slot["graph"].replay()
+        if not self._probe_skip:
+            with torch.cuda.stream(slot["stream"]):
+                slot["graph"].replay()
         self.calls += 1
 
     def timed_out(self):

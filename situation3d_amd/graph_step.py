@@ -137,7 +137,8 @@ class GraphedTrainStep:
                 self.plan_cur.copy_from(self.plan_next)      # builds the hand-over's copy table OUTSIDE any capture
             else:
                 self._pipe = GeometryPipeline(b, n, levels, pc.device, stream, depth=self.prefetch_depth,
-                                              handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0")
+                                              handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0",
+                                              example_xyz=pc[..., :3])
                 self.plan_cur = self._pipe.plan_cur
                 if reducer is not None:
                     from . import ddp

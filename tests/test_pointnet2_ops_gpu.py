@@ -32,7 +32,7 @@ def test_fps_sizes(hip_ext, oracle, n, m):
                                    (1, 24577, 100), (2, 40960, 100), (1, 40961, 80), (2, 65536, 80), (1, 65537, 60),
                                    (1, 98304, 60), (1, 98305, 50), (1, 150000, 40)])
 def test_fps_cooperative_instances(hip_ext, oracle, b, n, m):
-    """Every (points per thread) instance of the 8 x 512 cooperative kernel at and just past its size limit,
+    """Every (points per thread) instance of the cooperative kernel at and just past its size limit,
     batches that are not a multiple of the 8 scenes of one launch, ties and a zero tail included."""
     _fps_case(hip_ext, oracle, b, n, m, seed=n + b, dup=n // 20, zero_tail=n // 50)
 
@@ -57,6 +57,21 @@ def test_fps_all_skipped_and_m_gt_n(hip_ext, oracle):
     xyz = scene(1, 40, seed=3)
     assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 60).cpu(),
                        oracle.furthest_point_sampling(xyz, 60))
+
+
+@pytest.mark.parametrize("shape", ["0", "1", "2", "3"])
+def test_fps_workgroup_shapes_keep_the_reference_tie_order(hip_ext, oracle, shape, monkeypatch):
+    """SIG3D_FPS_SHAPE: 8 x 512 x 10, 16 x 256 x 10, 32 x 128 x 10 and 8 x 256 x 20 (the default) threads x points
+    per scene at 24 577-40 960 points.  A thread's points always share one slot of the reference's 512-thread block
+    (k = r + 512 (s G + grp)), so exact ties (duplicated points, a grid) and the zero tail resolve as in the reference
+    whatever the shape; read at launch time."""
+    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape)
+    _fps_case(hip_ext, oracle, 2, 40000, 600, seed=21, dup=4000, zero_tail=900)
+    _fps_case(hip_ext, oracle, 1, 24577, 300, seed=22, dup=2000, zero_tail=100)
+    g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1)
+    xyz = (g.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()          # 32 000 grid points: massive exact ties
+    ref = oracle.furthest_point_sampling(xyz, 400)
+    assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 400).cpu(), ref)
 
 
 def test_fps_scene_40k(hip_ext, oracle):

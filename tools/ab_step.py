@@ -1,0 +1,73 @@
+"""Same-process A/B of the graphed training step: two GraphedTrainStep objects over ONE model / optimizer, built with a
+module-level switch at value A and at value B, replayed alternately (A B B A ...) in blocks of `--replays` steps timed
+with events.  Box-to-box spread (+-0.1 ms) and the warm-up drift of one box (8.05 -> 8.27 ms within a minute) cancel in
+the paired differences; effects of ~0.02 ms become visible.
+
+python tools/ab_step.py situation3d_amd.qformer.FUSED_EMBED False True [--rounds 24] [--replays 10]
+python tools/ab_step.py env:SIG3D_GEO_HANDSHAKE 0 1
+"""
+import argparse, importlib, os, statistics, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from situation3d_amd import gemm_tuning  # noqa: E402
+from situation3d_amd.graph_step import GraphedTrainStep  # noqa: E402
+from situation3d_amd.model import SIG3DQFormer  # noqa: E402
+from situation3d_amd.trainer import build_optimizer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("switch", help="module.ATTRIBUTE, e.g. situation3d_amd.qformer.FUSED_EMBED")
+ap.add_argument("a"); ap.add_argument("b")
+ap.add_argument("--rounds", type=int, default=24)
+ap.add_argument("--replays", type=int, default=10)
+args = ap.parse_args()
+if args.switch.startswith("env:"):        # an environment variable read when the step is BUILT (graph_step / geometry)
+    class _Env:
+        pass
+    mod, attr = _Env(), args.switch[4:]
+    _Env.__setattr__ = lambda self, k, v: os.environ.__setitem__(k, str(v))
+else:
+    mod_name, attr = args.switch.rsplit(".", 1)
+    mod = importlib.import_module(mod_name)
+lit = lambda s: {"True": True, "False": False}.get(s, int(s) if s.lstrip("-").isdigit() else s)  # noqa: E731
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+gemm_tuning.enable(tune_missing=True)
+torch.manual_seed(1234)
+model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS).to(dev).train()
+opt = build_optimizer(model, name="flat_adamw")
+batches = [bench.synthetic_batch(bench.BATCH, bench.N_POINTS, 1234 + i, dev) for i in range(4)]
+work = torch.cuda.Stream(dev)
+steps = {}
+with torch.cuda.stream(work):
+    for name, val in (("A", lit(args.a)), ("B", lit(args.b))):
+        setattr(mod, attr, val)
+        steps[name] = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True)
+    k = [0]
+
+    def block(name):
+        g = steps[name]
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):                      # re-prime this variant's geometry pipeline (untimed)
+            g(batches[k[0] % 4], batches[(k[0] + 1) % 4]); k[0] += 1
+        s.record(work)
+        for _ in range(args.replays):
+            g(batches[k[0] % 4], batches[(k[0] + 1) % 4]); k[0] += 1
+        e.record(work)
+        e.synchronize()
+        return s.elapsed_time(e) / args.replays
+
+    for name in "ABBA":
+        block(name)                             # warm-up
+    ta, tb = [], []
+    for r in range(args.rounds):
+        order = "ABBA" if r % 2 == 0 else "BAAB"
+        t = {"A": [], "B": []}
+        for name in order:
+            t[name].append(block(name))
+        ta.append(sum(t["A"]) / 2); tb.append(sum(t["B"]) / 2)
+diff = [b - a for a, b in zip(ta, tb)]
+sd = statistics.stdev(diff) / len(diff) ** 0.5
+print("%s: A=%s %.3f ms   B=%s %.3f ms   B - A = %+.3f ms +- %.3f (paired, %d rounds x 2 x %d replays)"
+      % (args.switch, args.a, statistics.mean(ta), args.b, statistics.mean(tb), statistics.mean(diff), sd, args.rounds,
+         args.replays))
