@@ -333,6 +333,10 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             final_loss = float(loss.item())
+            if graphed is not None and graphed.handshake_timed_out():
+                # a geometry chain gave up waiting for its ticket (30 s) and ran on coordinates that may not have been
+                # staged: the numbers of this run would be those of a broken pipeline
+                raise RuntimeError("a geometry chain timed out waiting for its start ticket (sig3d_ticket_wait)")
             if kernels:
                 # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
                 # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are

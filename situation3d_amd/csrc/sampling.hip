@@ -470,7 +470,9 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
       else if (n <= 40960) {
         // 8 x 256 threads x 20 points since round 3: alone 1.71 us/round against 1.76 for 8 x 512 x 10, and half the
         // waves beside the training step (-0.06 ms per step, tools/ab_step.py); 16 x 256 x 10: 2.29 us/round alone and
-        // +1.4 ms per step, 32 x 128 x 10: 3.03 (more peers per hop).  SIG3D_FPS_SHAPE = 0 / 1 / 2 selects those.
+        // +1.4 ms per step, 32 x 128 x 10: 3.03 (more peers per hop); 4 x 256 x 40 and 8 x 128 x 40 (234 VGPRs): 2.18 / 2.15
+        // us/round and +0.23 / +0.44 ms per step (the chain becomes the critical path).  SIG3D_FPS_SHAPE = 0 / 1 / 2
+        // selects the first three.
         const char *shape = getenv("SIG3D_FPS_SHAPE");
         const int sh = shape ? atoi(shape) : 3;
         if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);

@@ -70,6 +70,10 @@ class PipelinedForward:
     def inline_chains(self):
         return self._pipe.inline_chains
 
+    def handshake_timed_out(self):
+        """True when a geometry chain ever gave up waiting for its start ticket (synchronises)."""
+        return self._pipe.timed_out()
+
     def __call__(self, batch, upcoming, token=None, upcoming_tokens=None):
         """Outputs of `batch`.  `upcoming`: the batches of the next `depth` calls, in order (upcoming[-1] is the one
         whose geometry chain starts now; the others were announced by earlier calls)."""
