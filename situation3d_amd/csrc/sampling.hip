@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
 // A 40 000-point scene does not fit the register file of ONE workgroup (16 waves x 128 VGPRs
 // hold ~24 points per thread), and a global-memory overflow tail costs ~5 us per round.  Here W
 // workgroups each keep n/W points in registers and exchange their per-round candidate
-// (distance, key) through 8-byte {round, value} granules in global memory:
+// (distance, key) through 8-byte granules in global memory -- ONE {round:16, key:16, value:32} granule per
+// workgroup and round up to 65 536 points, a {round, value} / {round, key} pair above:
 //   - a granule is ONE aligned 8-byte agent-scope relaxed store (sc1, write-through), so the
 //     data is its own flag -- no fence, no separate flag word, no torn reads;
 //   - consumers poll with agent-scope relaxed loads (L1 bypass) from one wave only;
@@ -250,7 +251,7 @@ constexpr int FPS_SLOT_U64 = 128;  // per scene: 2 parities x W <= 32 workgroups
 // scenes whose cooperative FPS gave up waiting for a peer workgroup (see the poison path below)
 __device__ unsigned g_fps_timeouts = 0;
 
-template <int NT, int PPT, int W>
+template <int NT, int PPT, int W, bool PACK>
 __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L,
                                                       const float *__restrict__ dataset_all,
                                                       u64 *__restrict__ slots_all,
@@ -322,11 +323,20 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
       const int lv = row_allreduce_max_i32(ov);
       const unsigned lk = row_allreduce_min_u32(ov == lv ? ok : 0xFFFFFFFFu);
       gu64 *slot = slots + (size_t)par * (2 * W);
+      // PACK (n <= 65536, L >= 6): ONE granule {round:16 | key:16 | value:32} per workgroup and round -- the hop pays
+      // per granule (each is its own write-through and its own polled load).  The 16-bit key is the tie key with its
+      // two fields moved together: (bitrev_L(k mod 2^L) << (16 - L)) | (k >> L), same order.
       if (lane == 0) {
-        __hip_atomic_store(slot + 2 * w + 0, ((u64)(unsigned)j << 32) | (unsigned)lv,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 2 * w + 1, ((u64)(unsigned)j << 32) | lk, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        if (PACK) {
+          const unsigned ck = ((lk >> 22) << (16 - L)) | (lk & 0x3FFFFFu);
+          __hip_atomic_store(slot + w, ((u64)(unsigned)(j & 0xFFFF) << 48) | ((u64)(ck & 0xFFFFu) << 32) | (unsigned)lv,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          __hip_atomic_store(slot + 2 * w + 0, ((u64)(unsigned)j << 32) | (unsigned)lv,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(slot + 2 * w + 1, ((u64)(unsigned)j << 32) | lk, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       // lanes 0..W-1 each wait for one peer's pair (lane w reads its own, already published)
       int pv = (int)0x80000000;
@@ -336,11 +346,19 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
       while (!ok_all) {
         bool mine = true;
         if (lane < W) {
+          if (PACK) {
+            const u64 a = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mine = (unsigned)(a >> 48) == (unsigned)(j & 0xFFFF);
+            pv = (int)(unsigned)a;
+            const unsigned ck = (unsigned)(a >> 32) & 0xFFFFu;
+            pk = ((ck >> (16 - L)) << 22) | (ck & ((1u << (16 - L)) - 1u));
+          } else {
           const u64 a = __hip_atomic_load(slot + 2 * lane + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const u64 c = __hip_atomic_load(slot + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           mine = ((unsigned)(a >> 32) == (unsigned)j) && ((unsigned)(c >> 32) == (unsigned)j);
           pv = (int)(unsigned)a;
           pk = (unsigned)c;
+          }
         }
         ok_all = __all(mine);
         if (!ok_all) {
@@ -376,10 +394,17 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
 template <int NT, int PPT, int W>
 int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
                     hipStream_t stream) {
+  // one packed granule per workgroup and round when the key fits 16 bits (SIG3D_FPS_PACK=0: the two-granule form)
+  const char *pk = getenv("SIG3D_FPS_PACK");
+  const bool pack = n <= 65536 && m <= 65536 && L >= 6 && L <= 16 && !(pk && atoi(pk) == 0);
   // the granule slots live at the front of the caller's temp scratch (b*n floats >= b*128)
   SIG3D_HIP_TRY(hipMemsetAsync(temp, 0, sizeof(u64) * (size_t)b * FPS_SLOT_U64, stream));
-  hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
-                     dataset, (u64 *)temp, idxs);
+  if (pack)
+    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, true>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
+                       dataset, (u64 *)temp, idxs);
+  else
+    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, false>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
+                       dataset, (u64 *)temp, idxs);
   SIG3D_LAUNCH_CHECK("fps_coop_kernel");
   return 0;
 }

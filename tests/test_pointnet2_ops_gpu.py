@@ -59,13 +59,15 @@ def test_fps_all_skipped_and_m_gt_n(hip_ext, oracle):
                        oracle.furthest_point_sampling(xyz, 60))
 
 
-@pytest.mark.parametrize("shape", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("shape", ["0", "1", "2", "3", "3-two-granules"])
 def test_fps_workgroup_shapes_keep_the_reference_tie_order(hip_ext, oracle, shape, monkeypatch):
     """SIG3D_FPS_SHAPE: 8 x 512 x 10, 16 x 256 x 10, 32 x 128 x 10 and 8 x 256 x 20 (the default) threads x points
     per scene at 24 577-40 960 points.  A thread's points always share one slot of the reference's 512-thread block
     (k = r + 512 (s G + grp)), so exact ties (duplicated points, a grid) and the zero tail resolve as in the reference
     whatever the shape; read at launch time."""
-    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape)
+    if shape.endswith("two-granules"):       # SIG3D_FPS_PACK=0: {round, value} + {round, key} instead of one packed granule
+        monkeypatch.setenv("SIG3D_FPS_PACK", "0")
+    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape[0])
     _fps_case(hip_ext, oracle, 2, 40000, 600, seed=21, dup=4000, zero_tail=900)
     _fps_case(hip_ext, oracle, 1, 24577, 300, seed=22, dup=2000, zero_tail=100)
     g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1)
