@@ -71,6 +71,86 @@ __global__ __launch_bounds__(CP_THREADS) void compact_lists_kernel(
   }
 }
 
+// The same lists with coalesced reads: a row of NS entries is read by NS consecutive lanes (64 / NS rows per wave
+// and load), the distinct entries of a row are its leading ones plus nothing else (a padded entry repeats the FIRST
+// hit), so "keep" = (s == 0 || entry != first) and a row's output positions are the popcount of the keep bits below
+// a lane.  Pass 1 counts per row into LDS, one workgroup-wide scan gives every row its offset, pass 2 emits.
+// (The thread-per-row kernel above walks 256-byte rows with a 256-byte stride between lanes: 200 us at SA1, at the
+// END of the geometry chain -- where every microsecond is one the next step may have to wait for.)
+constexpr int CW_MAX_M = 8192;
+
+template <int NS>
+__global__ __launch_bounds__(CP_THREADS) void compact_lists_wave_kernel(
+    int m, const int *__restrict__ idx_all, int *__restrict__ cidx_all, int *__restrict__ ccent_all,
+    float *__restrict__ mult_all, int *__restrict__ seg_all, int *__restrict__ n_act) {
+  constexpr int RPW = 64 / NS;                 // rows per wave and trip
+  constexpr int NWAVES = CP_THREADS / 64;
+  __shared__ int s_cnt[CW_MAX_M];              // per row: distinct count, then exclusive offset
+  __shared__ int s_wave[NWAVES];
+  const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long total = (long)m * NS;
+  const int *idx = idx_all + (size_t)bi * total;
+  int *cidx = cidx_all + (size_t)bi * total;
+  int *ccent = ccent_all + (size_t)bi * total;
+  float *mult = mult_all + (size_t)bi * total;
+  int *seg = seg_all + (size_t)bi * (m + 1);
+  const int sub = lane / NS, s_in = lane % NS;  // which row of the trip, which entry of the row
+  const unsigned long long rowmask = (NS == 64 ? ~0ull : ((1ull << NS) - 1ull)) << (sub * NS);
+  // pass 1: distinct count per row
+  for (int j0 = wave * RPW; j0 < m; j0 += NWAVES * RPW) {
+    const int j = j0 + sub;
+    const bool live = j < m;
+    const int a = live ? idx[(size_t)j * NS + s_in] : 0;
+    const int first = __shfl(a, sub * NS, 64);
+    const bool keep = live && (s_in == 0 || a != first);
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
+    if (live && s_in == 0) s_cnt[j] = __builtin_popcountll(bits);
+  }
+  __syncthreads();
+  // exclusive scan of s_cnt[0..m): thread t owns a contiguous run of rows
+  const int per = (m + CP_THREADS - 1) / CP_THREADS;
+  const int r0 = min(tid * per, m), r1 = min(r0 + per, m);
+  int mine = 0;
+  for (int j = r0; j < r1; ++j) mine += s_cnt[j];
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int run = incl - mine;
+  for (int w = 0; w < wave; ++w) run += s_wave[w];
+  for (int j = r0; j < r1; ++j) {
+    const int k = s_cnt[j];
+    s_cnt[j] = run;
+    seg[j] = run;
+    run += k;
+  }
+  if (tid == CP_THREADS - 1) {
+    seg[m] = run;
+    n_act[bi] = run;
+  }
+  __syncthreads();
+  // pass 2: emit
+  for (int j0 = wave * RPW; j0 < m; j0 += NWAVES * RPW) {
+    const int j = j0 + sub;
+    const bool live = j < m;
+    const int a = live ? idx[(size_t)j * NS + s_in] : 0;
+    const int first = __shfl(a, sub * NS, 64);
+    const bool keep = live && (s_in == 0 || a != first);
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
+    if (keep) {
+      const int pos = s_cnt[j] + __builtin_popcountll(bits & ((1ull << lane) - 1ull));
+      cidx[pos] = a;
+      ccent[pos] = j;
+      // the first hit also stands for the padding
+      mult[pos] = s_in == 0 ? (float)(NS - __builtin_popcountll(bits) + 1) : 1.f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sig3d_compact_neighbour_lists(int b, int m, int nsample, const int *idx, int *cidx, int *ccent,
@@ -78,7 +158,20 @@ extern "C" int sig3d_compact_neighbour_lists(int b, int m, int nsample, const in
   SIG3D_REQUIRE(b >= 0 && m >= 0 && nsample >= 1, "bad size");
   SIG3D_REQUIRE((long)m * nsample < (1L << 31), "m * nsample too large");
   if (b == 0) return 0;
-  hipLaunchKernelGGL(compact_lists_kernel, dim3(b), dim3(CP_THREADS), 0, (hipStream_t)stream_, m, nsample, idx, cidx,
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= CW_MAX_M && (nsample == 64 || nsample == 32 || nsample == 16 || nsample == 8)) {
+    if (nsample == 64)
+      hipLaunchKernelGGL(compact_lists_wave_kernel<64>, dim3(b), dim3(CP_THREADS), 0, stream, m, idx, cidx, ccent, mult, seg_off, n_act);
+    else if (nsample == 32)
+      hipLaunchKernelGGL(compact_lists_wave_kernel<32>, dim3(b), dim3(CP_THREADS), 0, stream, m, idx, cidx, ccent, mult, seg_off, n_act);
+    else if (nsample == 16)
+      hipLaunchKernelGGL(compact_lists_wave_kernel<16>, dim3(b), dim3(CP_THREADS), 0, stream, m, idx, cidx, ccent, mult, seg_off, n_act);
+    else
+      hipLaunchKernelGGL(compact_lists_wave_kernel<8>, dim3(b), dim3(CP_THREADS), 0, stream, m, idx, cidx, ccent, mult, seg_off, n_act);
+    SIG3D_LAUNCH_CHECK("compact_lists_wave_kernel");
+    return 0;
+  }
+  hipLaunchKernelGGL(compact_lists_kernel, dim3(b), dim3(CP_THREADS), 0, stream, m, nsample, idx, cidx,
                      ccent, mult, seg_off, n_act);
   SIG3D_LAUNCH_CHECK("compact_lists_kernel");
   return 0;

@@ -98,6 +98,8 @@ class GeometryPlan:
                           _lib.ptr(self.new_xyz[lvl]), s)
                 srcs.append(cur)
                 cur, n = self.new_xyz[lvl], npoint
+            if os.environ.get("SIG3D_PROBE_CHAIN_UNTIL") == "sampling" and torch.cuda.is_current_stream_capturing():
+                return self     # probe: FPS + proofs + centre gathers of all levels
             # the neighbour lists of ALL levels depend on coordinates only: one scatter + one rank launch
             # (csrc/ball_query.hip: centres binned into cells, points streamed once) instead of a chain per level
             ptrs = [t.data_ptr() for t in srcs]
@@ -114,6 +116,8 @@ class GeometryPlan:
             _lib.call("sig3d_ball_query_levels_ex", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
                       self._bq_work.numel(), _lib.BQ_CLEAN if self._bq_clean else 0, s)
             self._bq_clean = True
+            if os.environ.get("SIG3D_PROBE_CHAIN_UNTIL") == "ballquery" and torch.cuda.is_current_stream_capturing():
+                return self     # probe: ... + the ball queries (no distinct-neighbour lists)
             for lvl in range(len(self.levels)):
                 if self.compact[lvl] is not None:
                     self.compact[lvl].compute(self.ball_idx[lvl])

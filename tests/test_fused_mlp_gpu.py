@@ -163,15 +163,22 @@ def test_compact_sa_level_matches_dense(c_feat, mlp, npoint, nsample, radius):
     close(e1, e2, "eval output")
 
 
-def test_compact_lists_structure():
-    """sig3d_compact_neighbour_lists against a direct construction from the padded lists."""
+@pytest.mark.parametrize("b,m,ns", [(3, 300, 16), (2, 257, 64), (2, 130, 32), (1, 61, 8), (2, 90, 12), (1, 2048, 64),
+                                    (1, 8200, 16)])
+def test_compact_lists_structure(b, m, ns):
+    """sig3d_compact_neighbour_lists against a direct construction from the padded lists: the wave-per-row kernel
+    (nsample 8 / 16 / 32 / 64, m <= 8192: rows not a multiple of the rows per wave, full and single-entry rows) and
+    the thread-per-row one (any nsample, any m)."""
     from situation3d_amd.pointnet2 import fused_mlp
-    g = torch.Generator().manual_seed(3)
-    b, m, ns, n = 3, 300, 16, 900
+    g = torch.Generator().manual_seed(3 + m)
+    n = 4 * m + 100
+    ks = torch.randint(1, ns + 1, (b, m), generator=g)
+    ks[:, 0] = ns                                      # a full row
+    ks[:, -1] = 1                                      # a row that is all padding
     idx = torch.zeros(b, m, ns, dtype=torch.int32)
     for bi in range(b):
         for j in range(m):
-            k = int(torch.randint(1, ns + 1, (1,), generator=g))
+            k = int(ks[bi, j])
             hits = torch.sort(torch.randperm(n, generator=g)[:k]).values.int()
             idx[bi, j, :k] = hits
             idx[bi, j, k:] = hits[0]
