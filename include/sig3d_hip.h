@@ -69,6 +69,14 @@ int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, flo
  * that fail the proof run the m dependent rounds.  flags: b ints, 1 = proven, 0 = computed. */
 int sig3d_furthest_point_sampling_nested(int b, int n, int m, const float *dataset, float *temp,
                                          int *idxs, int *flags, void *stream);
+/* A chain of nested samplings with ONE proof: level l draws m[l] points from the output of level l-1 (level 0 from the
+ * n0 points of `dataset`), exactly as sig3d_furthest_point_sampling_nested + sig3d_gather_xyz called level by level
+ * (same indices, same centres, for ANY input), but one radius launch and one check launch cover all levels.
+ * m: nlevels (1..4) host ints with m[l] <= n[l] <= 8192, m[l] <= 4096; idxs[l] (b, m[l]) int32 and new_xyz[l]
+ * (b, m[l], 3) f32: HOST arrays of device pointers; temp (b, n0) f32 scratch; flags (nlevels, b) int32: 1 where
+ * level l of a scene was proven (and every level above it). */
+int sig3d_fps_nested_chain(int b, int n0, int nlevels, const int *m, const float *dataset, float *temp,
+                           int *const *idxs, float *const *new_xyz, int *flags, void *stream);
 
 /* replaces gather_points_kernel_wrapper(b,c,n,npoints,points,idx,out)
  *   sampling.cpp:4-6, sampling_gpu.cu:8-31.   points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */

@@ -20,6 +20,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_furthest_point_sampling_nested": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "sig3d_fps_nested_chain": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_fps_timeout_count": [_P, _I],
     "sig3d_timestamp": [_P, _P],
     "sig3d_timestamp_rate": [_I, _P],

@@ -150,14 +150,14 @@ int launch_fps(int b, int n, int m, int L, const float *dataset, float *temp, in
 // rule as fps_kernel: the check decides exactly what fps_kernel would have computed, and any
 // scene that fails it (ties, duplicates, zero padding, an input that is not FPS-ordered at all)
 // runs the ordinary kernel.  Bit-exact either way.
-__global__ __launch_bounds__(256) void fps_prefix_radius_kernel(int n, int m,
+__global__ __launch_bounds__(256) void fps_prefix_radius_kernel(int n, int m, int nflags,
                                                                 const float *__restrict__ dataset_all,
                                                                 float *__restrict__ r_all,
                                                                 int *__restrict__ ok_all) {
   const float *dataset = dataset_all + (size_t)blockIdx.y * n * 3;
   const int lane = threadIdx.x & 63;
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per round
-  if (blockIdx.x == 0 && threadIdx.x == 0) ok_all[blockIdx.y] = 1;
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)nflags) ok_all[threadIdx.x * gridDim.y + blockIdx.y] = 1;
   if (j >= m) return;
   const float x = dataset[3 * j + 0], y = dataset[3 * j + 1], z = dataset[3 * j + 2];
   const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
@@ -169,13 +169,23 @@ __global__ __launch_bounds__(256) void fps_prefix_radius_kernel(int n, int m,
   if (lane == 0) r_all[(size_t)blockIdx.y * n + j] = t;
 }
 
-__global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int L,
+// blockIdx.z = level of a CHAIN of nested samplings over one FPS-ordered array (sig3d_fps_nested_chain): level l
+// samples m[l] of the first n[l] points (n[l+1] = m[l]); all levels read the same array (stride n[0]) and the same
+// r[], and a violation at level l also fails every deeper level (whose input would no longer be this prefix).
+struct FpsChain {
+  int levels, stride;
+  int n[4], m[4], L[4];
+};
+
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(FpsChain ch,
                                                                const float *__restrict__ dataset_all,
                                                                const float *__restrict__ r_all,
                                                                int *__restrict__ ok_all) {
   extern __shared__ float s_prefix[];  // x,y,z,r of the first m points
-  const float *dataset = dataset_all + (size_t)blockIdx.y * n * 3;
-  const float *r = r_all + (size_t)blockIdx.y * n;
+  const int level = blockIdx.z, n = ch.n[level], m = ch.m[level], L = ch.L[level], nb = gridDim.y;
+  if ((int)(blockIdx.x * 256) >= n) return;
+  const float *dataset = dataset_all + (size_t)blockIdx.y * ch.stride * 3;
+  const float *r = r_all + (size_t)blockIdx.y * ch.stride;
   for (int i = threadIdx.x; i < m; i += 256) {
     s_prefix[4 * i + 0] = dataset[3 * i + 0];
     s_prefix[4 * i + 1] = dataset[3 * i + 1];
@@ -213,7 +223,8 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
     // after the first trip (half of all points beat point 1 in round 1), so calling the nested entry point
     // on arbitrary clouds costs little more than the plain one
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
-      if (bad) ok_all[blockIdx.y] = 0;
+      if (bad)
+        for (int l = level; l < ch.levels; ++l) ok_all[l * nb + blockIdx.y] = 0;
       return;
     }
   }
@@ -223,7 +234,8 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
     const float rj = s_prefix[4 * (i + 1) + 3];
     if (t >= rj && k != i + 1) bad |= (t > rj) || mykey < fps_key((unsigned)(i + 1), L, bsmask);
   }
-  if (bad) ok_all[blockIdx.y] = 0;
+  if (bad)
+    for (int l = level; l < ch.levels; ++l) ok_all[l * nb + blockIdx.y] = 0;
 }
 
 // ---- cooperative FPS: one scene spread over W workgroups ------------------------------------
@@ -515,6 +527,17 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
   return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
 }
 
+static int launch_fps_flagged(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
+                              hipStream_t stream, const int *flags) {
+  if (n <= 256) return launch_fps<256, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n < 512) return launch_fps<256, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 512) return launch_fps<512, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 1024) return launch_fps<512, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
+}
+
 // FPS of a cloud that is (expected to be) the FPS-ordered output of an earlier FPS: identical
 // results to sig3d_furthest_point_sampling for ANY input, the dependent rounds only run for the
 // scenes where the prefix property fails.  `flags`: b ints of scratch (1 = proven, 0 = computed).
@@ -530,19 +553,53 @@ extern "C" int sig3d_furthest_point_sampling_nested(int b, int n, int m, const f
   if (m > n || m > 4096 || n > 8192)
     return sig3d_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream_);
   const int L = ref_opt_n_threads_log2(n);
+  FpsChain ch{};
+  ch.levels = 1; ch.stride = n; ch.n[0] = n; ch.m[0] = m; ch.L[0] = L;
   hipLaunchKernelGGL(fps_prefix_radius_kernel, dim3(sig3d_ceil_div(m, 4), b), dim3(256), 0, stream,
-                     n, m, dataset, temp, flags);
+                     n, m, 1, dataset, temp, flags);
   SIG3D_LAUNCH_CHECK("fps_prefix_radius_kernel");
-  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n, 256), b), dim3(256),
-                     sizeof(float) * 4 * (size_t)m, stream, n, m, L, dataset, temp, flags);
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n, 256), b, 1), dim3(256),
+                     sizeof(float) * 4 * (size_t)m, stream, ch, dataset, temp, flags);
   SIG3D_LAUNCH_CHECK("fps_prefix_check_kernel");
-  if (n <= 256) return launch_fps<256, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  if (n < 512) return launch_fps<256, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  if (n <= 512) return launch_fps<512, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  if (n <= 1024) return launch_fps<512, 2>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  if (n <= 2048) return launch_fps<512, 4>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  if (n <= 4096) return launch_fps<512, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
-  return launch_fps<1024, 8>(b, n, m, L, dataset, temp, idxs, stream, flags);
+  return launch_fps_flagged(b, n, m, L, dataset, temp, idxs, stream, flags);
+}
+
+// A chain of nested samplings in one proof: level l draws m[l] points from the output of level l-1 (n[0] = n0 points
+// of `dataset`, n[l] = m[l-1]), exactly as calling sig3d_furthest_point_sampling_nested + sig3d_gather_xyz level by
+// level -- but the prefix property of ALL levels is checked by one radius launch and one check launch over the same
+// FPS-ordered array (level l's input is its first n[l] points as long as every level above was proven; a level that
+// fails also fails the levels below it, which then run the dependent rounds on their true input).  The geometry
+// chain ends with these levels, and the training step waits for the chain: three proofs back to back were ~250 us.
+extern "C" int sig3d_fps_nested_chain(int b, int n0, int nlevels, const int *m, const float *dataset, float *temp,
+                                      int *const *idxs, float *const *new_xyz, int *flags, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && n0 >= 1 && nlevels >= 1 && nlevels <= 4, "1 to 4 levels");
+  SIG3D_REQUIRE(m != nullptr && idxs != nullptr && new_xyz != nullptr && flags != nullptr, "null pointer");
+  if (b == 0) return 0;
+  FpsChain ch{};
+  ch.levels = nlevels; ch.stride = n0;
+  int n = n0;
+  for (int l = 0; l < nlevels; ++l) {
+    SIG3D_REQUIRE(m[l] >= 1 && m[l] <= n && m[l] <= 4096 && n <= 8192, "levels must shrink: 1 <= m[l] <= n[l] <= 8192, m[l] <= 4096");
+    ch.n[l] = n; ch.m[l] = m[l]; ch.L[l] = ref_opt_n_threads_log2(n);
+    n = m[l];
+  }
+  hipLaunchKernelGGL(fps_prefix_radius_kernel, dim3(sig3d_ceil_div(m[0], 4), b), dim3(256), 0, stream,
+                     n0, m[0], nlevels, dataset, temp, flags);
+  SIG3D_LAUNCH_CHECK("fps_prefix_radius_kernel");
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n0, 256), b, nlevels), dim3(256),
+                     sizeof(float) * 4 * (size_t)m[0], stream, ch, dataset, temp, flags);
+  SIG3D_LAUNCH_CHECK("fps_prefix_check_kernel");
+  const float *cur = dataset;
+  for (int l = 0; l < nlevels; ++l) {
+    // temp's r[] has been consumed by the check; the flagged kernel may use it as its scratch
+    const int rc = launch_fps_flagged(b, ch.n[l], ch.m[l], ch.L[l], cur, temp, idxs[l], stream, flags + (size_t)l * b);
+    if (rc) return rc;
+    const int rg = sig3d_gather_xyz(b, ch.n[l], ch.m[l], cur, idxs[l], new_xyz[l], stream_);
+    if (rg) return rg;
+    cur = new_xyz[l];
+  }
+  return 0;
 }
 
 extern "C" int sig3d_fps_timeout_count(unsigned *count, int reset) {

@@ -23,6 +23,8 @@ from .pointnet2 import _ext, fused_mlp
 
 # SIG3D_NESTED_FPS=0 runs the dependent rounds on every level (A/B timing; results are identical)
 NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
+# SIG3D_FPS_CHAIN=0: the nested levels prove their prefix one after the other (round 2) instead of in one launch pair
+NESTED_CHAIN = os.environ.get("SIG3D_FPS_CHAIN", "1") != "0"
 
 
 class Announced:
@@ -81,7 +83,16 @@ class GeometryPlan:
         with torch.cuda.device(dev):
             timeline.mark("geo:start")
             srcs = []
+            chain = self._nested_chain(b) if NESTED_FPS and NESTED_CHAIN else None
             for lvl, (npoint, radius, nsample) in enumerate(self.levels):
+                if chain is not None and lvl >= 1:
+                    if lvl == 1:   # levels 1.. sample the FPS-ordered centres of level 0: one proof for all of them
+                        _lib.call("sig3d_fps_nested_chain", b, n, len(self.levels) - 1, chain[0], _lib.ptr(cur),
+                                  _lib.ptr(self._temp[1]), chain[1], chain[2], _lib.ptr(self._chain_flags), s)
+                    timeline.mark("geo:L%d fps" % (lvl + 1))
+                    srcs.append(cur)
+                    cur, n = self.new_xyz[lvl], npoint
+                    continue
                 if lvl == 0 or not NESTED_FPS:
                     _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
                               _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
@@ -123,6 +134,23 @@ class GeometryPlan:
                     self.compact[lvl].compute(self.ball_idx[lvl])
             timeline.mark("geo:lists")
         return self
+
+    def _nested_chain(self, b):
+        """ctypes tables of sig3d_fps_nested_chain for levels 1.. (None when the chain's size limits do not hold)."""
+        if getattr(self, "_chain", False) is not False:
+            return self._chain
+        self._chain = None
+        deeper = self.levels[1:]
+        ns = [lv[0] for lv in self.levels[:-1]]
+        if 1 <= len(deeper) <= 4 and all(lv[0] <= n_in <= 8192 and lv[0] <= 4096 for lv, n_in in zip(deeper, ns)):
+            m = (ctypes.c_int * len(deeper))(*[lv[0] for lv in deeper])
+            idxs = (ctypes.c_void_p * len(deeper))(*[t.data_ptr() for t in self.inds[1:]])
+            cent = (ctypes.c_void_p * len(deeper))(*[t.data_ptr() for t in self.new_xyz[1:]])
+            self._chain_flags = torch.zeros(len(deeper), b, dtype=torch.int32, device=self.inds[0].device)
+            for k in range(len(deeper)):                        # fps_proven[lvl]: views of the chain's flags
+                self.fps_proven[k + 1] = self._chain_flags[k]
+            self._chain = (m, idxs, cent)
+        return self._chain
 
     def level(self, i):
         return self.inds[i], self.new_xyz[i], self.ball_idx[i], self.compact[i]
@@ -174,7 +202,7 @@ class GeometryPipeline:
         example = (example_xyz.detach().to(device=device, dtype=torch.float32).contiguous() if example_xyz is not None
                    else torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device))
         self._probe_sink = torch.zeros(16, dtype=torch.float32, device=device)
-        self._probe_skip = os.environ.get("SIG3D_PROBE_SKIP_CHAIN") == "1"   # tools/ab_step.py: what the chain costs the step
+        self._probe_skip = os.environ.get("SIG3D_PROBE_SKIP_CHAIN") in ("1", "2")   # tools/ab_step.py: what the chain costs the step
         # HIP multiplexes streams onto 4 hardware queues per priority, and which queue a new stream gets is not under
         # the caller's control (tools/probes/queue_map_probe.py: two fresh streams share one in ~1 of 4 cases).  A
         # chain on the consumer's queue is simply served in order with it (step 8.1 -> 11.8 ms): every slot stream is
@@ -225,6 +253,17 @@ class GeometryPipeline:
             raise ValueError("a geometry pipeline of depth %d needs the next %d batches" % (self.depth, self.depth))
         toks = list(upcoming_tokens) if upcoming_tokens is not None else [None] * self.depth
         slot = self.slots[self.calls % self.depth]
+        if os.environ.get("SIG3D_PROBE_SKIP_CHAIN") == "2":
+            # probe: no chain at all, yet every batch gets ITS plan (computed once per distinct batch tensor, cached) --
+            # the step alone over correct geometry, the number the chain's cost is measured against
+            cache = self.__dict__.setdefault("_probe_plans", {})
+            key = id(point_clouds)
+            if key not in cache:
+                plan = GeometryPlan(self.plan_cur.batch, self.plan_cur.n_points, self.plan_cur.levels, self.device)
+                cache[key] = (plan.compute(point_clouds[..., :3].contiguous()), point_clouds)
+            self.plan_cur.copy_from(cache[key][0])
+            self.calls += 1
+            return
         self.stream.wait_stream(slot["stream"])              # the chain launched `depth` calls ago (any chain: its
         if slot["announced"].matches(point_clouds, token):   # coordinate buffer is about to be overwritten)
             self.plan_cur.copy_from(slot["plan"])

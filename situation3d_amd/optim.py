@@ -25,6 +25,7 @@ the flat STORAGE order is a separate argument), so the reference's checkpoints (
 train.py:256-262) round-trip in both directions.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,11 @@ from . import _lib
 _CHUNK = 65536
 _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
                  ("pad", "f4")])
+
+
+# workgroups that walk the chunk table of one update launch when the optimizer is not given max_workgroups
+# (0: one workgroup per 64 Ki-element chunk); SIG3D_ADAMW_WORKGROUPS
+DEFAULT_MAX_WORKGROUPS = int(os.environ.get("SIG3D_ADAMW_WORKGROUPS", "0"))
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -371,10 +377,11 @@ class FlatAdamW(torch.optim.Optimizer):
         b1, b2 = g0["betas"]
         args = [n, _lib.ptr(table), _lib.ptr(self._step), ctypes.c_float(g0["lr"]), _lib.ptr(self._lr_dev),
                 ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]), ctypes.c_float(self.clip_value)]
-        if self.max_workgroups is None:
+        bound = self.max_workgroups if self.max_workgroups is not None else DEFAULT_MAX_WORKGROUPS
+        if not bound:
             _lib.call("sig3d_adamw_table", *args, stream)
         else:
-            _lib.call("sig3d_adamw_table_bounded", *args, self.max_workgroups, stream)
+            _lib.call("sig3d_adamw_table_bounded", *args, int(bound), stream)
 
     @torch.no_grad()
     def update_buckets(self, reducer):

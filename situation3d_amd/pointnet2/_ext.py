@@ -101,6 +101,24 @@ def furthest_point_sampling_nested(points, nsamples, return_proven=False):
     return (out, flags[:b]) if return_proven else out
 
 
+def furthest_point_sampling_nested_chain(points, nsamples):
+    """Levels of nested sampling in one proof (sig3d_fps_nested_chain): level l draws nsamples[l] points from the
+    output of level l-1 (level 0 from `points` (B, N, 3)), exactly as furthest_point_sampling_nested + a gather of the
+    centres level by level.  -> ([idx_l (B, m_l) i32], [xyz_l (B, m_l, 3)], proven (levels, B) i32)."""
+    _check_contiguous(points, "points"); _check_float(points, "points")
+    dev = _lib.require_device(points)
+    b, n, _ = points.shape
+    ms = [int(m) for m in nsamples]
+    idxs = [torch.zeros((b, m), dtype=torch.int32, device=dev) for m in ms]
+    cent = [torch.zeros((b, m, 3), dtype=torch.float32, device=dev) for m in ms]
+    flags = torch.zeros((len(ms), max(b, 1)), dtype=torch.int32, device=dev)
+    tmp = torch.empty((b, max(n, 1)), dtype=torch.float32, device=dev)
+    _run("sig3d_fps_nested_chain", dev, b, n, len(ms), (ctypes.c_int * len(ms))(*ms), _lib.ptr(points), _lib.ptr(tmp),
+         (ctypes.c_void_p * len(ms))(*[t.data_ptr() for t in idxs]),
+         (ctypes.c_void_p * len(ms))(*[t.data_ptr() for t in cent]), _lib.ptr(flags))
+    return idxs, cent, flags[:, :b]
+
+
 def three_nn(unknowns, knows):
     """interpolate.cpp:14-40: -> [dist2 (B,n,3) f32, idx (B,n,3) i32]."""
     _check_contiguous(unknowns, "unknowns"); _check_contiguous(knows, "knows")

@@ -127,6 +127,38 @@ def test_nested_fps_falls_back_per_scene_on_ties_skips_and_unordered_input(hip_e
         assert torch.equal(got, oracle.furthest_point_sampling(cloud, m)), (tuple(cloud.shape), m)
 
 
+@pytest.mark.parametrize("n0,ms", [(2048, [1024, 512, 256]), (600, [300, 128]), (700, [700]), (513, [512, 255, 100, 9])])
+def test_nested_fps_chain_equals_level_by_level(hip_ext, oracle, n0, ms):
+    """sig3d_fps_nested_chain (one proof for all levels) against sig3d_furthest_point_sampling_nested + gather, level
+    by level, and the oracle: FPS-ordered scenes (every level proven), a random order (nothing proven), an ordered
+    scene with duplicates / a zero tail inside the prefix, and one swapped pair late in the order (level 0 fails, the
+    levels below must then run on their TRUE input)."""
+    from situation3d_amd.pointnet2 import _ext as amd_ext
+    a = _fps_ordered(hip_ext, scene(1, 3 * n0, seed=n0), n0)
+    b_ = scene(1, n0, seed=n0 + 1).to(DEV)
+    c = _fps_ordered(hip_ext, scene(1, 3 * n0, seed=n0 + 2, dup=n0, zero_tail=n0 // 3), n0)
+    d = a.clone()
+    i, j = n0 - 3, n0 - 2
+    d[0, [i, j]] = d[0, [j, i]]
+    cloud = torch.cat([a, b_, c, d]).contiguous()
+    idxs, cent, proven = amd_ext.furthest_point_sampling_nested_chain(cloud, ms)
+    cur = cloud
+    for l, m in enumerate(ms):
+        ref = oracle.furthest_point_sampling(cur.cpu(), m)
+        assert torch.equal(idxs[l].cpu(), ref), (l, (idxs[l].cpu() != ref).nonzero()[:3].tolist())
+        assert torch.equal(idxs[l], _nested(cur, m))
+        nxt = torch.gather(cur, 1, ref.to(DEV).long()[..., None].expand(-1, -1, 3)).contiguous()
+        assert torch.equal(cent[l], nxt)
+        for sc in range(4):
+            if proven[l, sc].item():
+                assert torch.equal(idxs[l][sc].cpu(), torch.arange(m, dtype=torch.int32))
+                assert all(proven[k, sc].item() for k in range(l))       # a proof holds only below proven levels
+        cur = nxt
+    assert proven[:, 0].tolist() == [1] * len(ms) and proven[:, 1].sum().item() == 0
+    if ms[0] > n0 - 3:
+        assert proven[0, 3].item() == 0
+
+
 def test_nested_fps_rejects_a_prefix_that_is_one_swap_away(hip_ext, oracle):
     """Adversarial: swap two late points of an FPS-ordered cloud -- a single round is wrong, every other
     condition holds -- and perturb one point by one ulp-scale step so it wins its round early."""

@@ -5,6 +5,7 @@ the paired differences; effects of ~0.02 ms become visible.
 
 python tools/ab_step.py situation3d_amd.qformer.FUSED_EMBED False True [--rounds 24] [--replays 10]
 python tools/ab_step.py env:SIG3D_GEO_HANDSHAKE 0 1
+python tools/ab_step.py env:SIG3D_GEO_DEPTH 1 2
 """
 import argparse, importlib, os, statistics, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -42,17 +43,19 @@ steps = {}
 with torch.cuda.stream(work):
     for name, val in (("A", lit(args.a)), ("B", lit(args.b))):
         setattr(mod, attr, val)
-        steps[name] = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True)
+        steps[name] = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True,
+                                       prefetch_depth=int(os.environ.get("SIG3D_GEO_DEPTH", "1")))
     k = [0]
 
     def block(name):
         g = steps[name]
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(2):                      # re-prime this variant's geometry pipeline (untimed)
-            g(batches[k[0] % 4], batches[(k[0] + 1) % 4]); k[0] += 1
+        d = g.prefetch_depth
+        for _ in range(1 + d):                  # re-prime this variant's geometry pipeline (untimed)
+            g(batches[k[0] % 4], upcoming=[batches[(k[0] + 1 + i) % 4] for i in range(d)]); k[0] += 1
         s.record(work)
         for _ in range(args.replays):
-            g(batches[k[0] % 4], batches[(k[0] + 1) % 4]); k[0] += 1
+            g(batches[k[0] % 4], upcoming=[batches[(k[0] + 1 + i) % 4] for i in range(d)]); k[0] += 1
         e.record(work)
         e.synchronize()
         return s.elapsed_time(e) / args.replays
