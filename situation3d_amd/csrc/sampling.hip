@@ -238,6 +238,91 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(FpsChain ch,
     for (int l = level; l < ch.levels; ++l) ok_all[l * nb + blockIdx.y] = 0;
 }
 
+// The same check with the m - 1 rounds of a point split over S threads.  The running minimum t_j(k) is a prefix
+// minimum over i < j, and min is exact, so a segment [a, b) of the rounds can be checked on its own once the minimum
+// P over all rounds before `a` is known: t >= r  <=>  P >= r and (local running minimum) >= r.  Pass 1: every
+// (point, segment) thread takes the minimum over its segment (no checks); pass 2: P = min of the earlier segments'
+// results (LDS), then the original loop over the segment starting from P.  Twice the distances, 1 / S of the
+// dependent chain: 1024 rounds x 6 instructions were 87 us at the end of the geometry chain.
+template <int S>
+__global__ __launch_bounds__(256) void fps_prefix_check_seg_kernel(FpsChain ch,
+                                                                   const float *__restrict__ dataset_all,
+                                                                   const float *__restrict__ r_all,
+                                                                   int *__restrict__ ok_all) {
+  constexpr int PTS = 256 / S;
+  extern __shared__ float s_prefix[];  // x,y,z,r of the first m points, then S * PTS segment minima
+  const int level = blockIdx.z, n = ch.n[level], m = ch.m[level], L = ch.L[level], nb = gridDim.y;
+  if ((int)(blockIdx.x * PTS) >= n) return;
+  float *s_min = s_prefix + 4 * (size_t)ch.m[0];
+  const float *dataset = dataset_all + (size_t)blockIdx.y * ch.stride * 3;
+  const float *r = r_all + (size_t)blockIdx.y * ch.stride;
+  for (int i = threadIdx.x; i < m; i += 256) {
+    s_prefix[4 * i + 0] = dataset[3 * i + 0];
+    s_prefix[4 * i + 1] = dataset[3 * i + 1];
+    s_prefix[4 * i + 2] = dataset[3 * i + 2];
+    s_prefix[4 * i + 3] = r[i];
+  }
+  const int seg = threadIdx.x / PTS, kl = threadIdx.x % PTS;
+  const int k_raw = blockIdx.x * PTS + kl;
+  const bool valid = k_raw < n;
+  const int k = valid ? k_raw : n - 1;
+  const int len = m - 1;                                   // rounds i = 0 .. m - 2 (round j = i + 1)
+  const int seglen = (len + S - 1) / S;
+  const int a = min(seg * seglen, len), b = min(a + seglen, len);
+  const unsigned bsmask = (1u << L) - 1u;
+  const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+  const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+  const float t0 = ((double)mag <= 1e-3) ? -1.f : 1e10f;
+  __syncthreads();
+  constexpr int U = 8;
+  {  // pass 1: the minimum over my segment
+    float mn = 3.0e38f;
+    int i = a;
+    for (; i + U <= b; i += U) {
+      float4 p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = *reinterpret_cast<const float4 *>(&s_prefix[4 * (i + u)]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) mn = fminf(sq_dist3(x, y, z, p[u].x, p[u].y, p[u].z), mn);
+    }
+    for (; i < b; ++i) {
+      const float4 p = *reinterpret_cast<const float4 *>(&s_prefix[4 * i]);
+      mn = fminf(sq_dist3(x, y, z, p.x, p.y, p.z), mn);
+    }
+    s_min[seg * PTS + kl] = mn;
+  }
+  __syncthreads();
+  float t = t0;
+  for (int e = 0; e < seg; ++e) t = fminf(s_min[e * PTS + kl], t);
+  const unsigned mykey = fps_key((unsigned)k, L, bsmask);
+  bool bad = false;
+  int i = a;
+  for (; i + U <= b; i += U) {
+    float4 p[U];
+    float rj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      p[u] = *reinterpret_cast<const float4 *>(&s_prefix[4 * (i + u)]);
+      rj[u] = s_prefix[4 * (i + u + 1) + 3];  // round j = i + u + 1 must pick point j
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t = fminf(sq_dist3(x, y, z, p[u].x, p[u].y, p[u].z), t);
+      if (t >= rj[u] && k != i + u + 1)
+        bad |= (t > rj[u]) || mykey < fps_key((unsigned)(i + u + 1), L, bsmask);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad && valid) != 0) break;   // (no barrier follows: leaving early is safe)
+  }
+  for (; i < b && !bad; ++i) {
+    const float4 p = *reinterpret_cast<const float4 *>(&s_prefix[4 * i]);
+    t = fminf(sq_dist3(x, y, z, p.x, p.y, p.z), t);
+    const float rj = s_prefix[4 * (i + 1) + 3];
+    if (t >= rj && k != i + 1) bad |= (t > rj) || mykey < fps_key((unsigned)(i + 1), L, bsmask);
+  }
+  if (bad && valid)
+    for (int l = level; l < ch.levels; ++l) ok_all[l * nb + blockIdx.y] = 0;
+}
+
 // ---- cooperative FPS: one scene spread over W workgroups ------------------------------------
 // A 40 000-point scene does not fit the register file of ONE workgroup (16 waves x 128 VGPRs
 // hold ~24 points per thread), and a global-memory overflow tail costs ~5 us per round.  Here W
@@ -527,6 +612,21 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
   return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
 }
 
+// the segmented check from 256 rounds (8 threads per point); below, the plain one (SIG3D_FPS_CHECK_SEG=0: always)
+static void launch_prefix_check(const FpsChain &ch, int b, const float *dataset, const float *r, int *flags,
+                                hipStream_t stream) {
+  const char *e = getenv("SIG3D_FPS_CHECK_SEG");
+  const bool seg = ch.m[0] >= 256 && ch.m[0] <= 4000 && !(e && atoi(e) == 0);   // <= 64 KB of LDS
+  if (seg) {
+    constexpr int S = 8;
+    hipLaunchKernelGGL(fps_prefix_check_seg_kernel<S>, dim3(sig3d_ceil_div(ch.n[0], 256 / S), b, ch.levels), dim3(256),
+                       sizeof(float) * (4 * (size_t)ch.m[0] + 256), stream, ch, dataset, r, flags);
+  } else {
+    hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(ch.n[0], 256), b, ch.levels), dim3(256),
+                       sizeof(float) * 4 * (size_t)ch.m[0], stream, ch, dataset, r, flags);
+  }
+}
+
 static int launch_fps_flagged(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
                               hipStream_t stream, const int *flags) {
   if (n <= 256) return launch_fps<256, 1>(b, n, m, L, dataset, temp, idxs, stream, flags);
@@ -558,8 +658,7 @@ extern "C" int sig3d_furthest_point_sampling_nested(int b, int n, int m, const f
   hipLaunchKernelGGL(fps_prefix_radius_kernel, dim3(sig3d_ceil_div(m, 4), b), dim3(256), 0, stream,
                      n, m, 1, dataset, temp, flags);
   SIG3D_LAUNCH_CHECK("fps_prefix_radius_kernel");
-  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n, 256), b, 1), dim3(256),
-                     sizeof(float) * 4 * (size_t)m, stream, ch, dataset, temp, flags);
+  launch_prefix_check(ch, b, dataset, temp, flags, stream);
   SIG3D_LAUNCH_CHECK("fps_prefix_check_kernel");
   return launch_fps_flagged(b, n, m, L, dataset, temp, idxs, stream, flags);
 }
@@ -587,8 +686,7 @@ extern "C" int sig3d_fps_nested_chain(int b, int n0, int nlevels, const int *m, 
   hipLaunchKernelGGL(fps_prefix_radius_kernel, dim3(sig3d_ceil_div(m[0], 4), b), dim3(256), 0, stream,
                      n0, m[0], nlevels, dataset, temp, flags);
   SIG3D_LAUNCH_CHECK("fps_prefix_radius_kernel");
-  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3(sig3d_ceil_div(n0, 256), b, nlevels), dim3(256),
-                     sizeof(float) * 4 * (size_t)m[0], stream, ch, dataset, temp, flags);
+  launch_prefix_check(ch, b, dataset, temp, flags, stream);
   SIG3D_LAUNCH_CHECK("fps_prefix_check_kernel");
   const float *cur = dataset;
   for (int l = 0; l < nlevels; ++l) {
