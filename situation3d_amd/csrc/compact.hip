@@ -96,15 +96,25 @@ __global__ __launch_bounds__(CP_THREADS) void compact_lists_wave_kernel(
   int *seg = seg_all + (size_t)bi * (m + 1);
   const int sub = lane / NS, s_in = lane % NS;  // which row of the trip, which entry of the row
   const unsigned long long rowmask = (NS == 64 ? ~0ull : ((1ull << NS) - 1ull)) << (sub * NS);
-  // pass 1: distinct count per row
-  for (int j0 = wave * RPW; j0 < m; j0 += NWAVES * RPW) {
-    const int j = j0 + sub;
-    const bool live = j < m;
-    const int a = live ? idx[(size_t)j * NS + s_in] : 0;
-    const int first = __shfl(a, sub * NS, 64);
-    const bool keep = live && (s_in == 0 || a != first);
-    const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
-    if (live && s_in == 0) s_cnt[j] = __builtin_popcountll(bits);
+  // pass 1: distinct count per row.  UNR trips per iteration with all their loads issued first (clamped row, masked
+  // afterwards): a trip is one dependent global round trip, 128 of them in a row were the kernel's whole time
+  constexpr int UNR = 4;
+  for (int j0 = wave * RPW; j0 < m; j0 += UNR * NWAVES * RPW) {
+    int a[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = min(j0 + u * NWAVES * RPW + sub, m - 1);
+      a[u] = idx[(size_t)j * NS + s_in];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * NWAVES * RPW + sub;
+      const bool live = j < m;
+      const int first = __shfl(a[u], sub * NS, 64);
+      const bool keep = live && (s_in == 0 || a[u] != first);
+      const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
+      if (live && s_in == 0) s_cnt[j] = __builtin_popcountll(bits);
+    }
   }
   __syncthreads();
   // exclusive scan of s_cnt[0..m): thread t owns a contiguous run of rows
@@ -134,19 +144,27 @@ __global__ __launch_bounds__(CP_THREADS) void compact_lists_wave_kernel(
   }
   __syncthreads();
   // pass 2: emit
-  for (int j0 = wave * RPW; j0 < m; j0 += NWAVES * RPW) {
-    const int j = j0 + sub;
-    const bool live = j < m;
-    const int a = live ? idx[(size_t)j * NS + s_in] : 0;
-    const int first = __shfl(a, sub * NS, 64);
-    const bool keep = live && (s_in == 0 || a != first);
-    const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
-    if (keep) {
-      const int pos = s_cnt[j] + __builtin_popcountll(bits & ((1ull << lane) - 1ull));
-      cidx[pos] = a;
-      ccent[pos] = j;
-      // the first hit also stands for the padding
-      mult[pos] = s_in == 0 ? (float)(NS - __builtin_popcountll(bits) + 1) : 1.f;
+  for (int j0 = wave * RPW; j0 < m; j0 += UNR * NWAVES * RPW) {
+    int a[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = min(j0 + u * NWAVES * RPW + sub, m - 1);
+      a[u] = idx[(size_t)j * NS + s_in];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int j = j0 + u * NWAVES * RPW + sub;
+      const bool live = j < m;
+      const int first = __shfl(a[u], sub * NS, 64);
+      const bool keep = live && (s_in == 0 || a[u] != first);
+      const unsigned long long bits = __builtin_amdgcn_ballot_w64(keep) & rowmask;
+      if (keep) {
+        const int pos = s_cnt[j] + __builtin_popcountll(bits & ((1ull << lane) - 1ull));
+        cidx[pos] = a[u];
+        ccent[pos] = j;
+        // the first hit also stands for the padding
+        mult[pos] = s_in == 0 ? (float)(NS - __builtin_popcountll(bits) + 1) : 1.f;
+      }
     }
   }
 }
