@@ -466,7 +466,7 @@ def test_graphed_forward_with_prefetched_geometry_matches_inline():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("depth", [1, 2, 3, 4])
 def test_pipelined_forward_with_several_geometry_chains_in_flight_matches_inline(depth):
     """serve.PipelinedForward: the geometry chains of the next `depth` batches run on their own streams / graphs
     while the forward of the current batch replays; outputs equal the inline eval forward bit for bit, through the
@@ -498,7 +498,10 @@ def test_pipelined_forward_with_several_geometry_chains_in_flight_matches_inline
             out = pipe(batches[i], [batches[c] for c in coming])
             assert torch.equal(out["answer_scores"], refs[i]), (depth, k, i)
     torch.cuda.synchronize()
-    assert _lib.fps_timeouts() == 0
+    assert _lib.fps_timeouts() == 0 and not pipe.handshake_timed_out()
+    # one consumer + `depth` chains on the four hardware queues of a priority: the fifth stream shares a queue
+    # (served in order with another one: slower, never wrong)
+    assert pipe._pipe.shared_queues == (1 if depth == 4 else 0)
 
 
 def test_prefetched_geometry_is_never_reused_for_a_refilled_buffer():
