@@ -510,6 +510,37 @@ typedef struct sig3d_gemm_problem {
 } sig3d_gemm_problem;
 int sig3d_gemm_group(int nprob, const sig3d_gemm_problem *problems, void *stream);
 
+/* Round 4: the exact-f32 MFMA GEMM the step RUNS on (csrc/gemm16_core.h; sig3d_gemm above is round 2's family,
+ * kept as a tested entry point).  Replaces the rocBLAS / hipBLASLt launches behind
+ *   Qformer.py:116-118 (query / key / value: x W^T + b), :238 and :320 (the dense halves of BertSelfOutput /
+ *   BertOutput), :305-313 (BertIntermediate: dense + erf-GELU) and the input-gradient products dX = dY W of
+ *   their backward passes (torch: F.linear / addmm / bmm / mm).
+ * For every batch element i < batch (operands advance by their stride_* elements):
+ *     C (m x n, row stride ldc)  =  A (m x k, rows k-contiguous) * B  [+ bias]  [epilogue]  [+ addend]
+ * bmode 0: B(l,j) = B[j*ldb + l] -- an nn.Linear weight in the forward product (rows k-contiguous);
+ * bmode 1: B(l,j) = B[l*ldb + j] -- the same weight in the input-gradient product (rows n-contiguous).
+ * bias   : (n) per column, or NULL.       addend : same layout as C, or NULL; may BE C (the residual path's gradient).
+ * act    : 0 none;  1 C = gelu_erf(acc + bias), aux (layout of C, may be NULL) receives acc + bias;
+ *          2 C = (acc + bias) * gelu_erf'(aux)  (BertIntermediate backward).
+ * splits : s >= 1 workgroups share the reduction of a tile; split 0 writes C (with bias / addend), split z >= 1
+ *          writes C_slabs + (z-1)*slab_stride (+ i*stride_c, row stride ldc) and the CONSUMER adds the slabs while
+ *          it loads them (sig3d_dropout_add_ln_fwd_slabs / _bwd_slabs): no atomics, no zero fill, no fold launch.
+ *          act != 0 requires splits == 1.  sig3d_gemm16_splits proposes the count measured best on MI355X.
+ * config : 0 = choose; 1 = 64x64 workgroup tiles (8 waves), 2 = 32x64 (4 waves), 3 = 64x128 (8 waves).
+ * k % 4 == 0, 16-byte aligned operand rows (n % 4 == 0 for bmode 1); every operand below 2 GB per batch element. */
+typedef struct sig3d_gemm16_problem {
+  const float *A; int lda; long stride_a;
+  const float *B; int ldb; long stride_b;
+  float *C; int ldc; long stride_c;
+  float *C_slabs; long slab_stride;
+  const float *bias; long stride_bias;
+  const float *addend;
+  float *aux;
+  int bmode, batch, m, n, k, act, splits, config;
+} sig3d_gemm16_problem;
+int sig3d_gemm16(const sig3d_gemm16_problem *problem, void *stream);
+int sig3d_gemm16_splits(int bmode, int batch, int m, int n, int k, int act, int config);
+
 /* ---- Q-Former attention ---------------------------------------------------------------- */
 
 /* replaces BertSelfAttention.forward's core

@@ -143,6 +143,40 @@ def gemm_group(device, *problems):
     with torch.cuda.device(device):
         call("sig3d_gemm_group", len(problems), arr, stream_ptr(device))
 
+class Gemm16Problem(ctypes.Structure):
+    """struct sig3d_gemm16_problem of include/sig3d_hip.h (field order and types must match)."""
+    _fields_ = [("A", _P), ("lda", _I), ("stride_a", ctypes.c_long),
+                ("B", _P), ("ldb", _I), ("stride_b", ctypes.c_long),
+                ("C", _P), ("ldc", _I), ("stride_c", ctypes.c_long),
+                ("C_slabs", _P), ("slab_stride", ctypes.c_long),
+                ("bias", _P), ("stride_bias", ctypes.c_long),
+                ("addend", _P), ("aux", _P),
+                ("bmode", _I), ("batch", _I), ("m", _I), ("n", _I), ("k", _I), ("act", _I), ("splits", _I),
+                ("config", _I)]
+
+
+SIGNATURES["sig3d_gemm16"] = [ctypes.POINTER(Gemm16Problem), _P]
+SIGNATURES["sig3d_gemm16_splits"] = [_I, _I, _I, _I, _I, _I, _I]
+
+
+def gemm16_splits(bmode, batch, m, n, k, act=0, config=0):
+    """The split count sig3d_gemm16 is fastest with on MI355X (a RETURN VALUE, not a status)."""
+    return int(load().sig3d_gemm16_splits(bmode, batch, m, n, k, act, config))
+
+
+def gemm16(device, **kw):
+    """C = A B (+ bias) (epilogue) (+ addend) through sig3d_gemm16; tensors or raw pointers for the pointer fields."""
+    p = Gemm16Problem()
+    vals = dict(A=None, lda=0, stride_a=0, B=None, ldb=0, stride_b=0, C=None, ldc=0, stride_c=0, C_slabs=None,
+                slab_stride=0, bias=None, stride_bias=0, addend=None, aux=None, bmode=0, batch=1, m=0, n=0, k=0, act=0,
+                splits=1, config=0)
+    vals.update(kw)
+    for name, v in vals.items():
+        setattr(p, name, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    with torch.cuda.device(device):
+        call("sig3d_gemm16", ctypes.byref(p), stream_ptr(device))
+
+
 class BqLevel(ctypes.Structure):
     """sig3d_bq_level of include/sig3d_hip.h: one ball-query problem of a multi-level launch."""
     _fields_ = [("n", _I), ("m", _I), ("nsample", _I), ("radius", _F), ("xyz", _P), ("new_xyz", _P), ("idx", _P)]

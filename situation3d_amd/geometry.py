@@ -103,14 +103,14 @@ class GeometryPlan:
                               _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]),
                               _lib.ptr(self.fps_proven[lvl]), s)
                 timeline.mark("geo:L%d fps" % (lvl + 1))
-                if lvl == 0 and os.environ.get("SIG3D_PROBE_FPS_ONLY") == "1" and torch.cuda.is_current_stream_capturing():
-                    return self     # probe (tools/ab_step.py): what the FPS kernel alone costs the step beside it
+                if lvl == 0 and self._stop_after("fps0"):
+                    return self
                 _lib.call("sig3d_gather_xyz", b, n, npoint, _lib.ptr(cur), _lib.ptr(self.inds[lvl]),
                           _lib.ptr(self.new_xyz[lvl]), s)
                 srcs.append(cur)
                 cur, n = self.new_xyz[lvl], npoint
-            if os.environ.get("SIG3D_PROBE_CHAIN_UNTIL") == "sampling" and torch.cuda.is_current_stream_capturing():
-                return self     # probe: FPS + proofs + centre gathers of all levels
+            if self._stop_after("sampling"):
+                return self
             # the neighbour lists of ALL levels depend on coordinates only: one scatter + one rank launch
             # (csrc/ball_query.hip: centres binned into cells, points streamed once) instead of a chain per level
             ptrs = [t.data_ptr() for t in srcs]
@@ -126,14 +126,21 @@ class GeometryPlan:
             # after one completed call the workspace's counters are zero again (the rank kernel cleans up): no memset
             _lib.call("sig3d_ball_query_levels_ex", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
                       self._bq_work.numel(), _lib.BQ_CLEAN if self._bq_clean else 0, s)
-            self._bq_clean = True
-            if os.environ.get("SIG3D_PROBE_CHAIN_UNTIL") == "ballquery" and torch.cuda.is_current_stream_capturing():
-                return self     # probe: ... + the ball queries (no distinct-neighbour lists)
+            # the flag describes the workspace as the DEVICE will find it at the next call: only a call that was
+            # really issued (not one recorded into a graph that may never be replayed) leaves the counters zero
+            self._bq_clean = not torch.cuda.is_current_stream_capturing()
+            if self._stop_after("ballquery"):
+                return self
             for lvl in range(len(self.levels)):
                 if self.compact[lvl] is not None:
                     self.compact[lvl].compute(self.ball_idx[lvl])
             timeline.mark("geo:lists")
         return self
+
+    def _stop_after(self, stage):
+        """Measurement hook: tools/probes/geo_probes.py replaces this to cut a captured chain short after `stage`
+        ("fps0", "sampling", "ballquery").  The product never stops early and reads no environment variable here."""
+        return False
 
     def _nested_chain(self, b):
         """ctypes tables of sig3d_fps_nested_chain for levels 1.. (None when the chain's size limits do not hold)."""
@@ -168,7 +175,13 @@ class GeometryPlan:
         self._table_copy(pairs)
 
 
-_HANDSHAKE_TIMEOUT_US = 30 * 1000 * 1000   # sig3d_ticket_wait gives up (and raises its error word) after this long
+# sig3d_ticket_wait gives up (and raises its error word) after this long.  A chain that gave up runs on coordinates
+# that may not be staged yet, so the timeout is NOT a recovery path: it only keeps a crashed producer from hanging
+# the device, and GeometryPipeline.advance() raises as soon as it sees the error word (a captured device-to-host copy
+# at the end of every chain keeps a pinned host mirror of it current: no synchronisation).  The default is longer than
+# any stall a healthy run produces (a straggler rank inside an all-reduce, a checkpoint written by rank 0) and longer
+# than the process-group watchdog's 10 minutes.
+_HANDSHAKE_TIMEOUT_US = int(float(os.environ.get("SIG3D_HANDSHAKE_TIMEOUT_S", "1200")) * 1e6)
 
 
 class GeometryPipeline:
@@ -201,8 +214,8 @@ class GeometryPipeline:
         # but degenerate: every ball holds the same 64 points)
         example = (example_xyz.detach().to(device=device, dtype=torch.float32).contiguous() if example_xyz is not None
                    else torch.zeros(batch, n_points, 3, dtype=torch.float32, device=device))
-        self._probe_sink = torch.zeros(16, dtype=torch.float32, device=device)
-        self._probe_skip = os.environ.get("SIG3D_PROBE_SKIP_CHAIN") in ("1", "2")   # tools/ab_step.py: what the chain costs the step
+        # host mirror of the slots' error words (pinned: the copy at the end of a chain is an asynchronous graph node)
+        self._host_err = torch.zeros(self.depth, dtype=torch.int32).pin_memory()
         # HIP multiplexes streams onto 4 hardware queues per priority, and which queue a new stream gets is not under
         # the caller's control (tools/probes/queue_map_probe.py: two fresh streams share one in ~1 of 4 cases).  A
         # chain on the consumer's queue is simply served in order with it (step 8.1 -> 11.8 ms): every slot stream is
@@ -234,16 +247,20 @@ class GeometryPipeline:
                 if self.handshake:
                     _lib.call("sig3d_ticket_wait", _lib.ptr(w[0:1]), _lib.ptr(w[1:2]), _HANDSHAKE_TIMEOUT_US,
                               _lib.ptr(w[2:3]), _lib.stream_ptr(self.device))
-                spin = os.environ.get("SIG3D_PROBE_SPIN_US")   # probe: one idle thread instead of the chain
-                if spin:
-                    blocks, threads, vg, lds = [int(x) for x in os.environ.get("SIG3D_PROBE_SPIN_SHAPE", "1,64,0,4").split(",")]
-                    if not hasattr(self, "_probe_sink"):
-                        raise RuntimeError("probe sink missing")
-                    _lib.call("sig3d_hold", _lib.ptr(self._probe_sink), blocks, threads, int(spin), vg, lds,
-                              _lib.stream_ptr(self.device))
-                else:
-                    slot["plan"].compute(slot["xyz"])
+                self._slot_body(slot)
+                if self.handshake:
+                    k = self.slots.index(slot)
+                    self._host_err[k:k + 1].copy_(w[2:3], non_blocking=True)
             self.stream.wait_stream(slot["stream"])
+
+    def _slot_body(self, slot):
+        """What a slot's graph runs behind its ticket wait: the chain.  (tools/probes/geo_probes.py swaps in idle
+        kernels or nothing to measure what the chain costs the step beside it; the product never does.)"""
+        slot["plan"].compute(slot["xyz"])
+
+    def _skip_chain(self, point_clouds):
+        """Measurement hook (tools/probes/geo_probes.py); the product always runs its chains."""
+        return False
 
     def advance(self, point_clouds, upcoming, token=None, upcoming_tokens=None):
         """`point_clouds`: (B,N,3+C) of the batch the consumer is about to run; `upcoming`: those of the next `depth`
@@ -253,15 +270,14 @@ class GeometryPipeline:
             raise ValueError("a geometry pipeline of depth %d needs the next %d batches" % (self.depth, self.depth))
         toks = list(upcoming_tokens) if upcoming_tokens is not None else [None] * self.depth
         slot = self.slots[self.calls % self.depth]
-        if os.environ.get("SIG3D_PROBE_SKIP_CHAIN") == "2":
-            # probe: no chain at all, yet every batch gets ITS plan (computed once per distinct batch tensor, cached) --
-            # the step alone over correct geometry, the number the chain's cost is measured against
-            cache = self.__dict__.setdefault("_probe_plans", {})
-            key = id(point_clouds)
-            if key not in cache:
-                plan = GeometryPlan(self.plan_cur.batch, self.plan_cur.n_points, self.plan_cur.levels, self.device)
-                cache[key] = (plan.compute(point_clouds[..., :3].contiguous()), point_clouds)
-            self.plan_cur.copy_from(cache[key][0])
+        if self._host_err.any():
+            raise RuntimeError(
+                "geometry pipeline: a chain gave up waiting for its ticket after %.0f s (slot error words %s): the "
+                "consumer's stream was stalled for that long, and the plan of at least one batch since then was "
+                "computed from coordinates that were not staged yet.  Steps taken since are not trustworthy; restart "
+                "from the last checkpoint (SIG3D_HANDSHAKE_TIMEOUT_S raises the limit, SIG3D_GEO_HANDSHAKE=0 orders "
+                "the chains with stream waits instead)." % (_HANDSHAKE_TIMEOUT_US / 1e6, self._host_err.tolist()))
+        if self._skip_chain(point_clouds):
             self.calls += 1
             return
         self.stream.wait_stream(slot["stream"])              # the chain launched `depth` calls ago (any chain: its
@@ -273,19 +289,16 @@ class GeometryPipeline:
         far = upcoming[-1]
         slot["xyz"].copy_(far[..., :3], non_blocking=True)
         slot["announced"].set(far, toks[-1])
-        if self._probe_skip:
-            pass
-        elif self.handshake:                                 # coordinates staged, plan handed over: the slot may start
+        if self.handshake:                                   # coordinates staged, plan handed over: the slot may start
             with torch.cuda.device(self.device):
                 _lib.call("sig3d_ticket_signal", _lib.ptr(slot["words"][0:1]), self.stream.cuda_stream)
         else:
             slot["stream"].wait_stream(self.stream)
-        if not self._probe_skip:
-            with torch.cuda.stream(slot["stream"]):
-                slot["graph"].replay()
+        with torch.cuda.stream(slot["stream"]):
+            slot["graph"].replay()
         self.calls += 1
 
     def timed_out(self):
         """True when a chain ever gave up waiting for its ticket (it then ran anyway: a plan may be stale).
-        Synchronises; meant for the end of a run or a logging interval."""
+        Synchronises; advance() checks the pinned host mirror of the same words on every call without synchronising."""
         return bool(self._words.view(self.depth, 4)[:, 2].any().item())

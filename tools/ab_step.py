@@ -15,6 +15,10 @@ from situation3d_amd import gemm_tuning  # noqa: E402
 from situation3d_amd.graph_step import GraphedTrainStep  # noqa: E402
 from situation3d_amd.model import SIG3DQFormer  # noqa: E402
 from situation3d_amd.trainer import build_optimizer  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import geo_probes  # noqa: E402
+
+geo_probes.install()      # SIG3D_PROBE_* switches live in tools/, not in the product (bench.py refuses them)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("switch", help="module.ATTRIBUTE, e.g. situation3d_amd.qformer.FUSED_EMBED")
