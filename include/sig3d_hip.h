@@ -367,6 +367,22 @@ int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, int live_rows, f
                              const unsigned short *mask, float *dx, float *dres, float *dparams,
                              float *workspace, void *stream);
 
+/* The same tails behind a SPLIT dense layer (sig3d_gemm16 with splits > 1): x (dy in the backward) is the sum of
+ * slab 0 -- the x / dy argument -- and extra_slabs further (rows, cols) matrices at x_slabs + z*slab_stride, added
+ * while they are loaded (no fold launch, no atomics in the GEMM).  Backward: only rows below slab_rows have slabs
+ * (slab_rows <= 0: all rows), the others take dy alone -- the padding / pass-through rows a GEMM over the live rows
+ * never wrote. */
+int sig3d_dropout_add_ln_fwd_slabs(int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
+                                   const unsigned *rng_counter, const float *x, const float *x_slabs, int extra_slabs,
+                                   long slab_stride, const float *bias, const float *res, const float *gamma,
+                                   const float *beta, float eps, float *out, float *v, float *mean, float *rstd,
+                                   unsigned short *mask, void *stream);
+int sig3d_dropout_add_ln_bwd_slabs(int rows, int cols, int part_rows, int live_rows, float p_drop, const float *dy,
+                                   const float *dy_slabs, int extra_slabs, long slab_stride, int slab_rows,
+                                   const float *v, const float *mean, const float *rstd, const float *gamma,
+                                   const unsigned short *mask, float *dx, float *dres, float *dparams,
+                                   float *workspace, void *stream);
+
 /* The same fused tails with the MCAN blocks' own normalisation (situation3d/models/mcan_sqa_module.py:57-69:
  * a_2 * (x - mean) / (std + eps) + b_2 with the UNBIASED standard deviation and eps added to the std):
  * SA / SGA compute norm(x + dropout(sublayer(x))) (mcan_sqa_module.py:216-224, 249-261).  rstd receives

@@ -74,6 +74,10 @@ SIGNATURES = {
     "sig3d_dropout_add_ln_fwd": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                  _P, _P],
     "sig3d_dropout_add_ln_bwd": [_I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_dropout_add_ln_fwd_slabs": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _I, ctypes.c_long, _P, _P, _P, _P, _F,
+                                       _P, _P, _P, _P, _P, _P],
+    "sig3d_dropout_add_ln_bwd_slabs": [_I, _I, _I, _I, _F, _P, _P, _I, ctypes.c_long, _I, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _P, _P],
     "sig3d_dropout_add_mcan_norm_fwd": [_I, _I, _I, _I, _F, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,
                                  _P, _P],
     "sig3d_dropout_add_mcan_norm_bwd": [_I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

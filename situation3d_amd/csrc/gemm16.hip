@@ -11,10 +11,13 @@
 //   C  64 x 128,              8 waves of 32 x 32                      thousands of tiles
 // and the reduction is split (every split writes its own slab of C, gemm16_core.h) until ~256 (k <= 1024) or ~512
 // workgroups exist.
+#include <cstdlib>
 #include "gemm16_core.h"
 #include "sig3d_common.h"
 
 namespace {
+
+const int SIG3D_GEMM16_TARGET_WGS = getenv("SIG3D_GEMM16_TARGET_WGS") ? atoi(getenv("SIG3D_GEMM16_TARGET_WGS")) : 0;
 
 int tiles_of(const sig3d_gemm16_problem &q, int tm, int tn) {
   return q.batch * sig3d_ceil_div(q.m, tm) * sig3d_ceil_div(q.n, tn);
@@ -32,7 +35,10 @@ int choose_splits(const sig3d_gemm16_problem &q, int config) {
   if (q.act != 0 || config != 1) return 1;
   const int t64 = tiles_of(q, 64, 64);
   const int chunks = sig3d_ceil_div(q.k, gemm16::BK);
-  const int target = q.k <= 1024 ? 256 : 512;
+  // ~one workgroup per CU for short reductions, two for long ones (measured alone AND inside the training step:
+  // 256 / 384 everywhere cost the step +0.15 / +0.07 ms against this rule although every slab is re-read by the
+  // LayerNorm tail that consumes the product); SIG3D_GEMM16_TARGET_WGS overrides both
+  const int target = SIG3D_GEMM16_TARGET_WGS > 0 ? SIG3D_GEMM16_TARGET_WGS : (q.k <= 1024 ? 256 : 512);
   int s = (target + t64 / 2) / (t64 > 0 ? t64 : 1);
   if (s > chunks / 4) s = chunks / 4;
   if (s > 8) s = 8;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     float *__restrict__ out, float *__restrict__ v_out, float *__restrict__ mean_out,
     float *__restrict__ rstd_out, unsigned short *__restrict__ mask_out, int part_rows, int mcan, int live_rows,
-    int pad_copy) {
+    int pad_copy, const float *__restrict__ x_slabs, int extra_slabs, size_t slab_stride) {
   const int lane = lane_id();
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -106,6 +106,21 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     bb[i] = bias ? bias[cc] : 0.f;
     gam[i] = gamma[cc];
     bet[i] = beta[cc];
+  }
+  // x arrives as the slabs of a split reduction (sig3d_gemm16): they are added here, on the way in -- four slabs'
+  // loads in flight at a time (one slab per trip was one memory round trip per slab: 9 -> 24 us per call)
+  for (int z0 = 0; z0 < extra_slabs; z0 += 4) {
+    float t[4][PER_LANE];
+#pragma unroll
+    for (int zz = 0; zz < 4; ++zz) {
+      const float *xz = x_slabs + (size_t)min(z0 + zz, extra_slabs - 1) * slab_stride + (size_t)row * cols;
+#pragma unroll
+      for (int i = 0; i < PER_LANE; ++i) t[zz][i] = xz[min(lane + 64 * i, cols - 1)];
+    }
+#pragma unroll
+    for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+      for (int i = 0; i < PER_LANE; ++i) u[i] += (z0 + zz < extra_slabs) ? t[zz][i] : 0.f;
   }
   float sum = 0.f;
   unsigned keep_bits = 0;
@@ -146,7 +161,8 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float *__restrict__ v, const float *__restrict__ mean, const float *__restrict__ rstd,
     const float *__restrict__ gamma, const unsigned short *__restrict__ mask,
     float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ partial, int part_rows,
-    int mcan, float eps, int live_rows, int pad_copy) {
+    int mcan, float eps, int live_rows, int pad_copy, const float *__restrict__ dy_slabs, int extra_slabs,
+    size_t slab_stride, int slab_rows) {
   // partial: (gridDim.x, 3*cols) = per-workgroup [d gamma | d beta | d bias] column sums
   __shared__ float part[3][3][64 * PER_LANE];  // waves 1..3 park their sums here
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -167,8 +183,12 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                              // to the GEMM output (v, dx end earlier)
 #pragma unroll
       for (int i = 0; i < PER_LANE; ++i)
-        if (lane + 64 * i < cols)
-          dres[(size_t)row * cols + lane + 64 * i] = pad_copy ? dy[(size_t)row * cols + lane + 64 * i] : 0.f;
+        if (lane + 64 * i < cols) {
+          float d = pad_copy ? dy[(size_t)row * cols + lane + 64 * i] : 0.f;
+          if (pad_copy && row < slab_rows)
+            for (int z = 0; z < extra_slabs; ++z) d += dy_slabs[z * slab_stride + (size_t)row * cols + lane + 64 * i];
+          dres[(size_t)row * cols + lane + 64 * i] = d;
+        }
       continue;
     }
     const float mu = mean[row], rs = rstd[row];
@@ -181,6 +201,21 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
       g[i] = dyr[cc];
       xh[i] = vr[cc];
     }
+    // dy arrives as the slabs of a split reduction (rows below slab_rows): added on the way in
+    if (row < slab_rows)
+      for (int z0 = 0; z0 < extra_slabs; z0 += 4) {   // four slabs' loads in flight at a time
+        float t[4][PER_LANE];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz) {
+          const float *dz = dy_slabs + (size_t)min(z0 + zz, extra_slabs - 1) * slab_stride + (size_t)row * cols;
+#pragma unroll
+          for (int i = 0; i < PER_LANE; ++i) t[zz][i] = dz[min(lane + 64 * i, cols - 1)];
+        }
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+          for (int i = 0; i < PER_LANE; ++i) g[i] += (z0 + zz < extra_slabs) ? t[zz][i] : 0.f;
+      }
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < PER_LANE; ++i) {
@@ -282,8 +317,10 @@ extern "C" int sig3d_counter_increment(unsigned *counter, void *stream_) {
 static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, int live_rows, int pad_copy, float p_drop, unsigned call_id,
                        const unsigned *rng_counter, const float *x, const float *bias, const float *res,
                        const float *gamma, const float *beta, float eps, float *out, float *v, float *mean,
-                       float *rstd, unsigned short *mask, void *stream_) {
+                       float *rstd, unsigned short *mask, void *stream_, const float *x_slabs = nullptr,
+                       int extra_slabs = 0, long slab_stride = 0) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(extra_slabs >= 0 && (extra_slabs == 0 || x_slabs != nullptr), "slab count without slabs");
   SIG3D_REQUIRE(!mcan || cols >= 2, "the unbiased standard deviation needs at least two columns");
   SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
   SIG3D_REQUIRE((long)rows * cols < (1L << 32), "rows*cols must fit 32 bits (dropout hash index)");
@@ -296,11 +333,11 @@ static int ln_tail_fwd(int mcan, int rows, int cols, int part_rows, int live_row
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<12>, grid, dim3(256), 0, stream, rows, cols, p_drop,
                        call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask,
-                       part_rows, mcan, live_rows, pad_copy);
+                       part_rows, mcan, live_rows, pad_copy, x_slabs, extra_slabs, (size_t)slab_stride);
   else
     hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<LN_MAX_PER_LANE>, grid, dim3(256), 0, stream, rows, cols,
                        p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd,
-                       mask, part_rows, mcan, live_rows, pad_copy);
+                       mask, part_rows, mcan, live_rows, pad_copy, x_slabs, extra_slabs, (size_t)slab_stride);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_fwd_kernel");
   return 0;
 }
@@ -313,6 +350,17 @@ extern "C" int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, int l
                                         void *stream_) {
   return ln_tail_fwd(0, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, call_id, rng_counter, x, bias, res, gamma, beta, eps, out, v,
                      mean, rstd, mask, stream_);
+}
+
+extern "C" int sig3d_dropout_add_ln_fwd_slabs(int rows, int cols, int part_rows, int live_rows, float p_drop,
+                                              unsigned call_id, const unsigned *rng_counter, const float *x,
+                                              const float *x_slabs, int extra_slabs, long slab_stride,
+                                              const float *bias, const float *res, const float *gamma,
+                                              const float *beta, float eps, float *out, float *v, float *mean,
+                                              float *rstd, unsigned short *mask, void *stream_) {
+  return ln_tail_fwd(0, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, call_id,
+                     rng_counter, x, bias, res, gamma, beta, eps, out, v, mean, rstd, mask, stream_, x_slabs, extra_slabs,
+                     slab_stride);
 }
 
 extern "C" int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows, int live_rows, float p_drop, unsigned call_id,
@@ -328,8 +376,10 @@ extern "C" int sig3d_dropout_add_mcan_norm_fwd(int rows, int cols, int part_rows
 static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, int live_rows, int pad_copy, float p_drop, const float *dy,
                        const float *v, const float *mean, const float *rstd, const float *gamma,
                        const unsigned short *mask, float *dx, float *dres, float *dparams, float *workspace,
-                       void *stream_) {
+                       void *stream_, const float *dy_slabs = nullptr, int extra_slabs = 0, long slab_stride = 0,
+                       int slab_rows = 0) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(extra_slabs >= 0 && (extra_slabs == 0 || dy_slabs != nullptr), "slab count without slabs");
   SIG3D_REQUIRE(rows >= 0 && cols >= 1 && cols <= 64 * LN_MAX_PER_LANE, "hidden size must be <= 1024");
   SIG3D_REQUIRE(p_drop == 0.f || mask != nullptr, "the forward's mask buffer is required when p_drop > 0");
   if (rows == 0) {
@@ -350,11 +400,13 @@ static int ln_tail_bwd(int mcan, float eps, int rows, int cols, int part_rows, i
   const int blocks = sig3d_ceil_div(sig3d_ceil_div(rows, rpw), 4);
   if (cols <= 64 * 12)
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<12>, dim3(blocks), dim3(256), 0, stream, rows, cols, p_drop,
-                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan, eps, live_rows, pad_copy);
+                       rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan, eps, live_rows, pad_copy,
+                       dy_slabs, extra_slabs, (size_t)slab_stride, slab_rows <= 0 ? rows : slab_rows);
   else
     hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<LN_MAX_PER_LANE>, dim3(blocks), dim3(256), 0, stream, rows,
                        cols, p_drop, rpw, dy, v, mean, rstd, gamma, mask, dx, dres, workspace, part_rows, mcan,
-                       eps, live_rows, pad_copy);
+                       eps, live_rows, pad_copy, dy_slabs, extra_slabs, (size_t)slab_stride,
+                       slab_rows <= 0 ? rows : slab_rows);
   SIG3D_LAUNCH_CHECK("dropout_add_ln_bwd_kernel");
   // fold the per-workgroup partial rows, part by part: dparams is (parts, 3, cols).  dparams == NULL: the
   // caller folds the partial rows itself later (several tails in one sig3d_column_sum launch): the workspace
@@ -373,6 +425,17 @@ extern "C" int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, int l
                                         void *stream_) {
   return ln_tail_bwd(0, 0.f, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, dy, v, mean, rstd, gamma, mask, dx, dres, dparams,
                      workspace, stream_);
+}
+
+extern "C" int sig3d_dropout_add_ln_bwd_slabs(int rows, int cols, int part_rows, int live_rows, float p_drop,
+                                              const float *dy, const float *dy_slabs, int extra_slabs,
+                                              long slab_stride, int slab_rows, const float *v, const float *mean,
+                                              const float *rstd, const float *gamma, const unsigned short *mask,
+                                              float *dx, float *dres, float *dparams, float *workspace,
+                                              void *stream_) {
+  return ln_tail_bwd(0, 0.f, rows, cols, part_rows, live_rows < 0 ? -live_rows : live_rows, live_rows < 0, p_drop, dy, v,
+                     mean, rstd, gamma, mask, dx, dres, dparams, workspace, stream_, dy_slabs, extra_slabs, slab_stride,
+                     slab_rows);
 }
 
 extern "C" int sig3d_dropout_add_mcan_norm_bwd(int rows, int cols, int part_rows, int live_rows, float p_drop, float eps,

@@ -116,8 +116,55 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
+# SIG3D_QF_GEMM=1: the projections, the feed-forward pair and their input-gradient products on sig3d_gemm16
+# (csrc/gemm16_core.h) with bias / GELU / gelu' / residual-gradient epilogues and split reductions whose slabs the
+# LayerNorm tails add while loading.  Correct at every golden and full-size parity test, and level with rocBLAS's
+# default picks kernel by kernel (tools/micro/gemm16_bench.hip) -- but INSIDE the training step the tuned library
+# launches stay ahead (7.85-7.98 ms vs 8.18-8.28 per step, same box, alternating: DESIGN.md section 4f), so the default
+# is the vendor library (rocBLAS / hipBLASLt through torch) and this switch is the A/B.
+OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
+
+
+def _g16(dev, **kw):
+    _lib.gemm16(dev, **kw)
+
+
+def _dense_fwd(x2, w, bias, out=None, act=0, aux=None, split=False):
+    """x2 (M, K) or (batch, M, K) contiguous, w (N, K) or (batch, N, K) nn.Linear weights, bias (N) / (batch, N) / None
+    -> (out, slabs): out = x w^T (+ bias) (gelu; aux keeps the pre-activation), shaped like x2 with N columns.
+    split: the reduction may be split; `slabs` (S - 1, rows, N) are then to be ADDED to out by the consumer."""
+    batch = x2.shape[0] if x2.dim() == 3 else 1
+    m, k = x2.shape[-2], x2.shape[-1]
+    n = w.shape[-2]
+    dev = x2.device
+    if out is None:
+        out = torch.empty(x2.shape[:-1] + (n,), dtype=torch.float32, device=dev)
+    splits = _lib.gemm16_splits(0, batch, m, n, k, act) if split else 1
+    slabs = torch.empty((splits - 1, batch * m, n), dtype=torch.float32, device=dev) if splits > 1 else None
+    _g16(dev, A=x2, lda=k, stride_a=m * k, B=w, ldb=k, stride_b=n * k, C=out, ldc=n, stride_c=m * n, C_slabs=slabs,
+         slab_stride=batch * m * n, bias=bias, stride_bias=n, aux=aux, bmode=0, batch=batch, m=m, n=n, k=k, act=act,
+         splits=splits)
+    return out, slabs
+
+
+def _dense_dgrad(dy2, w, out=None, addend=None, act=0, aux=None, split=False):
+    """dy2 (M, K) or (batch, M, K) contiguous, w (K, N) or (batch, K, N): the nn.Linear weight whose OUTPUT index is
+    reduced over -> (out, slabs): out = dy w (* gelu'(aux)) (+ addend; addend may be out itself)."""
+    batch = dy2.shape[0] if dy2.dim() == 3 else 1
+    m, k = dy2.shape[-2], dy2.shape[-1]
+    n = w.shape[-1]
+    dev = dy2.device
+    if out is None:
+        out = torch.empty(dy2.shape[:-1] + (n,), dtype=torch.float32, device=dev)
+    splits = _lib.gemm16_splits(1, batch, m, n, k, act) if split else 1
+    slabs = torch.empty((splits - 1, batch * m, n), dtype=torch.float32, device=dev) if splits > 1 else None
+    _g16(dev, A=dy2, lda=k, stride_a=m * k, B=w, ldb=n, stride_b=n * k, C=out, ldc=n, stride_c=m * n, C_slabs=slabs,
+         slab_stride=batch * m * n, addend=addend, aux=aux, bmode=1, batch=batch, m=m, n=n, k=k, act=act, splits=splits)
+    return out, slabs
+
+
 def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, mcan=False, out=None,
-                 pass_through=False):
+                 pass_through=False, x_slabs=None):
     """sig3d_dropout_add_ln_fwd on contiguous (rows, cols) operands -> out, v, stats, mask.
     part_rows > 0: bias / gamma / beta are (parts, cols), one set per block of part_rows rows.
     mcan: the MCAN blocks' normalisation (unbiased std, eps on the std) instead of nn.LayerNorm's.
@@ -133,6 +180,15 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, m
     stats = torch.empty((2, rows), dtype=torch.float32, device=dev)
     mask = torch.empty((rows, 64), dtype=torch.int16, device=dev) if p_drop > 0 else None
     with torch.cuda.device(dev):
+        if x_slabs is not None:    # x2 is slab 0 of a split dense layer: the others are added on the way in
+            assert not mcan and x_slabs.shape[1:] == x2.shape
+            _lib.call("sig3d_dropout_add_ln_fwd_slabs", rows, cols, part_rows,
+                      -live if (pass_through and live < rows) else live, ctypes.c_float(p_drop),
+                      ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(x_slabs),
+                      x_slabs.shape[0], x_slabs.stride(0), _lib.ptr(bias), _lib.ptr(r2), _lib.ptr(gamma), _lib.ptr(beta),
+                      ctypes.c_float(eps), _lib.ptr(out), _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]),
+                      _lib.ptr(mask), _lib.stream_ptr(dev))
+            return out, v, stats, mask
         _lib.call("sig3d_dropout_add_mcan_norm_fwd" if mcan else "sig3d_dropout_add_ln_fwd", rows, cols, part_rows,
                   -live if (pass_through and live < rows) else live, ctypes.c_float(p_drop),
                   ctypes.c_uint(call_id), _lib.ptr(_rng_counter(dev)), _lib.ptr(x2), _lib.ptr(bias),
@@ -152,7 +208,7 @@ def _ln_bwd_blocks(rows, part_rows=0):
 
 
 def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None, dx_out=None, pass_through=False,
-                 work_out=None):
+                 work_out=None, dy_slabs=None, slab_rows=0):
     """sig3d_dropout_add_ln_bwd -> dx (grad of the GEMM output), dres (grad of the residual),
     dparams = [d gamma | d beta | d bias]  ((parts, 3, cols) when part_rows > 0).
     v may hold fewer rows than dy2 (see _ln_tail_fwd): dx has v's rows, dres has dy2's with zeros beyond."""
@@ -171,7 +227,11 @@ def _ln_tail_bwd(dy2, v, stats, gamma, mask, p_drop, part_rows=0, mcan_eps=None,
     tail = (_lib.ptr(dy2), _lib.ptr(v), _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(gamma), _lib.ptr(mask),
             _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dparams), _lib.ptr(work), _lib.stream_ptr(v.device))
     with torch.cuda.device(v.device):
-        if mcan_eps is None:
+        if dy_slabs is not None:   # dy2 is slab 0 of a split input-gradient product (rows < slab_rows have more)
+            assert mcan_eps is None and dy_slabs.shape[2] == cols
+            _lib.call("sig3d_dropout_add_ln_bwd_slabs", rows, cols, part_rows, live, ctypes.c_float(p_drop),
+                      _lib.ptr(dy2), _lib.ptr(dy_slabs), dy_slabs.shape[0], dy_slabs.stride(0), int(slab_rows), *tail[1:])
+        elif mcan_eps is None:
             _lib.call("sig3d_dropout_add_ln_bwd", rows, cols, part_rows, live, ctypes.c_float(p_drop), *tail)
         else:
             _lib.call("sig3d_dropout_add_mcan_norm_bwd", rows, cols, part_rows, live, ctypes.c_float(p_drop),
@@ -520,6 +580,18 @@ class _WeightGradArena:
         self._expected = 2 * NL + nc
         self._flushed_hi = NL           # layers >= this are flushed
         self.side_stream, self._forked = None, False
+        # Input-gradient products whose reduction is split hand their slabs from one block's backward to the next
+        # block's LayerNorm-tail backward, which adds them while loading (sig3d_dropout_add_ln_bwd_slabs).  The
+        # tensor autograd carries is slab 0; the others wait here under its address.  Only between blocks of THIS
+        # stack (the consumer is known to look here); whatever is left when the last block is done is an error.
+        self.slabs_ok = OWN_GEMM
+        self._slabs = {}
+
+    def put_slabs(self, grad, slabs, slab_rows):
+        self._slabs[grad.data_ptr()] = (slabs, slab_rows)
+
+    def take_slabs(self, grad):
+        return self._slabs.pop(grad.data_ptr(), (None, 0))
 
     # ---- bookkeeping -----------------------------------------------------------------------------------
     def mark(self, kind, layer):
@@ -528,6 +600,9 @@ class _WeightGradArena:
             raise RuntimeError("deferred weight gradients: a Q-Former block ran its backward twice "
                                "(retain_graph is not supported; set encoder.defer_weight_grads = False)")
         self._marks.add(key)
+        if len(self._marks) == self._expected and self._slabs:
+            raise RuntimeError("Q-Former backward: the slabs of a split input-gradient product were never added "
+                               "(their gradient did not reach the block below unchanged); set SIG3D_QF_GEMM=0")
         if len(self._marks) == self._expected:
             if self.shared:
                 # the products are ADDED to `.grad`, which autograd only completes after this backward call has
@@ -725,9 +800,13 @@ class _AttentionBlockFn(torch.autograd.Function):
         hd = wq.shape[0]
         d = hd // num_heads
         scale = 1.0 / math.sqrt(d)
+        own = OWN_GEMM
         if not cross:  # self-attention
             w_all = _stacked((wq, wk, wv))
-            proj = torch.addmm(_stacked((bq, bk, bv)), xl, w_all.t())     # (L, 3*hd)
+            if own:
+                proj, _ = _dense_fwd(xl, w_all, _stacked((bq, bk, bv)))   # (L, 3*hd)
+            else:
+                proj = torch.addmm(_stacked((bq, bk, bv)), xl, w_all.t())
             qp, kp, vp, ldq, ldk, ldv, nk = _off(proj, 0), _off(proj, hd), _off(proj, 2 * hd), 3 * hd, 3 * hd, 3 * hd, nq
             klay = (seg, base2, live)
             kvproj, e2 = None, None
@@ -758,12 +837,15 @@ class _AttentionBlockFn(torch.autograd.Function):
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
                       _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
-        y = att.mm(wo.t())
+        if own:   # split reduction: the LayerNorm tail adds the slabs while it loads them
+            y, y_slabs = _dense_fwd(att, wo, None, split=True)
+        else:
+            y, y_slabs = att.mm(wo.t()), None
         out_buf = None
         if arena is not None:   # the block's output is the next block's input: written where flush() will read it
             out_buf = arena.x_ffn[li] if (cross or li not in arena.cross_ord) else arena.sa_out[arena.cross_ord[li]]
         out, v, stats, keep = _ln_tail_fwd(y, bo, x, gamma, beta, p_hidden, eps, id_out, out=out_buf,
-                                           pass_through=total > rows)
+                                           pass_through=total > rows, x_slabs=y_slabs)
         ctx.save_for_backward(x, kv_src, w_all, wq, wo, proj, kvproj, mask, att, lse, v, stats, gamma, keep)
         ctx.cfg = (num_heads, scale, p_attn, p_hidden, id_attn, hd, nk, b, nq, seg, base2, live, klay, total > rows)
         ctx.arena, ctx.li = arena, li
@@ -785,8 +867,10 @@ class _AttentionBlockFn(torch.autograd.Function):
         work = None
         if arena is not None:
             work = arena.ln_work_attn[li] if self_attn else arena.ln_work_x[j]
-        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, p_hidden, dx_out=dyo_buf,
-                                          pass_through=passing, work_out=work)
+        dy = dy.contiguous()
+        dy_slabs, slab_rows = arena.take_slabs(dy) if arena is not None else (None, 0)
+        dyo, dres, dparams = _ln_tail_bwd(dy, v, stats, gamma, keep, p_hidden, dx_out=dyo_buf,
+                                          pass_through=passing, work_out=work, dy_slabs=dy_slabs, slab_rows=slab_rows)
         if arena is not None:
             dparams = arena.ln_attn[li] if self_attn else arena.ln_x[j]
         datt = dyo.mm(wo)
@@ -814,8 +898,20 @@ class _AttentionBlockFn(torch.autograd.Function):
                       _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))
         nones = (None,) * 10
+        # residual + projection paths meet in the product's epilogue.  With an arena the block BELOW is one of this
+        # stack's (layer 0's self-attention sits on the embeddings): the reduction is split and the slabs wait in
+        # the arena for that block's LayerNorm-tail backward
+        split_ok = OWN_GEMM and arena is not None and arena.slabs_ok and (li > 0 or not self_attn)
+
+        def input_grad(w):
+            if split_ok:
+                _, slabs = _dense_dgrad(dproj, w, out=dres[:live], addend=dres[:live], split=True)
+                if slabs is not None:
+                    arena.put_slabs(dres, slabs, live)
+            else:
+                dres[:live].addmm_(dproj, w)
         if self_attn:
-            dres[:live].addmm_(dproj, w_all)           # residual + projection paths in one epilogue
+            input_grad(w_all)
             if arena is None:
                 gwo = dyo.t().mm(att)
                 gw = dproj.t().mm(xl)                  # (3*hd, c)
@@ -825,7 +921,7 @@ class _AttentionBlockFn(torch.autograd.Function):
                 arena.mark("attn", li)
             return (dres, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:],
                     gwo, dparams[2], dparams[0], dparams[1]) + nones
-        dres[:live].addmm_(dproj, wq)
+        input_grad(wq)
         if arena is None:
             e2 = kv_src.reshape(b * nk, kv_src.shape[2])
             gwo = dyo.t().mm(att)
@@ -900,13 +996,22 @@ class _FFNPairBlockFn(torch.autograd.Function):
         w1, b1, w2, b2 = _pair(w1q, w1t), _pair(b1q, b1t), _pair(w2q, w2t), _pair(b2q, b2t)
         gamma, beta = _pair(gq, gt), _pair(bq, bt)
         x3 = x.view(2, P, -1)
-        pre = torch.bmm(x3, w1.transpose(1, 2))                       # (2, P, I), bias added below
-        act = _bias_gelu(pre.view(2 * P, -1), b1, P, out=None if arena is None else arena.act[li])   # (2P, I)
-        y = torch.bmm(act.view(2, P, -1), w2.transpose(1, 2))         # (2, P, C)
+        own = OWN_GEMM
+        if own:   # bias + GELU in the product's epilogue; `pre` keeps x w1^T + b1 for the backward pass
+            inter = w1.shape[1]
+            pre = torch.empty((2, P, inter), dtype=torch.float32, device=x.device)
+            act = arena.act[li] if arena is not None else torch.empty((2 * P, inter), dtype=torch.float32, device=x.device)
+            _dense_fwd(x3, w1, b1, out=act.view(2, P, inter), act=1, aux=pre)
+            y, y_slabs = _dense_fwd(act.view(2, P, inter), w2, None, split=True)         # (2, P, C) + slabs
+        else:
+            pre = torch.bmm(x3, w1.transpose(1, 2))                       # (2, P, I), bias added below
+            act = _bias_gelu(pre.view(2 * P, -1), b1, P, out=None if arena is None else arena.act[li])   # (2P, I)
+            y, y_slabs = torch.bmm(act.view(2, P, -1), w2.transpose(1, 2)), None         # (2, P, C)
         out_buf = arena.x_attn[li + 1] if (arena is not None and li + 1 < arena.nl) else None
-        out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P, out=out_buf)
+        out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P, out=out_buf,
+                                           x_slabs=y_slabs)
         ctx.save_for_backward(x, w1, b1, w2, pre, act, v, stats, gamma, keep)
-        ctx.p_drop = p_drop
+        ctx.p_drop, ctx.own = p_drop, own
         ctx.arena, ctx.li = arena, li
         return out
 
@@ -915,17 +1020,33 @@ class _FFNPairBlockFn(torch.autograd.Function):
         x, w1, b1, w2, pre, act, v, stats, gamma, keep = ctx.saved_tensors
         arena, li = ctx.arena, ctx.li
         P = x.shape[0] // 2
-        dyo, dres, dparams = _ln_tail_bwd(dy.contiguous(), v, stats, gamma, keep, ctx.p_drop, P,
+        dy = dy.contiguous()
+        dy_slabs, slab_rows = arena.take_slabs(dy) if arena is not None else (None, 0)
+        dyo, dres, dparams = _ln_tail_bwd(dy, v, stats, gamma, keep, ctx.p_drop, P,
                                           dx_out=None if arena is None else arena.dyo_ffn[li],
-                                          work_out=None if arena is None else arena.ln_work_ffn[li])
+                                          work_out=None if arena is None else arena.ln_work_ffn[li],
+                                          dy_slabs=dy_slabs, slab_rows=slab_rows)
         if arena is not None:
             dparams = arena.ln_ffn[li]
         dyo3 = dyo.view(2, P, -1)
-        gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
-        gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
-                          out=None if arena is None else arena.gpre[li])
-        gpre3 = gpre.view(2, P, -1)
-        gx = dres.view(2, P, -1).baddbmm_(gpre3, w1).view(2 * P, -1)   # residual + dense1 input grads
+        if ctx.own:   # `pre` holds the bias already; gelu' rides in the product's epilogue
+            gpre = arena.gpre[li] if arena is not None else torch.empty_like(act)
+            gpre3 = gpre.view(2, P, -1)
+            _dense_dgrad(dyo3, w2, out=gpre3, act=2, aux=pre)
+        else:
+            gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
+            gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
+                              out=None if arena is None else arena.gpre[li])
+            gpre3 = gpre.view(2, P, -1)
+        if ctx.own and arena is not None and arena.slabs_ok:
+            # residual + dense1 input gradients; the block below (this layer's attention block) adds the slabs
+            dres3 = dres.view(2, P, -1)
+            _, slabs = _dense_dgrad(gpre3, w1, out=dres3, addend=dres3, split=True)
+            if slabs is not None:
+                arena.put_slabs(dres, slabs, 2 * P)
+            gx = dres
+        else:
+            gx = dres.view(2, P, -1).baddbmm_(gpre3, w1).view(2 * P, -1)   # residual + dense1 input grads
         if arena is None:
             gw2 = torch.bmm(dyo3.transpose(1, 2), act.view(2, P, -1))  # (2, C, I)
             gb1 = _colsum(gpre, parts=2)                               # (2, I)
@@ -1409,6 +1530,8 @@ class BertEncoder(nn.Module):
         arena = _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
                                  self.layer[0].attention.self.num_attention_heads, ret,
                                  grad_store=getattr(self, "grad_store", None))
+        if cut is not None:
+            arena.slabs_ok = False   # the gradient crosses the cut through a leaf's .grad, not from block to block
         if self.flush_on_side_stream:
             dev = hidden_states.device
             if self._side is None or self._side.device != dev:

@@ -138,3 +138,39 @@ def test_ffn_pair_block_equals_two_single_blocks(p_drop):
     for t, rr, name in zip(a, r, ["x", "w1q", "b1q", "w1t", "b1t", "w2q", "b2q", "w2t", "b2t", "gq", "bq", "gt", "bt"]):
         scale = max(1.0, rr.grad.abs().max().item())
         torch.testing.assert_close(t.grad.double(), rr.grad, rtol=1e-3, atol=1e-4 * scale, msg=lambda m: name + ": " + m)
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("rows,live,part_rows,slab_rows,pass_through", [
+    (512, 416, 0, 416, False), (512, 512, 256, 0, False), (512, 256, 0, 256, True), (52, 52, 0, 0, False)])
+def test_tails_add_the_slabs_of_a_split_dense_layer(p_drop, rows, live, part_rows, slab_rows, pass_through):
+    """sig3d_dropout_add_ln_fwd_slabs / _bwd_slabs == the plain tails on the pre-summed operand (the slabs of
+    sig3d_gemm16's split reductions are added while they are loaded), padding and pass-through rows included."""
+    from situation3d_amd import qformer as Q
+    cols, extra = 768, 4
+    g = torch.Generator().manual_seed(rows + live + int(p_drop * 100))
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    parts = rows // part_rows if part_rows else 1
+    x0, xs, res = mk(live, cols), mk(extra, live, cols), mk(rows, cols)
+    bias, gamma, beta = mk(parts, cols), mk(parts, cols) + 1.0, mk(parts, cols)
+    if parts == 1:
+        bias, gamma, beta = bias[0], gamma[0], beta[0]
+    out_a, v_a, st_a, m_a = Q._ln_tail_fwd(x0 + xs.sum(0), bias, res, gamma, beta, p_drop, 1e-12, 11, part_rows,
+                                           pass_through=pass_through)
+    out_b, v_b, st_b, m_b = Q._ln_tail_fwd(x0, bias, res, gamma, beta, p_drop, 1e-12, 11, part_rows,
+                                           pass_through=pass_through, x_slabs=xs)
+    torch.testing.assert_close(out_b, out_a, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(v_b, v_a, rtol=2e-5, atol=2e-5)
+    if m_a is not None:
+        assert torch.equal(m_a[:live], m_b[:live])     # rows beyond the live ones have no mask
+    # backward: dy = slab 0 + slabs on the rows below slab_rows
+    n_slab = slab_rows if slab_rows else rows
+    dy0, dys = mk(rows, cols), mk(extra, n_slab, cols)
+    dy_sum = dy0.clone()
+    dy_sum[:n_slab] += dys.sum(0)
+    dx_a, dres_a, dp_a = Q._ln_tail_bwd(dy_sum, v_a, st_a, gamma, m_a, p_drop, part_rows, pass_through=pass_through)
+    dx_b, dres_b, dp_b = Q._ln_tail_bwd(dy0, v_a, st_a, gamma, m_a, p_drop, part_rows, pass_through=pass_through,
+                                        dy_slabs=dys, slab_rows=slab_rows)
+    torch.testing.assert_close(dx_b, dx_a, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dres_b, dres_a, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dp_b, dp_a, rtol=2e-5, atol=2e-4)

@@ -3,6 +3,9 @@
 python tools/summarize_rocprof.py gpurun_out/prof_x profiles/r01_name.md "command line" [steps]
 
 Groups at the end: library GEMMs (Cijk_*), torch glue (at::native / rocclr copy+fill), own kernels.
+Per-step figures divide by the call count of a kernel that runs exactly ONCE per step (the flat AdamW launch), not by
+a step count guessed from the command line (round 3's table used 16 where 19 replays had run); the optional [steps]
+argument is only used when the trace holds no such kernel.
 """
 import csv
 import glob
@@ -13,6 +16,9 @@ src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
 stats = glob.glob(os.path.join(src, "*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(stats)))
+once = [int(r["Calls"]) for r in rows if "adamw_table_kernel" in r["Name"]]
+if once:
+    steps = once[0]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 calls = sum(int(r["Calls"]) for r in rows)
 with open(dst, "w") as f:
@@ -35,6 +41,8 @@ with open(dst, "w") as f:
             return "torch glue (aten elementwise / cat / copy / fill)"
         if "rccl" in name.lower() or "nccl" in name.lower():
             return "RCCL"
+        if "gemm16_kernel" in name:
+            return "own GEMM (gemm16_kernel)"
         return "own HIP kernels"
     agg = {}
     for r in rows:
