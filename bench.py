@@ -72,21 +72,44 @@ def spawn_ranks(n, argv, script=None):
     relay = threading.Thread(target=lambda: lines.extend(ln.rstrip("\n") for ln in procs[0].stdout), daemon=True)
     relay.start()
     code, live = 0, set(range(n))
-    while live:
-        for r in sorted(live):
-            rc = procs[r].poll()
-            if rc is None:
-                continue
-            live.discard(r)
-            if rc != 0 and code == 0:
-                code = rc if rc > 0 else 1
-                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
-                for o in live:        # exactly the process groups started above
-                    try:
-                        os.killpg(procs[o].pid, 15)
-                    except OSError:
-                        pass
-        time.sleep(0.05)
+
+    def stop(which, sig):             # exactly the process groups started above
+        for o in which:
+            try:
+                os.killpg(procs[o].pid, sig)
+            except OSError:
+                pass
+
+    def on_signal(signum, _frame):    # a harness timeout / Ctrl-C must not leave ranks behind holding the GPUs
+        raise KeyboardInterrupt("signal %d" % signum)
+
+    import signal
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
+                    stop(live, signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt as why:
+        sys.stderr.write("bench.py: interrupted (%s); stopping the ranks\n" % why)
+        code = code or 130
+    finally:
+        still = [r for r in range(n) if procs[r].poll() is None]
+        if still:                     # SIGTERM, a grace period, then SIGKILL
+            stop(still, signal.SIGTERM)
+            t_end = time.time() + 10
+            while time.time() < t_end and any(procs[r].poll() is None for r in still):
+                time.sleep(0.1)
+            stop([r for r in still if procs[r].poll() is None], signal.SIGKILL)
+        for sg, h in old.items():
+            signal.signal(sg, h)
     relay.join(timeout=10)
     for ln in lines:
         print(ln)
@@ -95,6 +118,9 @@ def spawn_ranks(n, argv, script=None):
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _probes = sorted(k for k in os.environ if k.startswith("SIG3D_PROBE_"))
+    if _probes:
+        sys.exit("bench.py: refusing to run with %s set (probe switches belong to tools/ab_step.py)" % ", ".join(_probes))
     _n = parse_args().gpus
     if _n > 1:
         sys.exit(spawn_ranks(_n, sys.argv[1:]))
@@ -189,14 +215,18 @@ def group_algorithmic_bytes(b, n, m, ns, c):
     return b * (4 * 3 * n + 4 * c * n + 4 * m * ns + 4 * (3 + c) * m * ns)
 
 
-def oracle_forward(cpu_model, batch, backward=False):
+def oracle_forward(cpu_model, batch, backward=False, ext=None):
     """The composed path of `batch` on the HOST through the oracle: the nine native ops from
     oracle/pointnet2_oracle.c (bound as `pointnet2._ext` under this build's module stack), SharedMLP on
     torch CPU, the Q-Former through oracle/qformer_ref.py (eval-mode dropout) -> data_dict with the model's
-    output keys and the loss.  Checker code only -- never on the product path."""
+    output keys and the loss.  Checker code only -- never on the product path.
+    ext: another binding of the nine ops + pose_to_matrix (tests: the float64 adjudication run keeps the oracle's
+    indices and moves data in float64)."""
     from oracle import pointnet2_ref, qformer_ref
     from situation3d_amd.pointnet2 import pointnet2_utils
     saved_ext = pointnet2_utils._ext
+    if ext is not None:
+        pointnet2_ref = ext
     pointnet2_utils._ext = pointnet2_ref  # CPU restatement of the nine ops
     try:
         n = batch["point_clouds"].shape[0]
@@ -337,6 +367,24 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
                 # a geometry chain gave up waiting for its ticket (30 s) and ran on coordinates that may not have been
                 # staged: the numbers of this run would be those of a broken pipeline
                 raise RuntimeError("a geometry chain timed out waiting for its start ticket (sig3d_ticket_wait)")
+            comm = None
+            if reducer is not None:
+                # the gradient exchange of a few more steps, bracketed by events on the compute stream (ddp.CommStats):
+                # bytes and collectives per step, time spent waiting for them, share of their window covered by compute
+                from situation3d_amd import ddp
+                ddp.COMM_STATS = ddp.CommStats()
+                try:
+                    for i in range(3):
+                        ddp.COMM_STATS.begin_step()
+                        step(warmup + steps + i)
+                    comm = ddp.COMM_STATS.summary()
+                finally:
+                    ddp.COMM_STATS = None
+                if world > 1:   # the slowest rank's exposure is the step's
+                    t = torch.tensor([comm["exposed_ms"], comm["comm_window_ms"]], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    comm["exposed_ms"], comm["comm_window_ms"] = round(float(t[0]), 4), round(float(t[1]), 4)
+                    comm["overlap_frac"] = round(1.0 - float(t[0]) / float(t[1]), 4) if float(t[1]) > 0 else None
             if kernels:
                 # Per-launch durations of the hand-written kernels: HIP events on the launch stream around
                 # every call.  Under hipGraph replay there are no per-kernel events, so the SAME launches are
@@ -372,7 +420,7 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return dict(dt=float(t.item()), final_loss=final_loss, recs=recs, model=model, compact_info=compact_info,
-                    distinct=distinct, use_graph=use_graph)
+                    distinct=distinct, use_graph=use_graph, comm=comm)
     finally:
         fused_mlp.COMPACT = saved_compact
 
@@ -517,8 +565,17 @@ def forward_only_variant(device, bsz=4, reps=20):
             "batch": bsz, "note": "hipGraph replay of one forward; and two geometry chains in flight (serve.PipelinedForward)"}
 
 
+def refuse_probes():
+    """Measurement switches (tools/probes/geo_probes.py) skip or replace work inside a captured step; the product reads
+    none of them any more, but a bench line produced with one in the environment would invite the question."""
+    probes = sorted(k for k in os.environ if k.startswith("SIG3D_PROBE_"))
+    if probes:
+        raise SystemExit("bench.py: refusing to run with %s set (probe switches belong to tools/ab_step.py)" % ", ".join(probes))
+
+
 def main():
     args = parse_args()
+    refuse_probes()
 
     rank, local, world = init_distributed()
     if world != args.gpus:
@@ -599,7 +656,7 @@ def main():
             # the pair the north star names, all four levels of a step, compact launches at their own bytes;
             # dense-equivalent = SURVEY.md 8d's 314.8 MB per step over the same time
             "roofline": {"bound": "hbm", "kernel": "ball_query (all levels, cell-binned centres) + query_group (fused / point-major / "
-                                                   "compact) + point-major transposes, SA1-4",
+                                                   "compact), SA1-4",
                          "achieved": round(pair_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(pair_gbs / HBM_PEAK_GBS, 4),
                          # HBM bytes of the same kernels per step (PMC, FETCH_SIZE x 2 + WRITE_SIZE) and the commit
@@ -617,11 +674,7 @@ def main():
                          "floor_model": {"launches": pair_launches // KSTEPS, "us_per_launch": 1.5, "stream_gbs": 6300.0,
                                          "floor_ms": round((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3, 4),
                                          "vs_floor": round(((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3)
-                                                           / (pair_ms / KSTEPS), 4) if pair_ms else None},
-                         "dense_equivalent_frac": round(sum(ball_query_algorithmic_bytes(BATCH, n, m, ns)
-                                                            + group_algorithmic_bytes(BATCH, n, m, ns, c)
-                                                            for n, m, ns, c in SA_LEVELS) * KSTEPS
-                                                        / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pair_ms else None},
+                                                           / (pair_ms / KSTEPS), 4) if pair_ms else None}},
             "roofline_group_dense": {"bound": "hbm", "kernel": "query_group_fused_kernel + query_group_fused_pm_kernel "
                                                                "(levels that form the dense grouped tensor)",
                                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -647,6 +700,9 @@ def main():
             "final_loss": round(head["final_loss"], 5),
             "fps_timeouts": _lib.fps_timeouts(),
         }
+        if head["comm"] is not None:
+            # data-parallel form (N > 1, or --force-reducer): what the gradient exchange costs the step (ddp.CommStats)
+            out["comm"] = head["comm"]
     # ---- beside the headline (N = 1): the same step with every level dense, and on surface-shaped scenes
     if world == 1 and not args.no_variants:
         vsteps, vwarm = min(args.steps, 10), min(args.warmup, 3)

@@ -29,24 +29,15 @@ extern "C" {
 const char *sig3d_version(void);          /* "sig3d-hip <semver> gfx950" */
 const char *sig3d_last_error(void);       /* thread-local message of the last failing call */
 
-/* Diagnostic: store the GPU wall clock into *slot from `stream` (a graph node when captured) --
- * the concurrent timeline of a replayed hipGraph, which per-node events and profilers cannot give.
- * sig3d_timestamp_rate: ticks per second of that clock. */
-int sig3d_timestamp(unsigned long long *slot, void *stream);
-int sig3d_timestamp_rate(int device, long long *hz);
-
 /* Device-side handshake between two streams of one device (no reference counterpart: the reference runs one stream).
  * sig3d_ticket_signal: *ticket += 1 (release, agent scope) as a one-lane kernel on `stream`.
  * sig3d_ticket_wait: a one-lane kernel on `stream` that spins until *ticket has passed *consumed, then sets
  * *consumed += 1; after `timeout_us` it sets *error = 1 and returns anyway.  ticket / consumed / error are device
  * words the caller zeroes once.  Replaces hipStreamWaitEvent where the waiting stream would otherwise hold a blocked
- * barrier packet for milliseconds (see csrc/capi.hip). */
-int sig3d_stream_create_with_cu_mask(int words, const unsigned int *mask, void **stream);
-int sig3d_stream_destroy(void *stream);
-int sig3d_whereami(unsigned int *slots, int blocks, int threads, int hold_us, void *stream);
-/* Diagnostic: blocks x threads workgroups that keep ~vgprs (0 / 100 / 220) registers per lane and lds_bytes of LDS
- * while they sleep for hold_us: the cost of a resident footprint to another stream's kernels. */
-int sig3d_hold(float *sink, int blocks, int threads, int hold_us, int vgprs, int lds_bytes, void *stream);
+ * barrier packet for milliseconds (see csrc/capi.hip).  A waiter that gave up runs on inputs that may not be staged:
+ * the caller must treat a raised error word as fatal (geometry.GeometryPipeline.advance raises).
+ * (The measurement entry points -- timestamps, CU-masked streams, resident-footprint probes -- are declared in
+ * include/sig3d_debug.h: they are not part of the drop-in boundary.) */
 int sig3d_ticket_signal(unsigned int *ticket, void *stream);
 int sig3d_ticket_wait(const unsigned int *ticket, unsigned int *consumed, long long timeout_us, int *error,
                       void *stream);

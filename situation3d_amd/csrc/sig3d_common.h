@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/sig3d_hip.h"
+#include "../../include/sig3d_debug.h"
 
 // ---- host-side error plumbing (capi.hip owns the thread-local buffer) -------------------
 void sig3d_set_error(const char *where, hipError_t err);

@@ -129,6 +129,8 @@ class GradBucketReducer:
 
     def _launch(self, b):
         b["launched"] = True
+        if COMM_STATS is not None and b["flat"].is_cuda:
+            COMM_STATS.launched(b["flat"].numel() * b["flat"].element_size())
         if self.world == 1 and not _single_rank_rehearsal():
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -211,6 +213,9 @@ class GradBucketReducer:
                       comm.cuda_stream)
             for b in self.buckets:
                 b["launched"] = True
+                if COMM_STATS is not None:
+                    with torch.cuda.stream(main):
+                        COMM_STATS.launched(b["flat"].numel() * b["flat"].element_size())
                 dist.all_reduce(b["flat"], op=op, group=self.group, async_op=False)
                 ev = b.get("done")
                 if ev is None:
@@ -221,6 +226,14 @@ class GradBucketReducer:
     def wait(self, b):
         """Make the current stream wait for ONE bucket's collective (and apply the mean for backends
         without ReduceOp.AVG)."""
+        if COMM_STATS is not None and b["flat"].is_cuda:
+            h = b["handle"]
+            COMM_STATS.join((lambda: h.wait()) if h is not None else (lambda: None))
+            if h is not None:
+                b["handle"] = None
+                if not self._avg:
+                    b["flat"].div_(self.world)
+            return
         if b["handle"] is not None:
             b["handle"].wait()
             b["handle"] = None
@@ -229,6 +242,64 @@ class GradBucketReducer:
 
     def num_collectives(self):
         return len(self.buckets)
+
+
+class CommStats:
+    """Exposed-communication accounting of the data-parallel step (SURVEY.md section 5: "report overlap %";
+    reference: DDP's bucketed all-reduce, runner_base.py:88-95).  While `ddp.COMM_STATS` holds an instance, every
+    GradBucketReducer.launch_all() / wait() and SparseRowExchange.launch() / finish_into() brackets itself with HIP events
+    on the compute stream:
+      bytes_per_step   what this rank hands to collectives (gradient buckets + embedding-row all-gathers)
+      buckets          collectives per step
+      exposed_ms       time the compute stream sat in the waits for its collectives (0 when they had finished)
+      comm_window_ms   first launch -> last join, on the compute stream's clock
+      overlap_frac     1 - exposed / window: the share of the communication window that was covered by compute
+    bench.py turns it on for a few steps AFTER the timed region (events inside it would be part of the timing)."""
+
+    def __init__(self):
+        self.bytes = 0
+        self.collectives = 0
+        self.waits = []        # (event before, event after) per join
+        self.first = []        # event at the first launch of a step
+        self.steps = 0
+        self._open = False
+
+    def begin_step(self):
+        self.steps += 1
+        self._open = False
+
+    def launched(self, nbytes, n=1):
+        if not self._open:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.first.append(ev)
+            self._open = True
+        self.bytes += int(nbytes)
+        self.collectives += n
+
+    def join(self, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.waits.append((e0, e1, self.steps))
+
+    def summary(self):
+        """Synchronises.  Per-step averages over the steps seen."""
+        torch.cuda.synchronize()
+        n = max(self.steps, 1)
+        exposed = sum(a.elapsed_time(b) for a, b, _ in self.waits)
+        window = 0.0
+        for k, first in enumerate(self.first):
+            last = [b for _, b, st in self.waits if st == k + 1]
+            if last:
+                window += first.elapsed_time(last[-1])
+        return {"bytes_per_step": self.bytes // n, "buckets": self.collectives // n,
+                "exposed_ms": round(exposed / n, 4), "comm_window_ms": round(window / n, 4),
+                "overlap_frac": round(1.0 - exposed / window, 4) if window > 0 else None}
+
+
+COMM_STATS = None   # a CommStats while bench.py (or a training loop's logging interval) measures
 
 
 class SparseRowExchange:
@@ -259,14 +330,20 @@ class SparseRowExchange:
 
     def launch(self):
         """Asynchronous all-gathers of this rank's (ids, rows), stream-ordered after the current stream."""
+        if COMM_STATS is not None and self.rows.is_cuda:
+            COMM_STATS.launched(self.ids.numel() * 8 + self.rows.numel() * 4, 2)
         if self._wire:
             self._handles = (dist.all_gather_into_tensor(self.ids_all, self.ids, group=self.group, async_op=True),
                              dist.all_gather_into_tensor(self.rows_all, self.rows, group=self.group, async_op=True))
 
     def finish_into(self, dense):
         """dense (V, C): the zeroed gradient slot of the table; += mean over ranks of the scattered rows."""
-        for h in self._handles:
-            h.wait()
+        if COMM_STATS is not None and self.rows.is_cuda:
+            hs = self._handles
+            COMM_STATS.join(lambda: [h.wait() for h in hs])
+        else:
+            for h in self._handles:
+                h.wait()
         self._handles = ()
         ids, rows = (self.ids_all, self.rows_all) if self._wire else (self.ids, self.rows)
         dense.index_add_(0, ids, rows, alpha=1.0 / self.world)

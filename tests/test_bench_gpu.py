@@ -59,6 +59,10 @@ def test_data_parallel_path_over_real_rccl_group_of_one(comm):
         env["SIG3D_DDP_COMM"] = "own"
     out = _run(["--force-reducer", "--no-variants"], env)
     assert out["value"] > 0 and out["n_gpus"] == 1
+    # the exchange explains itself (ddp.CommStats): ~614 MB of buckets + the embedding rows, time spent waiting
+    c = out["comm"]
+    assert c["bytes_per_step"] > 500e6 and c["buckets"] >= 10
+    assert c["exposed_ms"] >= 0 and c["comm_window_ms"] > 0 and c["overlap_frac"] is not None
     ref = _run(["--no-variants"], {})
     # same seeds, same batches, mean over one rank == identity: the loss after 6 steps must agree
     assert abs(out["final_loss"] - ref["final_loss"]) <= 2e-3 * abs(ref["final_loss"])
@@ -76,3 +80,12 @@ def test_bare_gpus_2_spawns_its_own_ranks():
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo"
     assert out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["comm"]["bytes_per_step"] > 500e6 and out["comm"]["buckets"] >= 10 and out["comm"]["exposed_ms"] >= 0
+
+
+def test_probe_switches_are_refused():
+    """A SIG3D_PROBE_* variable in the environment (tools/probes/geo_probes.py) must not produce a bench line."""
+    env = dict(os.environ, SIG3D_PROBE_SKIP_CHAIN="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "SIG3D_PROBE_SKIP_CHAIN" in (p.stderr + p.stdout)

@@ -25,10 +25,21 @@ def _load(name):
 
 
 # ---- boundary ------------------------------------------------------------------------------
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "sig3d_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sig3d_[a-z0-9_]+)\s*\(", text)))
+def _declared_symbols(headers=("sig3d_hip.h", "sig3d_debug.h")):
+    """Every entry point include/*.h declares (the drop-in boundary + the measurement header)."""
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sig3d_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_measurement_entry_points_are_not_in_the_boundary_header():
+    boundary = _declared_symbols(("sig3d_hip.h",))
+    for name in ("sig3d_hold", "sig3d_whereami", "sig3d_stream_create_with_cu_mask", "sig3d_timestamp"):
+        assert name not in boundary and name in _declared_symbols(("sig3d_debug.h",))
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["sig3d_debug.h", "sig3d_hip.h"]
 
 
 def test_library_exports_every_declared_symbol():
