@@ -139,6 +139,8 @@ from situation3d_amd.trainer import build_optimizer, get_loss, train_step  # noq
 
 N_POINTS, BATCH, N_QUERY, N_TEXT, NUM_ANSWERS = 40000, 8, 32, 20, 706
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_F32_PEAK_TFLOPS = 157.3   # same guide: peak FP32 (vector)
+LDS_PEAK_GBS = 150000.0        # same guide: ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
 SA_LEVELS = [(40000, 2048, 64, 3), (2048, 1024, 32, 128), (1024, 512, 16, 256), (512, 256, 16, 256)]
 
 
@@ -367,7 +369,7 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
                 # a geometry chain gave up waiting for its ticket (30 s) and ran on coordinates that may not have been
                 # staged: the numbers of this run would be those of a broken pipeline
                 raise RuntimeError("a geometry chain timed out waiting for its start ticket (sig3d_ticket_wait)")
-            comm = None
+            comm, bq_tests = None, None
             if reducer is not None:
                 # the gradient exchange of a few more steps, bracketed by events on the compute stream (ddp.CommStats):
                 # bytes and collectives per step, time spent waiting for them, share of their window covered by compute
@@ -403,6 +405,14 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
                 torch.cuda.synchronize()
                 recs = _lib.timing_records()
                 _lib.enable_timing(None)
+                # the neighbour search's own work: the distance tests of one more call over the last plan
+                # (sig3d_ball_query_levels_stats; the kernel is bound by LDS round trips, not by HBM)
+                bq_tests = None
+                if getattr(eplan, "_bq_levels", None) is not None:
+                    words = torch.zeros(1, dtype=torch.int64, device=device)
+                    _lib.call("sig3d_ball_query_levels_stats", BATCH, len(eplan._bq_levels), eplan._bq_levels,
+                              _lib.ptr(eplan._bq_work), eplan._bq_work.numel(), 0, _lib.ptr(words), _lib.stream_ptr(device))
+                    bq_tests = int(words.item())
         # set-abstraction levels that ran over the distinct neighbours only, with the fraction of their
         # (centre, sample) positions that are distinct on the last batch
         compact_info, distinct = {}, {}
@@ -420,7 +430,7 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return dict(dt=float(t.item()), final_loss=final_loss, recs=recs, model=model, compact_info=compact_info,
-                    distinct=distinct, use_graph=use_graph, comm=comm)
+                    distinct=distinct, use_graph=use_graph, comm=comm, bq_tests=bq_tests)
     finally:
         fused_mlp.COMPACT = saved_compact
 
@@ -675,6 +685,19 @@ def main():
                                          "floor_ms": round((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3, 4),
                                          "vs_floor": round(((pair_launches // KSTEPS) * 1.5e-3 + pair_bytes / KSTEPS / 6.3e12 * 1e3)
                                                            / (pair_ms / KSTEPS), 4) if pair_ms else None}},
+            # the neighbour search against the bound it really has: a distance test is 8 flop (3 sub, 3 mul, 2 add, each
+            # individually rounded) on a 16-byte centre record read from LDS; peaks from MI355X_MICROARCH.md
+            # (157.3 TFLOP/s f32 vector, ~150 TB/s of ds_read_b128 with every CU streaming)
+            "roofline_ball_query": None if not (head["bq_tests"] and bq) else {
+                "bound": "valu/lds", "kernel": "bqc_scatter_kernel + bqc_rank_kernel (SA1-4 in one launch pair)",
+                "tests_per_step": head["bq_tests"], "flop_per_test": 8,
+                "achieved": round(head["bq_tests"] * 8 / (sum(bq) / len(bq) * 1e-3) / 1e12, 4), "peak": VALU_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(head["bq_tests"] * 8 / (sum(bq) / len(bq) * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS, 5),
+                "lds_bytes_per_step": head["bq_tests"] * 16,
+                "lds_frac": round(head["bq_tests"] * 16 / (sum(bq) / len(bq) * 1e-3) / 1e9 / LDS_PEAK_GBS, 5),
+                "avg_launch_pair_us": round(sum(bq) / len(bq) * 1e3, 2),
+                "note": "latency-bound: 40 000 points per scene walk ~5 candidate centres each through dependent LDS reads"},
             "roofline_group_dense": {"bound": "hbm", "kernel": "query_group_fused_kernel + query_group_fused_pm_kernel "
                                                                "(levels that form the dense grouped tensor)",
                                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -129,6 +129,11 @@ int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, vo
 #define SIG3D_BQ_CLEAN 1
 int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                                long workspace_bytes, int flags, void *stream);
+/* The same call, counting its work: *stats (a device word the caller zeroes) += the centre-point distance tests the
+ * scatter kernel performed (16 bytes of LDS read and 8 flop each) -- what bench.py's roofline_ball_query prices the
+ * kernel against; the neighbour search streams 10 MB and is bound by LDS round trips, not by HBM.  stats may be NULL. */
+int sig3d_ball_query_levels_stats(int b, int nlevels, const sig3d_bq_level *levels, void *workspace, long workspace_bytes,
+                                  int flags, unsigned long long *stats, void *stream);
 
 /* One problem through sig3d_ball_query_levels (the round-1 name: it was a hashed grid over the points).
  * workspace: 1028 * b * m bytes.  n < 256, radius <= 0 or more than 65536 centres are forwarded to

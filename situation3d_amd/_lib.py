@@ -188,6 +188,7 @@ class BqLevel(ctypes.Structure):
 
 SIGNATURES["sig3d_ball_query_levels"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _P]
 SIGNATURES["sig3d_ball_query_levels_ex"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P]
+SIGNATURES["sig3d_ball_query_levels_stats"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P, _P]
 BQ_CLEAN = 1
 
 

@@ -23,7 +23,7 @@ constexpr int BQ_WAVES = 4;  // waves per workgroup
 template <int CPW>
 __device__ __forceinline__ void bq_scan_wave(int n, int m, float radius2, int nsample,
                                              const float *__restrict__ new_xyz, const float *__restrict__ xyz,
-                                             int *__restrict__ idx, int c0, int lane) {
+                                             int *__restrict__ idx, int c0, int lane, int *tests = nullptr) {
   float cx[CPW], cy[CPW], cz[CPW];
   int cnt[CPW], first[CPW];
 #pragma unroll
@@ -57,6 +57,7 @@ __device__ __forceinline__ void bq_scan_wave(int n, int m, float radius2, int ns
       }
       open |= (cnt[c] < nsample);
     }
+    if (tests) *tests += CPW;   // per lane: CPW tests of this 64-point step
     if (!open) break;  // every centre of this wave is full (ball_query_gpu.cu:27 cnt < nsample)
   }
 
@@ -141,6 +142,7 @@ struct BqcLevel {
 };
 struct BqcParams {
   int nlevels, b;
+  unsigned long long *stats;   // or null: [0] += distance tests of the scatter kernel (bench.py's roofline_ball_query)
   BqcLevel lv[BQC_MAXLV];
 };
 
@@ -178,10 +180,12 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
     if (c0 >= m) return;
     const float *cs = L.new_xyz + ((size_t)bi * L.m_total + L.c_off) * 3;
     int *rows = L.idx + ((size_t)bi * L.m_total + L.c_off) * L.nsample;
-    if (L.cpw == 8) bq_scan_wave<8>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane);
-    else if (L.cpw == 4) bq_scan_wave<4>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane);
-    else if (L.cpw == 2) bq_scan_wave<2>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane);
-    else bq_scan_wave<1>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane);
+    int tests = 0;
+    if (L.cpw == 8) bq_scan_wave<8>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane, &tests);
+    else if (L.cpw == 4) bq_scan_wave<4>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane, &tests);
+    else if (L.cpw == 2) bq_scan_wave<2>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane, &tests);
+    else bq_scan_wave<1>(n, m, radius2, L.nsample, cs, s_pts, rows, c0, lane, &tests);
+    if (P.stats && lane == 0) atomicAdd(P.stats, (unsigned long long)tests * 64ull);
     return;
   }
   const unsigned hmask = (unsigned)H - 1u;
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
   int *s_list = s_base + m;                // [BQC_HITS] centre << 10 | point of the chunk
   if (tid == 0) s_nhit = 0;
   __syncthreads();
+  int ntests = 0;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && s_nhit <= BQC_HITS) {   // uniform: every hit is in the list
@@ -316,12 +321,17 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
       }
       break;
     }
+    // (Round 4 tried requesting the first two records of four buckets at a time, eight LDS reads in flight, with only
+    // the 1.4 % of buckets that hold more than two centres left in a dependent loop: 42 us instead of 39 for the four
+    // levels at 128 registers, 61 us at the 171 the compiler wants -- with four waves per SIMD the walk's LDS round
+    // trips were hidden already, and the second workgroup per CU is worth more than the reads in flight.)
 #pragma unroll
     for (int t = 0; t < BQC_PPT; ++t) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         for (int p = p0[t][q]; p < p1[t][q]; ++p) {
           const float4 C = s_ctr[p];
+          ++ntests;
           if (sq_dist3(C.x, C.y, C.z, px[t], py[t], pz[t]) < radius2) {   // ball_query_gpu.cu:31-33
             const int j = __builtin_bit_cast(int, C.w);
             if (pass == 0) {
@@ -354,6 +364,10 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
     }
   }
   BQ_MARK(8);
+  if (P.stats) {
+    const int wsum = (int)wave_allreduce_sum_f32((float)ntests);   // < 2^24 per wave: exact
+    if (lane == 0) atomicAdd(P.stats, (unsigned long long)wsum);
+  }
 }
 
 __global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, int *__restrict__ cnt,
@@ -523,6 +537,7 @@ extern "C" int sig3d_ball_query(int b, int n, int m, float radius, int nsample,
 extern "C" long sig3d_ball_query_levels_workspace_bytes(int b, int nlevels, const sig3d_bq_level *levels) {
   if (b <= 0 || nlevels <= 0 || levels == nullptr) return 0;
   BqcParams P;
+  P.stats = nullptr;
   return bqc_plan(b, nlevels, levels, &P, nullptr, nullptr, nullptr);
 }
 
@@ -533,6 +548,12 @@ extern "C" int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level 
 
 extern "C" int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                                           long workspace_bytes, int flags, void *stream_) {
+  return sig3d_ball_query_levels_stats(b, nlevels, levels, workspace, workspace_bytes, flags, nullptr, stream_);
+}
+
+extern "C" int sig3d_ball_query_levels_stats(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
+                                             long workspace_bytes, int flags, unsigned long long *stats,
+                                             void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && nlevels >= 0 && (nlevels == 0 || levels != nullptr), "bad arguments");
   if (b == 0 || nlevels == 0) return 0;
@@ -547,6 +568,7 @@ extern "C" int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_lev
   size_t lds = 0;
   const long need = bqc_plan(b, nlevels, levels, &P, &wgs, &rwgs, &lds);
   SIG3D_REQUIRE(need >= 0, "too many problems / centres for one launch (16 blocks of 4096 centres)");
+  P.stats = stats;
   if (P.nlevels == 0) return 0;
   SIG3D_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need),
                 "workspace too small: see sig3d_ball_query_levels_workspace_bytes");
