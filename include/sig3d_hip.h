@@ -355,7 +355,7 @@ int sig3d_dropout_add_ln_fwd(int rows, int cols, int part_rows, int live_rows, f
  * column sums, folded without atomics: deterministic).  part_rows as in the forward: dparams is then
  * (parts, 3, cols) and part_rows must be a multiple of 4.
  * dparams == NULL: the fold is left to the caller -- the workspace then holds `blocks` partial rows of 3*cols
- * floats, blocks = ceil(ceil(rows / r) / 4) with r = 8 / 2 / 1 rows per wave for rows >= 4096 / >= 256 / below
+ * floats, blocks = ceil(ceil(rows / r) / 4) with r = 8 / 2 / 1 rows per wave for rows >= 4096 / >= 2048 / below
  * (halved until part_rows % (4 r) == 0), blocks / parts consecutive rows per part; sig3d_column_sum over
  * the workspaces of many tails folds them in one launch. */
 int sig3d_dropout_add_ln_bwd(int rows, int cols, int part_rows, int live_rows, float p_drop, const float *dy, const float *v,

@@ -162,13 +162,24 @@ class FlatAdamW(torch.optim.Optimizer):
         One small MAX all-reduce in the eager data-parallel step (where the set can depend on the data); a captured
         step has one static launch structure on every rank and skips it."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) \
+        # the ranks that AVERAGE these gradients: the reducer's group when one was named (`process_group`
+        # attribute, set by whoever pairs this optimizer with a ddp.GradBucketReducer), else the default group
+        group = getattr(self, "process_group", None)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1) \
                 or torch.cuda.is_current_stream_capturing():
             return live
-        dev = self._dev if dist.get_backend() == "nccl" else "cpu"
+        # the set only changes when the data changes which parameters are used: a rank that sees the mask it agreed
+        # on last time skips the exchange -- if EVERY rank does (one 1-byte MAX all-reduce of "mine changed")
+        changed = self.__dict__.get("_live_agreed_for") is None or not np.array_equal(self._live_agreed_for, live)
+        dev = self._dev if dist.get_backend(group) == "nccl" else "cpu"
+        flag = torch.tensor([1 if changed else 0], dtype=torch.uint8, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 0:
+            return self._live_agreed
         mask = torch.from_numpy(live.astype(np.uint8)).to(dev)
-        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
-        return mask.cpu().numpy().astype(bool)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+        self._live_agreed_for, self._live_agreed = live.copy(), mask.cpu().numpy().astype(bool)
+        return self._live_agreed
 
     # ---- public ----------------------------------------------------------------------------------
     def flat_grad_buffers(self):
@@ -308,6 +319,7 @@ class FlatAdamW(torch.optim.Optimizer):
         launched at once (ddp.GradBucketReducer over flat_grad_buffers(), after gather_grads()), then
         the AdamW kernel runs bucket by bucket as soon as that bucket's collective has completed --
         the 1 ms HBM-bound update hides under the remaining collectives instead of following them."""
+        self.process_group = reducer.group     # liveness is agreed among the ranks that share these gradients
         reducer.launch_all()
         self.begin_bucketed_step()
         self.update_buckets(reducer)
@@ -385,6 +397,11 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def update_buckets(self, reducer):
+        self.process_group = reducer.group
+        return self._update_buckets(reducer)
+
+    @torch.no_grad()
+    def _update_buckets(self, reducer):
         """AdamW on every bucket of `reducer` (slices of flat_grad_buffers()), each right behind its own
         all-reduce; the collectives must have been launched (reducer.launch_all()).  The gradients stay in
         place: the next gather_grads(zero=True) clears the buffers."""

@@ -200,7 +200,7 @@ def _ln_tail_fwd(x2, bias, r2, gamma, beta, p_drop, eps, call_id, part_rows=0, m
 
 def _ln_bwd_blocks(rows, part_rows=0):
     """Partial rows sig3d_dropout_add_ln_bwd leaves in its workspace (see include/sig3d_hip.h)."""
-    rpw = 8 if rows >= 4096 else (2 if rows >= 256 else 1)
+    rpw = 8 if rows >= 4096 else (2 if rows >= 2048 else 1)      # csrc/rowops.hip: ln_bwd_rows_per_wave
     if 0 < part_rows < rows:
         while part_rows % (4 * rpw) != 0:
             rpw >>= 1
