@@ -123,6 +123,9 @@ def advance_dropout_seed(device):
 # launches stay ahead (7.85-7.98 ms vs 8.18-8.28 per step, same box, alternating: DESIGN.md section 4f), so the default
 # is the vendor library (rocBLAS / hipBLASLt through torch) and this switch is the A/B.
 OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
+# which products (bit mask, all by default): 1 query/key/value, 2 attention output, 4 feed-forward up (+ GELU),
+# 8 feed-forward down, 16 d(feed-forward up) (* gelu'), 32 d(feed-forward down) + residual, 64 d(projections) + residual
+OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
 
 
 def _g16(dev, **kw):
@@ -803,7 +806,7 @@ class _AttentionBlockFn(torch.autograd.Function):
         own = OWN_GEMM
         if not cross:  # self-attention
             w_all = _stacked((wq, wk, wv))
-            if own:
+            if own and OWN_MASK & 1:
                 proj, _ = _dense_fwd(xl, w_all, _stacked((bq, bk, bv)))   # (L, 3*hd)
             else:
                 proj = torch.addmm(_stacked((bq, bk, bv)), xl, w_all.t())
@@ -837,7 +840,7 @@ class _AttentionBlockFn(torch.autograd.Function):
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       ctypes.c_float(p_attn), ctypes.c_uint(id_attn), _lib.ptr(_rng_counter(dev)),
                       _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
-        if own:   # split reduction: the LayerNorm tail adds the slabs while it loads them
+        if own and OWN_MASK & 2:   # split reduction: the LayerNorm tail adds the slabs while it loads them
             y, y_slabs = _dense_fwd(att, wo, None, split=True)
         else:
             y, y_slabs = att.mm(wo.t()), None
@@ -901,7 +904,7 @@ class _AttentionBlockFn(torch.autograd.Function):
         # residual + projection paths meet in the product's epilogue.  With an arena the block BELOW is one of this
         # stack's (layer 0's self-attention sits on the embeddings): the reduction is split and the slabs wait in
         # the arena for that block's LayerNorm-tail backward
-        split_ok = OWN_GEMM and arena is not None and arena.slabs_ok and (li > 0 or not self_attn)
+        split_ok = OWN_GEMM and OWN_MASK & 64 and arena is not None and arena.slabs_ok and (li > 0 or not self_attn)
 
         def input_grad(w):
             if split_ok:
@@ -996,16 +999,18 @@ class _FFNPairBlockFn(torch.autograd.Function):
         w1, b1, w2, b2 = _pair(w1q, w1t), _pair(b1q, b1t), _pair(w2q, w2t), _pair(b2q, b2t)
         gamma, beta = _pair(gq, gt), _pair(bq, bt)
         x3 = x.view(2, P, -1)
-        own = OWN_GEMM
+        own = OWN_GEMM and bool(OWN_MASK & 4)
         if own:   # bias + GELU in the product's epilogue; `pre` keeps x w1^T + b1 for the backward pass
             inter = w1.shape[1]
             pre = torch.empty((2, P, inter), dtype=torch.float32, device=x.device)
             act = arena.act[li] if arena is not None else torch.empty((2 * P, inter), dtype=torch.float32, device=x.device)
             _dense_fwd(x3, w1, b1, out=act.view(2, P, inter), act=1, aux=pre)
-            y, y_slabs = _dense_fwd(act.view(2, P, inter), w2, None, split=True)         # (2, P, C) + slabs
         else:
             pre = torch.bmm(x3, w1.transpose(1, 2))                       # (2, P, I), bias added below
             act = _bias_gelu(pre.view(2 * P, -1), b1, P, out=None if arena is None else arena.act[li])   # (2P, I)
+        if OWN_GEMM and OWN_MASK & 8:
+            y, y_slabs = _dense_fwd(act.view(2, P, -1), w2, None, split=True)            # (2, P, C) + slabs
+        else:
             y, y_slabs = torch.bmm(act.view(2, P, -1), w2.transpose(1, 2)), None         # (2, P, C)
         out_buf = arena.x_attn[li + 1] if (arena is not None and li + 1 < arena.nl) else None
         out, v, stats, keep = _ln_tail_fwd(y.view(2 * P, -1), b2, x, gamma, beta, p_drop, eps, call_id, P, out=out_buf,
@@ -1029,16 +1034,22 @@ class _FFNPairBlockFn(torch.autograd.Function):
         if arena is not None:
             dparams = arena.ln_ffn[li]
         dyo3 = dyo.view(2, P, -1)
-        if ctx.own:   # `pre` holds the bias already; gelu' rides in the product's epilogue
+        if ctx.own and OWN_MASK & 16:   # `pre` holds the bias already; gelu' rides in the product's epilogue
             gpre = arena.gpre[li] if arena is not None else torch.empty_like(act)
             gpre3 = gpre.view(2, P, -1)
             _dense_dgrad(dyo3, w2, out=gpre3, act=2, aux=pre)
         else:
             gact = torch.bmm(dyo3, w2)                                     # (2, P, I)
-            gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
-                              out=None if arena is None else arena.gpre[li])
+            if ctx.own:      # `pre` holds the bias already
+                gpre = torch.ops.aten.gelu_backward(gact.view(2 * P, -1), pre.view(2 * P, -1))
+                if arena is not None:
+                    arena.gpre[li].copy_(gpre)
+                    gpre = arena.gpre[li]
+            else:
+                gpre = _bias_gelu(pre.view(2 * P, -1), b1, P, gy=gact.view(2 * P, -1),
+                                  out=None if arena is None else arena.gpre[li])
             gpre3 = gpre.view(2, P, -1)
-        if ctx.own and arena is not None and arena.slabs_ok:
+        if OWN_GEMM and OWN_MASK & 32 and arena is not None and arena.slabs_ok:
             # residual + dense1 input gradients; the block below (this layer's attention block) adds the slabs
             dres3 = dres.view(2, P, -1)
             _, slabs = _dense_dgrad(gpre3, w1, out=dres3, addend=dres3, split=True)
