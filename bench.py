@@ -47,6 +47,9 @@ def parse_args(argv=None):
                     help="skip the stand-alone dense op-level pair (roofline_ops); for --pmc passes over the step's own kernels")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute FPS/ball-query geometry inline instead of one batch ahead")
+    ap.add_argument("--surface", action="store_true",
+                    help="time the step on surface-shaped scenes (the 'synthetic-surface data' variant) INSTEAD of the "
+                         "SURVEY 8d headline distribution -- for profiles; the line says so in `data`")
     ap.add_argument("--geo-depth", type=int, default=int(os.environ.get("SIG3D_GEO_DEPTH", "1")),
                     help="geometry chains in flight beside the step (geometry.GeometryPipeline; 1 = round 2's one-ahead)")
     return ap.parse_args(argv)
@@ -607,7 +610,7 @@ def main():
         assert ranks_seen == dist.get_world_size() == world
 
     # ---- headline: SURVEY.md 8d distribution (volume-uniform points), compact set abstraction where it pays
-    head = measure(args, rank, world, device, args.steps, args.warmup)
+    head = measure(args, rank, world, device, args.steps, args.warmup, surface=args.surface)
     dt, recs, model = head["dt"], head["recs"], head["model"]
 
     if rank == 0:
@@ -636,7 +639,9 @@ def main():
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
         traffic, traffic_commit, traffic_stale = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_group_pair.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_group_pair.json")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_group_pair.json")
         if os.path.exists(pmc):
             j = json.load(open(pmc))
             traffic, traffic_commit = round(j["traffic_bytes_per_step"]), j.get("commit")
@@ -656,7 +661,7 @@ def main():
             "rccl_ranks": ranks_seen, "dist_backend": backend,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic-surface (NOT the headline distribution)" if args.surface else "synthetic",
             "config": {"workload": "SQA3D train step fwd+bwd+AdamW, 40k pts/scene, B=8/GPU, "
                                    "SA1-4 -> 256 tokens -> situational re-encode -> Q-Former "
                                    "(32 queries + 20 question tokens, 12 layers)",
