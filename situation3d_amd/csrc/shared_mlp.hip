@@ -615,6 +615,8 @@ __device__ __forceinline__ float upstream_grad(const float *__restrict__ dA, con
 
 constexpr int BNB_THREADS = 256;
 constexpr int BNB_CHUNK = 8192;  // elements of one (b, c) row per workgroup
+constexpr int BNB_CGRID = 4;     // compact rows: workgroups per (batch, channel) row, each walking chunks up to n_act
+                                 // (16 = the dense grid: 7.92-7.99 ms per step; 4: 7.85-7.87; 2: 7.84-7.86, same box)
 
 template <bool TOP>
 __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_kernel(
@@ -786,13 +788,17 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_c_kernel(
   __shared__ float red[2][BNB_THREADS / 64];
   const int ch = blockIdx.y, bi = blockIdx.z;
   const unsigned En = (unsigned)n_act[bi];
-  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
-  if (e0 >= En) return;
+  // The grid is static (a captured step cannot follow the data) but no longer covers the dense row: BNB_CGRID
+  // workgroups per (batch, channel) row walk the live positions chunk by chunk -- at SA1 11 % of a row is live and
+  // 14 of every 16 workgroups used to load n_act only to exit.
+  if (blockIdx.x * (unsigned)BNB_CHUNK >= En) return;
   const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
   const int *cent = cent_all + (size_t)bi * E, *sg = seg_all + (size_t)bi * (P + 1);
   const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
   // upstream gradients are already summed over the columns a position stands for: no weights here
   float a1 = 0.f, a2 = 0.f;
+  for (unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK; e0 < En; e0 += gridDim.x * (unsigned)BNB_CHUNK) {
+  const unsigned e1 = min(En, e0 + (unsigned)BNB_CHUNK);
   unsigned es = e0;   // first position of the scalar loop below
   if (!TOP && (E & 3) == 0 && e1 - e0 >= 4) {
     // float4 per lane, the eight loads of a thread requested before the first use (the scalar loop below is a
@@ -827,6 +833,7 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_stats_c_kernel(
     a1 += dz;
     a2 += dz * ((yv - mu) * is);
   }
+  }
   a1 = wave_allreduce_sum_f32(a1);
   a2 = wave_allreduce_sum_f32(a2);
   if (lane_id() == 0) { red[0][threadIdx.x >> 6] = a1; red[1][threadIdx.x >> 6] = a2; }
@@ -850,13 +857,14 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_c_kernel(
     float *__restrict__ dY) {
   const int ch = blockIdx.y, bi = blockIdx.z;
   const unsigned En = (unsigned)n_act[bi];
-  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
-  if (e0 >= En) return;
+  if (blockIdx.x * (unsigned)BNB_CHUNK >= En) return;
   const size_t row = ((size_t)bi * c + ch) * E, grow = ((size_t)bi * c + ch) * (size_t)P;
   const int *cent = cent_all + (size_t)bi * E, *sg = seg_all + (size_t)bi * (P + 1);
   const float *mult = mult_all + (size_t)bi * E;
   const float sc = scale[ch], sh = shift[ch], mu = mean[ch], is = invstd[ch];
   const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
+  for (unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK; e0 < En; e0 += gridDim.x * (unsigned)BNB_CHUNK) {
+  const unsigned e1 = min(En, e0 + (unsigned)BNB_CHUNK);
   unsigned es = e0;
   if (!TOP && (E & 3) == 0 && e1 - e0 >= 4) {   // float4 per lane, loads batched (see the statistics kernel)
     constexpr int ITERS = BNB_CHUNK / 4 / BNB_THREADS;
@@ -890,6 +898,7 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_apply_c_kernel(
     const float g = upstream_grad_c<TOP>(dA, dOut, arg, cent, sg, row, grow, e);
     const float dz = (yv * sc + sh > 0.f) ? g : 0.f;
     dY[row + e] = sc * (dz - mult[e] * (m1 + (yv - mu) * is * m2));
+  }
   }
 }
 
@@ -931,12 +940,13 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_sweep_c_kernel(
     float *__restrict__ dY) {
   const int ch = blockIdx.y, bi = blockIdx.z;
   const unsigned En = (unsigned)n_act[bi];
-  const unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK, e1 = min(En, e0 + (unsigned)BNB_CHUNK);
-  if (e0 >= En) return;
+  if (blockIdx.x * (unsigned)BNB_CHUNK >= En) return;
   const size_t row = ((size_t)bi * c + ch) * E;
   const float *mult = mult_all + (size_t)bi * E;
   const float sc = scale[ch], mu = mean[ch], is = invstd[ch];
   const float m1 = (float)(s1[ch] / count), m2 = (float)(s2[ch] / count);
+  for (unsigned e0 = blockIdx.x * (unsigned)BNB_CHUNK; e0 < En; e0 += gridDim.x * (unsigned)BNB_CHUNK) {
+  const unsigned e1 = min(En, e0 + (unsigned)BNB_CHUNK);
   unsigned es = e0;
   if ((E & 3) == 0 && e1 - e0 >= 4) {   // float4 per lane, loads batched (see the statistics kernel)
     constexpr int ITERS = BNB_CHUNK / 4 / BNB_THREADS;
@@ -961,6 +971,7 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_sweep_c_kernel(
   }
   for (unsigned e = es + threadIdx.x; e < e1; e += BNB_THREADS)
     dY[row + e] = -sc * mult[e] * (m1 + (y[row + e] - mu) * is * m2);
+  }
 }
 
 __global__ __launch_bounds__(BNB_THREADS) void bn_relu_bwd_top_fix_c_kernel(
@@ -1699,7 +1710,9 @@ extern "C" int sig3d_bn_relu_bwd_compact(int b, int c, long e, int p, const floa
   if (int rc = zero_pair(s1, s2, c, accumulate, stream)) return rc;
   if (b == 0 || e == 0) return 0;
   const double count = (double)b * (double)e;  // the statistics are over ALL columns, padded ones included
-  dim3 grid((unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK), c, b);
+  // compact rows are mostly empty behind n_act[b]: BNB_CGRID workgroups per row, each walking chunks (kernels above)
+  const unsigned chunks = (unsigned)((e + BNB_CHUNK - 1) / BNB_CHUNK);
+  dim3 grid(chunks < (unsigned)BNB_CGRID ? chunks : (unsigned)BNB_CGRID, c, b);
   if (dA) {
     hipLaunchKernelGGL((bn_relu_bwd_stats_c_kernel<false>), grid, dim3(BNB_THREADS), 0, stream, c, e, p, dA, dOut, arg,
                        y, scale, shift, mean, invstd, n_act, centre_of, seg_off, s1, s2);
