@@ -229,6 +229,11 @@ int sig3d_transpose_cn(int b, int c, int n, const float *in, float *out, void *s
 int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total,
                                     int c_off, const float *grad_out, const int *idx,
                                     float *grad_features_pm, void *stream);
+/* _z: grad_features_pm arrives ZEROED (a slice of the region a training step clears with one fill,
+ * situation3d_amd/scratch.py) and is not cleared here. */
+int sig3d_query_group_fused_grad_pm_z(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                      int c_off, const float *grad_out, const int *idx,
+                                      float *grad_features_pm, void *stream);
 
 /* Backward of the feature half of sig3d_query_group_fused: grad_out (b,c_total,m,nsample)
  * with channel offset c_off -> grad_features (b,c,n) (zeroed here). */
@@ -605,6 +610,15 @@ int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_se
                         const float *out, const float *lse, const float *grad_out,
                         float *dq, float *dk, float *dv, float p_drop, unsigned call_id,
                         const unsigned *rng_counter, void *stream);
+/* _z: dq arrives ZEROED (few queries, many keys: the key range is split over workgroups and dq is accumulated with
+ * float atomics; sig3d_attention_bwd clears it with a memset of its own, this one does not). */
+int sig3d_attention_bwd_z(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                          int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv, float scale,
+                          const float *q,
+                          const float *k, const float *v, const float *mask,
+                          const float *out, const float *lse, const float *grad_out,
+                          float *dq, float *dk, float *dv, float p_drop, unsigned call_id,
+                          const unsigned *rng_counter, void *stream);
 
 /* ---- small dense layers around the Q-Former as single launches (csrc/small_mlp.hip) ----------------------
  * The positional MLP of the scene tokens (situation3d/models/sqa_module.py:274-278, applied at :319-321):
@@ -618,6 +632,9 @@ int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const float *x, cons
                       const float *w2, const float *b2, const float *residual, float *pre, float *out, void *stream);
 int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
                       const float *dy, float *dpre, float *grads, void *stream);
+/* _z: grads arrives ZEROED and is accumulated into (no memset here). */
+int sig3d_pos_mlp_bwd_z(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
+                        const float *dy, float *dpre, float *grads, void *stream);
 
 /* ---- compact mode: set abstraction over the DISTINCT neighbours only ------------------------------------
  * ball_query pads a short list by repeating its first hit (ball_query_gpu.cu:30-40); every padded entry is
@@ -666,6 +683,15 @@ int sig3d_mlp_layer0_gather_dw(int b, int n, int m, int nsample, int c, int cout
 int sig3d_mlp_layer0_scatter_dx(int b, int n, int m, int nsample, int c, int cout, const int *idx,
                                 const float *dY, const float *wt, float *grad_features_pm,
                                 const int *n_act, void *stream);
+/* The same with the forward layer's weight AS STORED, w (cout, 3 + c): staged transposed inside the kernel. */
+int sig3d_mlp_layer0_scatter_dx_w(int b, int n, int m, int nsample, int c, int cout, const int *idx,
+                                const float *dY, const float *w, float *grad_features_pm,
+                                const int *n_act, void *stream);
+/* Input gradient of a SharedMLP layer (pytorch_utils.py:11-36: Conv2d 1x1 backward): dA (b, cin, e) = W^T dY with
+ * W (cout, cin) as the forward layer stores it -- the weight tile is staged transposed, no W^T copy.  n_act: the
+ * compact lists' live counts (first n_act[b] positions of every row), or NULL for dense rows. */
+int sig3d_mlp_layer_dx(int b, int cin, int cout, long e, const float *dY, const float *w, float *dA,
+                       const int *n_act, void *stream);
 
 /* point_major != 0: grad (b,n,ld); else grad (b,c,n); zeroed here */
 int sig3d_query_group_compact_grad(int b, int n, int m, int c, int ld, int nsample, int c_total, int c_off,

@@ -35,6 +35,8 @@ SIGNATURES = {
     "sig3d_mlp_layer0_gather_fwd": [_I, _I, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "sig3d_mlp_layer0_gather_dw": [_I, _I, _I, _I, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer0_scatter_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer0_scatter_dx_w": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer_dx": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
     "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],
@@ -51,6 +53,7 @@ SIGNATURES = {
     "sig3d_query_group_fused": [_I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused_pm": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "sig3d_query_group_fused_grad_pm": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "sig3d_query_group_fused_grad_pm_z": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_transpose_cn": [_I, _I, _I, _P, _P, _P],
     "sig3d_query_group_fused_grad": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -61,6 +64,7 @@ SIGNATURES = {
     "sig3d_sa_first_layer_dw": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_pos_mlp_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_pos_mlp_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_pos_mlp_bwd_z": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_bn_relu_maxpool_pm": [_I, _I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_channel_stats": [_I, _I, ctypes.c_long, _P, _P, _P, _I, _P],
     "sig3d_bn_relu_apply": [_I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
@@ -107,6 +111,8 @@ SIGNATURES = {
                             ctypes.c_uint, _P, _I, _P, _P],
     "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                             _F, ctypes.c_uint, _P, _P],
+    "sig3d_attention_bwd_z": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                              _F, ctypes.c_uint, _P, _P],
 }
 
 

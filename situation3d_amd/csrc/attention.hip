@@ -1020,13 +1020,14 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   return 0;
 }
 
-extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
-                                   int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
-                                   float scale, const float *q, const float *k, const float *v,
-                                   const float *mask, const float *out, const float *lse,
-                                   const float *grad_out, float *dq, float *dk, float *dv,
-                                   float p_drop, unsigned call_id, const unsigned *rng_counter,
-                                   void *stream_) {
+// dq_zeroed: the caller hands over dq rows that are zero already (sig3d_attention_bwd_z)
+static int attention_bwd_impl(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                              int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
+                              float scale, const float *q, const float *k, const float *v,
+                              const float *mask, const float *out, const float *lse,
+                              const float *grad_out, float *dq, float *dk, float *dv,
+                              float p_drop, unsigned call_id, const unsigned *rng_counter,
+                              bool dq_zeroed, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dropout probability must be in [0, 1)");
   SIG3D_REQUIRE(b >= 0 && h >= 0 && nq >= 0 && nk >= 0, "negative size");
@@ -1053,7 +1054,7 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
   splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
   SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
                 "row strides must be >= h*d and multiples of 4 floats");
-  if (splits > 1)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
+  if (splits > 1 && !dq_zeroed)  // dq is accumulated with atomics across key splits: zero its (possibly strided) rows
   {
     const int q_extent = (q_seg > 0 && q_seg < nq) ? q_base2 + b * (nq - q_seg) : b * nq;
     SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * d,
@@ -1099,4 +1100,28 @@ extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_se
 #undef SIG3D_ATT_BWD
   SIG3D_LAUNCH_CHECK("attention_bwd_kernel");
   return 0;
+}
+
+extern "C" int sig3d_attention_bwd(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                                   int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
+                                   float scale, const float *q, const float *k, const float *v,
+                                   const float *mask, const float *out, const float *lse,
+                                   const float *grad_out, float *dq, float *dk, float *dv,
+                                   float p_drop, unsigned call_id, const unsigned *rng_counter,
+                                   void *stream_) {
+  return attention_bwd_impl(b, h, nq, nk, d, q_seg, k_seg, q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, q, k, v,
+                            mask, out, lse, grad_out, dq, dk, dv, p_drop, call_id, rng_counter, false, stream_);
+}
+
+// Same, for a dq whose rows the caller has ZEROED (one fill per step for all such buffers: scratch.py): when the keys
+// are split over workgroups dq is accumulated with atomics and this entry point does not clear it first.
+extern "C" int sig3d_attention_bwd_z(int b, int h, int nq, int nk, int d, int q_seg, int k_seg, int q_base2,
+                                     int k_base2, int q_rows, int k_rows, int ldq, int ldk, int ldv,
+                                     float scale, const float *q, const float *k, const float *v,
+                                     const float *mask, const float *out, const float *lse,
+                                     const float *grad_out, float *dq, float *dk, float *dv,
+                                     float p_drop, unsigned call_id, const unsigned *rng_counter,
+                                     void *stream_) {
+  return attention_bwd_impl(b, h, nq, nk, d, q_seg, k_seg, q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, q, k, v,
+                            mask, out, lse, grad_out, dq, dk, dv, p_drop, call_id, rng_counter, true, stream_);
 }

@@ -602,14 +602,14 @@ extern "C" int sig3d_query_group_compact(int b, int n, int m, int c, int ld, int
 
 static int launch_group_grad_pm(int b, int n, int m, int c, int ld, int nsample, int c_total, int c_off,
                                 const float *grad_out, const int *idx, float *grad_features_pm,
-                                const int *n_act, void *stream_) {
+                                const int *n_act, void *stream_, bool zeroed = false) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && c >= 1 && n >= 0 && m >= 0 && nsample >= 0 && ld >= c, "bad size");
   SIG3D_REQUIRE(c_off >= 0 && c_off + c <= c_total, "channel window out of range");
   const long total = (long)m * nsample;
   SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
   if (b == 0 || n == 0) return 0;
-  SIG3D_HIP_TRY(hipMemsetAsync(grad_features_pm, 0, sizeof(float) * (size_t)b * n * ld, stream));
+  if (!zeroed) SIG3D_HIP_TRY(hipMemsetAsync(grad_features_pm, 0, sizeof(float) * (size_t)b * n * ld, stream));
   if (total == 0) return 0;
   dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
   hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, c, ld, (int)total, c_total,
@@ -623,6 +623,14 @@ extern "C" int sig3d_query_group_fused_grad_pm(int b, int n, int m, int c, int l
                                                float *grad_features_pm, void *stream_) {
   return launch_group_grad_pm(b, n, m, c, ld, nsample, c_total, c_off, grad_out, idx, grad_features_pm, nullptr,
                               stream_);
+}
+
+// grad_features_pm zeroed by the caller (scratch.py: one fill per step)
+extern "C" int sig3d_query_group_fused_grad_pm_z(int b, int n, int m, int c, int ld, int nsample, int c_total,
+                                                 int c_off, const float *grad_out, const int *idx,
+                                                 float *grad_features_pm, void *stream_) {
+  return launch_group_grad_pm(b, n, m, c, ld, nsample, c_total, c_off, grad_out, idx, grad_features_pm, nullptr,
+                              stream_, true);
 }
 
 // compact mode: grad_out holds one (duplicate-summed) gradient column per distinct neighbour.

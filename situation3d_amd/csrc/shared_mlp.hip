@@ -95,7 +95,7 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq,
-    const int *__restrict__ n_act, const float *__restrict__ mult, MlpGather ga) {
+    const int *__restrict__ n_act, const float *__restrict__ mult, MlpGather ga, int w_t) {
   // Compact mode (n_act given, compact.hip): only the first n_act[b] positions of every row exist -- the
   // distinct neighbours -- and position u stands for mult[b][u] equal columns: the statistics are weighted.
   // E stays the row stride; En is the number of positions.
@@ -120,6 +120,21 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   ML_MARK(0);
   // weight tile -> LDS: a wave takes 8 rows at a time and issues their (clamped, unconditional)
   // loads together; one load -> wait -> ds_write per element took 20 us per workgroup at 128x128
+  // w_t: the operand is the TRANSPOSE of the stored matrix -- an input-gradient product dA = W^T dY reads the forward
+  // layer's weight W (cin x cout here, row length cout) as it lies, with the lanes along its rows (no W^T copy per step)
+  if (w_t) {
+    for (int c0 = wave * 8; c0 < kpad; c0 += ML_WAVES * 8) {
+      for (int r = lane; r < CT; r += 64) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = w[(size_t)min(c0 + j, cin - 1) * cout + min(co0 + r, cout - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c0 + j < kpad) s_w[r * ldw + c0 + j] = (c0 + j < cin && co0 + r < cout) ? v[j] : 0.f;
+      }
+    }
+  } else
   for (int r0 = wave * 8; r0 < CT; r0 += ML_WAVES * 8) {
     for (int c = lane; c < kpad; c += 64) {
       float v[8];
@@ -1297,6 +1312,7 @@ static thread_local const int *tl_n_act = nullptr;
 static thread_local const float *tl_mult = nullptr;
 
 static thread_local const MlpGather *tl_gather = nullptr;
+static thread_local int tl_w_t = 0;   // the weight operand of the call in flight is given transposed (sig3d_mlp_layer_dx)
 
 template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER = false>
 static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, const float *w,
@@ -1327,7 +1343,7 @@ static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, co
   dim3 grid(cblocks, (unsigned)gy, b);
   hipLaunchKernelGGL((mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER, SCATTER>), grid, dim3(ML_WAVES * 64), lds, stream,
                      cin, cout, e, tpw, x, w, pscale, pshift, y, stat_sum, stat_sq, tl_n_act, tl_mult,
-                     tl_gather ? *tl_gather : MlpGather{});
+                     tl_gather ? *tl_gather : MlpGather{}, (GATHER ? 0 : tl_w_t));
   SIG3D_LAUNCH_CHECK("mlp_layer_fwd_kernel");
   return 0;
 }
@@ -1630,6 +1646,29 @@ extern "C" int sig3d_mlp_layer0_scatter_dx(int b, int n, int m, int nsample, int
                                      nullptr, nullptr, 0, stream_);
   tl_gather = nullptr;
   tl_n_act = nullptr;
+  return rc;
+}
+
+// Input gradient of a layer: dA (b, cin, e) = W^T dY with W (cout, cin) AS STORED by the forward layer (the kernel
+// stages it transposed; rounds 1-3 made a W^T copy per layer per step).  n_act: compact lists, or NULL.
+extern "C" int sig3d_mlp_layer_dx(int b, int cin, int cout, long e, const float *dY, const float *w, float *dA,
+                                  const int *n_act, void *stream_) {
+  SIG3D_REQUIRE(dY && w && dA, "null operand");
+  tl_n_act = n_act;
+  tl_w_t = 1;
+  const int rc = sig3d_mlp_layer_fwd(b, cout, cin, e, dY, w, nullptr, nullptr, dA, nullptr, nullptr, 0, stream_);
+  tl_w_t = 0;
+  tl_n_act = nullptr;
+  return rc;
+}
+
+// sig3d_mlp_layer0_scatter_dx with the weight as stored, w (cout, 3 + c)
+extern "C" int sig3d_mlp_layer0_scatter_dx_w(int b, int n, int m, int nsample, int c, int cout, const int *idx,
+                                             const float *dY, const float *w, float *grad_features_pm,
+                                             const int *n_act, void *stream_) {
+  tl_w_t = 1;
+  const int rc = sig3d_mlp_layer0_scatter_dx(b, n, m, nsample, c, cout, idx, dY, w, grad_features_pm, n_act, stream_);
+  tl_w_t = 0;
   return rc;
 }
 

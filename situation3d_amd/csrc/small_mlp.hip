@@ -257,15 +257,16 @@ extern "C" int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const flo
   return 0;
 }
 
-extern "C" int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
-                                 const float *dy, float *dpre, float *grads, void *stream_) {
+static int pos_mlp_bwd_impl(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
+                            const float *dy, float *dpre, float *grads, bool grads_zeroed, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(rows >= 0 && cin >= 1 && cin <= PE_MAXCIN && hid >= 4 && hid <= PE_MAXHID && hid % 4 == 0 && cout >= 4 &&
                     cout % 4 == 0, "pos_mlp: 1 <= cin <= 4, hid <= 128, hid and cout multiples of 4");
   SIG3D_REQUIRE(x && w2 && pre && dy && dpre && grads, "null argument");
   // grads = [dw1 (hid*cin) | db1 (hid) | dw2 (cout*hid) | db2 (cout)]: one buffer, one memset node
   float *dw1 = grads, *db1 = dw1 + (size_t)hid * cin, *dw2 = db1 + hid, *db2 = dw2 + (size_t)cout * hid;
-  SIG3D_HIP_TRY(hipMemsetAsync(grads, 0, sizeof(float) * ((size_t)hid * cin + hid + (size_t)cout * hid + cout), stream));
+  if (!grads_zeroed)
+    SIG3D_HIP_TRY(hipMemsetAsync(grads, 0, sizeof(float) * ((size_t)hid * cin + hid + (size_t)cout * hid + cout), stream));
   if (rows == 0) return 0;
   const size_t lds = sizeof(float) * 2 * SG_K * SG_LD;
   SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)pos_mlp_bwd_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -276,4 +277,15 @@ extern "C" int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const flo
                      dim3(256), lds, stream, rows, hid, cout, pre, dy, dw2, db2);
   SIG3D_LAUNCH_CHECK("pos_mlp_bwd kernels");
   return 0;
+}
+
+extern "C" int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
+                                 const float *dy, float *dpre, float *grads, void *stream_) {
+  return pos_mlp_bwd_impl(rows, cin, hid, cout, x, w2, pre, dy, dpre, grads, false, stream_);
+}
+
+// grads zeroed by the caller (scratch.py: one fill per step)
+extern "C" int sig3d_pos_mlp_bwd_z(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
+                                   const float *dy, float *dpre, float *grads, void *stream_) {
+  return pos_mlp_bwd_impl(rows, cin, hid, cout, x, w2, pre, dy, dpre, grads, true, stream_);
 }

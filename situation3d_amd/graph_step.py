@@ -38,6 +38,7 @@ import torch.nn as nn
 
 from . import gemm_tuning, timeline
 from .geometry import Announced, GeometryPipeline, GeometryPlan  # noqa: F401  (Announced: re-exported)
+from .scratch import STEP_ZEROS
 from .trainer import get_loss
 
 
@@ -149,13 +150,18 @@ class GraphedTrainStep:
             batch = dict(self.static_batch)
             if self.prefetch:
                 batch["geometry_plan"] = self.plan_cur
-            out = model(batch)
-            loss, out = get_loss(out)
-            self.static_out = out  # answer_scores, aux_scores, ... of the last replay
-            loss.backward()
-            _flush_deferred(model)
-            if reducer is not None and fused_opt:
-                optimizer.gather_grads()  # scattered grads -> the flat buffers the reducer owns
+            # every zero-initialised accumulator of the step: slices of one region, one fill node (scratch.py)
+            STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=fused_opt)
+            try:
+                out = model(batch)
+                loss, out = get_loss(out)
+                self.static_out = out  # answer_scores, aux_scores, ... of the last replay
+                loss.backward()
+                _flush_deferred(model)
+                if reducer is not None and fused_opt:
+                    optimizer.gather_grads()  # scattered grads -> the flat buffers the reducer owns
+            finally:
+                STEP_ZEROS.end_step()
             return loss
 
         def fwd_bwd_head():
@@ -166,6 +172,7 @@ class GraphedTrainStep:
             batch["_qf_cut"] = self._qf_cut
             if self.prefetch:
                 batch["geometry_plan"] = self.plan_cur
+            STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)   # closed by bwd_encoder()
             out = model(batch)
             self._boundary = out.pop("_boundary")
             self._qf_boundary = out.pop("_qf_boundary", None)
@@ -194,6 +201,7 @@ class GraphedTrainStep:
             tokens.backward(leaf.grad)
             optimizer.gather_grads(slot=2, zero=False)
             self._boundary = None
+            STEP_ZEROS.end_step()
 
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
         # data parallel + flat storage: AdamW runs bucket by bucket behind that bucket's all-reduce

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, scratch
 
 
 def _layers(mlp):
@@ -209,7 +209,7 @@ class _FusedMLPMax(torch.autograd.Function):
         cmax = max(conv.out_channels for conv, _ in layers)
         with torch.cuda.device(dev):
             # all statistic accumulators of the stack are zeroed by ONE fill (accumulate = 1 below)
-            st_all = torch.zeros((len(layers), 2, cmax), dtype=torch.float64, device=dev)
+            st_all = scratch.zeros((len(layers), 2, cmax), torch.float64, dev)
             for i, (conv, bn) in enumerate(layers):
                 w = flat[3 * i].reshape(conv.out_channels, conv.in_channels).contiguous()
                 gamma, beta = flat[3 * i + 1], flat[3 * i + 2]
@@ -340,9 +340,15 @@ class _FusedMLPMax(torch.autograd.Function):
             # one fill each for every BatchNorm-gradient accumulator and every dW of the stack
             cmax = max(w.shape[0] for w in ws)
             n_dw = sum(w.numel() for w in ws)
-            zeros = torch.zeros(nl * 2 * cmax * 8 + n_dw * 4, dtype=torch.uint8, device=dev)
-            sums_all = zeros[:nl * 2 * cmax * 8].view(torch.float64).view(nl, 2, cmax)
-            dw_all = zeros[nl * 2 * cmax * 8:].view(torch.float32)
+            # (slices of the step's zeroed region when a step is open -- scratch.py; the dW slices become `.grad`s,
+            # so they only come from there when the optimizer consumes the gradients inside the step)
+            if scratch.STEP_ZEROS.grads_ok:
+                zeros = scratch.zeros(nl * 2 * cmax * 8 + n_dw * 4, torch.uint8, dev)
+                sums_all = zeros[:nl * 2 * cmax * 8].view(torch.float64).view(nl, 2, cmax)
+                dw_all = zeros[nl * 2 * cmax * 8:].view(torch.float32)
+            else:
+                sums_all = scratch.zeros((nl, 2, cmax), torch.float64, dev)
+                dw_all = torch.zeros(n_dw, dtype=torch.float32, device=dev)
             dw_off = 0
             for k in range(nl - 1, -1, -1):
                 cout, cin = ws[k].shape
@@ -401,10 +407,9 @@ class _FusedMLPMax(torch.autograd.Function):
                     pass          # the raw scan is not differentiable
                 elif k == 0 and regroup is not None:
                     if ctx.needs_input_grad[0]:
-                        wt = ws[0].t().contiguous()
                         dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
-                        _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt), _lib.ptr(None),
-                                  _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None), _lib.ptr(None), 0, stream)
+                        _lib.call("sig3d_mlp_layer_dx", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(ws[0]), _lib.ptr(dA),
+                                  _lib.ptr(None), stream)
                         grad_pm = torch.empty((b, n_src, c_src), dtype=torch.float32, device=dev)
                         _lib.call("sig3d_query_group_fused_grad_pm", b, n_src, p, c_src, c_src, s, cin, 3,
                                   _lib.ptr(dA), _lib.ptr(g_idx), _lib.ptr(grad_pm), stream)
@@ -416,10 +421,9 @@ class _FusedMLPMax(torch.autograd.Function):
                 elif k == 0 and gather is not None:
                     if ctx.needs_input_grad[0]:
                         # W^T dY added straight into the point-major feature gradient at the neighbours' rows
-                        wt = ws[0].t().contiguous()
-                        grad_pm = torch.zeros((b, n_src, c_src), dtype=torch.float32, device=dev)
-                        _lib.call("sig3d_mlp_layer0_scatter_dx", b, n_src, p, s, c_src, cout, _lib.ptr(g_idx),
-                                  _lib.ptr(dY), _lib.ptr(wt), _lib.ptr(grad_pm),
+                        grad_pm = scratch.zeros((b, n_src, c_src), torch.float32, dev)
+                        _lib.call("sig3d_mlp_layer0_scatter_dx_w", b, n_src, p, s, c_src, cout, _lib.ptr(g_idx),
+                                  _lib.ptr(dY), _lib.ptr(ws[0]), _lib.ptr(grad_pm),
                                   _lib.ptr(c_nact if compact is not None else None), stream)
                         if ctx.x_is_pm:
                             grad_x = grad_pm
@@ -430,16 +434,10 @@ class _FusedMLPMax(torch.autograd.Function):
                     if ctx.library_gemm:
                         dA = torch.bmm(ws[k].t().unsqueeze(0).expand(b, cin, cout), dY.view(b, cout, e)).view(b, cin, p, s)
                     else:
-                        wt = ws[k].t().contiguous()  # (cin, cout): dA = W^T dY through the same GEMM
+                        # dA = W^T dY through the forward kernel, the weight staged transposed (no W^T copy)
                         dA = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
-                        if compact is not None:
-                            _lib.call("sig3d_mlp_layer_fwd_compact", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
-                                      _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
-                                      _lib.ptr(None), 0, _lib.ptr(c_nact), _lib.ptr(None), stream)
-                        else:
-                            _lib.call("sig3d_mlp_layer_fwd", b, cout, cin, e, _lib.ptr(dY), _lib.ptr(wt),
-                                      _lib.ptr(None), _lib.ptr(None), _lib.ptr(dA), _lib.ptr(None),
-                                      _lib.ptr(None), 0, stream)   # no statistics for an input gradient
+                        _lib.call("sig3d_mlp_layer_dx", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(ws[k]), _lib.ptr(dA),
+                                  _lib.ptr(c_nact if compact is not None else None), stream)
                     if k == 0:
                         grad_x = dA
             sums32 = sums_all.to(torch.float32)                # one conversion launch for the whole stack

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .. import _lib
+from .. import _lib, scratch
 from . import _ext
 
 
@@ -191,9 +191,9 @@ class _QueryGroupFused(Function):
             if c > 0 and ctx.needs_input_grad[7]:
                 grad_out = grad_out.contiguous()
                 dev = grad_out.device
-                grad_pm = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+                grad_pm = scratch.zeros((b, n, c), torch.float32, dev)      # the step's one fill (scratch.py)
                 with torch.cuda.device(dev):
-                    _lib.call("sig3d_query_group_fused_grad_pm", b, n, m, c, c, nsample, c_total, c_off,
+                    _lib.call("sig3d_query_group_fused_grad_pm_z", b, n, m, c, c, nsample, c_total, c_off,
                               _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_pm), _lib.stream_ptr(dev))
             return None, None, None, None, None, None, None, grad_pm
         if c > 0 and ctx.needs_input_grad[2]:

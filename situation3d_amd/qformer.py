@@ -32,7 +32,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, scratch
 
 
 class QFormerConfig:
@@ -552,7 +552,10 @@ class _WeightGradArena:
         if nc:
             nrow_e, cenc = enc2.shape
             self.sa_out, self.att_x = e(nc, rows, H), e(nc, rq, H)
-            self.dyo_x, self.dq_x = e(nc, rq, H), e(nc, rq, H)
+            self.dyo_x = e(nc, rq, H)
+            # dQ of the cross-attention blocks: few queries against many keys -> the backward splits the keys over
+            # workgroups and accumulates dQ with atomics; zeroed once for all blocks (sig3d_attention_bwd_z)
+            self.dq_x = scratch.zeros((nc, rq, H), torch.float32, dev)
             self.kv, self.dkv = e(nrow_e, nc * 2 * H), e(nrow_e, nc * 2 * H)
             xs = [layers[i].crossattention for i in self.cross]
             self.gwq_x = res([x.self.query.weight for x in xs], nc, H, H)
@@ -896,7 +899,8 @@ class _AttentionBlockFn(torch.autograd.Function):
             qp, kp, vp = _off(proj, 0), _off(arena.kv, j * 2 * hd), _off(arena.kv, j * 2 * hd + hd)
             dqp, dkp, dvp = _off(dproj, 0), _off(arena.dkv, j * 2 * hd), _off(arena.dkv, j * 2 * hd + hd)
         with torch.cuda.device(dev):
-            _lib.call("sig3d_attention_bwd", b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], live, klay[2],
+            _lib.call("sig3d_attention_bwd" if (self_attn or arena is None) else "sig3d_attention_bwd_z",
+                      b, num_heads, nq, nk, d, seg, klay[0], base2, klay[1], live, klay[2],
                       ldq, ldk, ldv, ctypes.c_float(scale), qp, kp, vp, _lib.ptr(mask), _lib.ptr(att), _lib.ptr(lse),
                       _lib.ptr(datt), dqp, dkp, dvp, ctypes.c_float(p_attn), ctypes.c_uint(id_attn),
                       _lib.ptr(_rng_counter(dev)), _lib.stream_ptr(dev))

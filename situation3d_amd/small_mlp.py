@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, scratch
 
 # SIG3D_SMALL_MLP=0: the torch modules (A/B timing; same results up to f32 summation order)
 ENABLED = os.environ.get("SIG3D_SMALL_MLP", "1") != "0"
@@ -38,9 +38,13 @@ class _PosMLPFn(torch.autograd.Function):
         dev = x.device
         dy = dy.contiguous()
         dpre = torch.empty((rows, hid), dtype=torch.float32, device=dev)
-        grads = torch.empty(hid * cin + hid + cout * hid + cout, dtype=torch.float32, device=dev)
+        n_grads = hid * cin + hid + cout * hid + cout
+        if scratch.STEP_ZEROS.grads_ok:     # zeroed with the step's one fill (the slices become `.grad`s: scratch.py)
+            grads, entry = scratch.zeros(n_grads, torch.float32, dev), "sig3d_pos_mlp_bwd_z"
+        else:
+            grads, entry = torch.empty(n_grads, dtype=torch.float32, device=dev), "sig3d_pos_mlp_bwd"
         with torch.cuda.device(dev):
-            _lib.call("sig3d_pos_mlp_bwd", rows, cin, hid, cout, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(pre), _lib.ptr(dy),
+            _lib.call(entry, rows, cin, hid, cout, _lib.ptr(x), _lib.ptr(w2), _lib.ptr(pre), _lib.ptr(dy),
                       _lib.ptr(dpre), _lib.ptr(grads), _lib.stream_ptr(dev))
         o = 0
         dw1 = grads[o:o + hid * cin].view(hid, cin); o += hid * cin

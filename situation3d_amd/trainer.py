@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .scratch import STEP_ZEROS
+
 LOSS_W = dict(SITUATION_W=0.1, QA_W=0.1, SITUATION_POS_W=1.0, SITUATION_ROT_W=1.0)
 
 
@@ -150,17 +152,23 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
         reducer.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=False)
-    data_dict = model(data_dict)
-    loss, data_dict = get_loss(data_dict)
-    loss.backward()
-    enc = getattr(getattr(getattr(model, "Qformer", None), "bert", None), "encoder", None)
-    if enc is not None and hasattr(enc, "flush_weight_grads"):
-        enc.flush_weight_grads()   # deferred, layer-batched weight gradients (qformer._WeightGradArena)
-    if reducer is not None:
-        if fused:
-            optimizer.gather_grads()  # scattered grads -> flat buffers (reducer.from_flat slices)
-        reducer.finish()
-    if not fused and max_grad_value is not None and max_grad_value > 0:
-        nn.utils.clip_grad_value_(model.parameters(), clip_value=max_grad_value)
-    optimizer.step()  # FlatAdamW: clip + update + zero_grad in one kernel per group
+    pc = data_dict.get("point_clouds")
+    # every zero-initialised accumulator of the step comes out of one region cleared by one fill (scratch.py)
+    STEP_ZEROS.begin_step(pc.device if torch.is_tensor(pc) else "cpu", grads_ok=fused)
+    try:
+        data_dict = model(data_dict)
+        loss, data_dict = get_loss(data_dict)
+        loss.backward()
+        enc = getattr(getattr(getattr(model, "Qformer", None), "bert", None), "encoder", None)
+        if enc is not None and hasattr(enc, "flush_weight_grads"):
+            enc.flush_weight_grads()   # deferred, layer-batched weight gradients (qformer._WeightGradArena)
+        if reducer is not None:
+            if fused:
+                optimizer.gather_grads()  # scattered grads -> flat buffers (reducer.from_flat slices)
+            reducer.finish()
+        if not fused and max_grad_value is not None and max_grad_value > 0:
+            nn.utils.clip_grad_value_(model.parameters(), clip_value=max_grad_value)
+        optimizer.step()  # FlatAdamW: clip + update + zero_grad in one kernel per group
+    finally:
+        STEP_ZEROS.end_step()
     return loss
