@@ -636,6 +636,30 @@ int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, cons
 int sig3d_pos_mlp_bwd_z(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
                         const float *dy, float *dpre, float *grads, void *stream);
 
+/* ---- the two MLP heads on the pooled Q-Former output (csrc/heads.hip) ----------------------------------------
+ * situation3d/models/sqa_module.py: the fused query tokens are averaged per sample and feed
+ *   aux    (b, n_aux) = Linear(hidden, n_aux)(GELU(Linear(hidden, hidden)(pooled)))             [w1a b1a w2a b2a]
+ *   answer (b, n_ans) = Linear(hidden, n_ans)(Dropout(GELU(Linear(hidden, hidden)(pooled))))    [w1c b1c w2c b2c]
+ * b <= 16 samples, hidden % 16 == 0, hidden <= 1024.  rows (b * q, hidden): the q query rows of sample i are rows
+ * [i*q, (i+1)*q).  Outputs of the forward that the backward needs: pooled (b, hidden), pre (2, b, hidden) first-layer
+ * pre-activations [aux | answer], h (2, b, hidden) second-layer inputs (the answer head's after dropout).
+ * Dropout keep bits: hash(*rng_counter, call_id, element), as in sig3d_dropout_add_ln_fwd; p_drop == 0 in eval mode.
+ * _bwd: daux (b, n_aux), dans (b, n_ans) -> grads = ONE buffer
+ *   [dw1a (hidden^2) | db1a (hidden) | dw2a (n_aux*hidden) | db2a (n_aux) | dw1c | db1c | dw2c (n_ans*hidden) | db2c]
+ * and drows (b * q, hidden) = d pooled / q in every query row; all OVERWRITTEN; work: sig3d_pooled_heads_work_floats(b,
+ * hidden) floats of scratch (partial input gradients of the four layers).  n_aux, n_ans <= 1024.
+ * Three launches forward, three backward; sums in fixed orders (no atomics). */
+int sig3d_pooled_heads_fwd(int b, int q, int hidden, int n_aux, int n_ans, const float *rows,
+                           const float *w1a, const float *b1a, const float *w2a, const float *b2a,
+                           const float *w1c, const float *b1c, const float *w2c, const float *b2c,
+                           float p_drop, unsigned call_id, const unsigned *rng_counter, float *pooled,
+                           float *pre, float *h, float *aux, float *ans, void *stream);
+int sig3d_pooled_heads_bwd(int b, int q, int hidden, int n_aux, int n_ans, const float *daux, const float *dans,
+                           const float *pooled, const float *pre, const float *h, const float *w1a,
+                           const float *w2a, const float *w1c, const float *w2c, float p_drop, unsigned call_id,
+                           const unsigned *rng_counter, float *work, float *grads, float *drows, void *stream);
+long sig3d_pooled_heads_work_floats(int b, int hidden);
+
 /* ---- compact mode: set abstraction over the DISTINCT neighbours only ------------------------------------
  * ball_query pads a short list by repeating its first hit (ball_query_gpu.cu:30-40); every padded entry is
  * an identical column of the grouped tensor, of each SharedMLP layer above it (pytorch_utils.py:11-36) and of

@@ -64,6 +64,9 @@ SIGNATURES = {
     "sig3d_sa_first_layer_dw": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_pos_mlp_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_pos_mlp_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_pooled_heads_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.c_uint, _P, _P, _P, _P, _P,
+                               _P, _P],
+    "sig3d_pooled_heads_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.c_uint, _P, _P, _P, _P, _P],
     "sig3d_pos_mlp_bwd_z": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_bn_relu_maxpool_pm": [_I, _I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_channel_stats": [_I, _I, ctypes.c_long, _P, _P, _P, _I, _P],
@@ -212,7 +215,7 @@ def bq_levels_workspace_bytes(batch, arr):
 
 
 INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes",
-                "sig3d_ball_query_levels_workspace_bytes")
+                "sig3d_ball_query_levels_workspace_bytes", "sig3d_pooled_heads_work_floats")
 
 _lib = None
 
@@ -242,6 +245,8 @@ def load():
     lib.sig3d_voxelize_workspace_bytes.restype = ctypes.c_long
     lib.sig3d_ball_query_levels_workspace_bytes.argtypes = [_I, _I, ctypes.POINTER(BqLevel)]
     lib.sig3d_ball_query_levels_workspace_bytes.restype = ctypes.c_long
+    lib.sig3d_pooled_heads_work_floats.argtypes = [_I, _I]
+    lib.sig3d_pooled_heads_work_floats.restype = ctypes.c_long
     _lib = lib
     return lib
 

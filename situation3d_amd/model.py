@@ -17,6 +17,7 @@ from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .qformer import init_Qformer
 from .situational import gaussian_localisation_target, situational_transform
 from .small_mlp import pos_embed_add
+from . import heads
 
 
 class PointNet2Encoder(nn.Module):
@@ -146,7 +147,15 @@ class SIG3DQFormer(nn.Module):
         if fused is None:
             fused = out.last_hidden_state[:, :query_tokens.shape[1], :]
         data_dict["att_feat_ori"] = fused
-        pooled = fused.mean(dim=1)
-        data_dict["aux_scores"] = self.aux_reg(pooled)
-        data_dict["answer_scores"] = self.answer_cls(pooled)
+        rows = getattr(out, "rows", None)      # the two-segment row matrix `fused` is a view of (qformer._SegmentedOutput)
+        if rows is None and fused.is_contiguous():
+            rows = fused.view(-1, fused.shape[-1])
+        if rows is not None and heads.covered(rows, b, fused.shape[1], self.aux_reg, self.answer_cls):
+            # mean over the query rows + both heads: three launches, two in the backward pass (csrc/heads.hip)
+            data_dict["aux_scores"], data_dict["answer_scores"] = heads.pooled_heads(rows, b, fused.shape[1], self.aux_reg,
+                                                                                    self.answer_cls)
+        else:
+            pooled = fused.mean(dim=1)
+            data_dict["aux_scores"] = self.aux_reg(pooled)
+            data_dict["answer_scores"] = self.answer_cls(pooled)
         return data_dict
