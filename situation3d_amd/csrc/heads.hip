@@ -42,10 +42,13 @@ __global__ __launch_bounds__(HD_THREADS) void pool_rows_kernel(int q, int cols, 
   const int ncol4 = cols / 4;
   const float4 *p = reinterpret_cast<const float4 *>(rows + (size_t)b * q * cols) + min(c4, ncol4 - 1);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-  for (int i = qg; i < q; i += 4) {
-    const float4 v = p[(size_t)i * ncol4];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int i0 = qg; i0 < q; i0 += 32) {   // eight requests in flight (clamped row, masked afterwards)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(i0 + 4 * u, q - 1) * ncol4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 4 * u < q) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
   }
   s_part[qg][threadIdx.x & 63] = s;
   __syncthreads();
@@ -195,7 +198,11 @@ __global__ __launch_bounds__(HD_THREADS) void rows_linear_bwd_kernel(HdBwdSeg s0
       if (s.dy) {
         v = s.dy[at];
       } else {
-        for (int pi = 0; pi < s.n_parts; ++pi) v += s.dyp[(size_t)pi * rows * s.n_out + at];
+        float t[HD_OS];   // all partials requested together (clamped, masked): a counted loop waits for each
+#pragma unroll
+        for (int pi = 0; pi < HD_OS; ++pi) t[pi] = s.dyp[(size_t)min(pi, s.n_parts - 1) * rows * s.n_out + at];
+#pragma unroll
+        for (int pi = 0; pi < HD_OS; ++pi) v += pi < s.n_parts ? t[pi] : 0.f;
         v *= hd_gelu_grad(s.pre[at]);
         if (s.act == 2 && p_drop > 0.f) {
           const unsigned seed = hd_mix32((rng_counter ? *rng_counter : 0u) * 0x9E3779B9u + s.call_id);
@@ -257,9 +264,16 @@ __global__ __launch_bounds__(HD_THREADS) void spread_pooled_grad_kernel(int rows
                                                                         float *__restrict__ drows) {
   const int i = blockIdx.x * HD_THREADS + threadIdx.x;
   if (i >= rows * k) return;
-  float v = 0.f;
-  for (int j = 0; j < n0; ++j) v += p0[(size_t)j * rows * k + i];
-  for (int j = 0; j < n1; ++j) v += p1[(size_t)j * rows * k + i];
+  float v = 0.f, t0[HD_OS], t1[HD_OS];
+#pragma unroll
+  for (int j = 0; j < HD_OS; ++j) {
+    t0[j] = p0[(size_t)min(j, n0 - 1) * rows * k + i];
+    t1[j] = p1[(size_t)min(j, n1 - 1) * rows * k + i];
+  }
+#pragma unroll
+  for (int j = 0; j < HD_OS; ++j) v += j < n0 ? t0[j] : 0.f;
+#pragma unroll
+  for (int j = 0; j < HD_OS; ++j) v += j < n1 ? t1[j] : 0.f;
   v /= (float)q;
   const int r = i / k, c = i - r * k;
   float *o = drows + (size_t)r * q * k + c;

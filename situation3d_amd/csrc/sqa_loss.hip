@@ -21,36 +21,67 @@ __device__ __forceinline__ float block_sum_256(float v, float *s_red) {
   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+constexpr int LOSS_THREADS = 1024;
+
+__device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
+  v = wave_allreduce_sum_f32(v);
+  __syncthreads();
+  if (lane_id() == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < LOSS_THREADS / 64; ++i) t += s_red[i];
+  return t;
+}
+
 // losses[5] = {loss, answer_loss, pos_loss, rot_loss, aux_loss}
-__global__ __launch_bounds__(256) void sqa_loss_kernel(int b, int num_answers, int aux_dim, int l1,
-                                                       const float *__restrict__ answer_scores,
-                                                       const float *__restrict__ answer_targets,
-                                                       const float *__restrict__ aux_scores,
-                                                       const float *__restrict__ aux_targets, float qa_w,
-                                                       float situation_w, float pos_w, float rot_w, float amplify,
-                                                       float *__restrict__ losses, float *__restrict__ d_answer,
-                                                       float *__restrict__ d_aux) {
-  __shared__ float s_red[4];
+// One workgroup of 1024 threads, four elements per thread and trip with all eight loads requested before the first is
+// used: the first version (256 threads, one element per trip) spent 22 dependent memory round trips = 17 us on 45 KB.
+__global__ __launch_bounds__(LOSS_THREADS) void sqa_loss_kernel(int b, int num_answers, int aux_dim, int l1,
+                                                                const float *__restrict__ answer_scores,
+                                                                const float *__restrict__ answer_targets,
+                                                                const float *__restrict__ aux_scores,
+                                                                const float *__restrict__ aux_targets, float qa_w,
+                                                                float situation_w, float pos_w, float rot_w, float amplify,
+                                                                float *__restrict__ losses, float *__restrict__ d_answer,
+                                                                float *__restrict__ d_aux) {
+  __shared__ float s_red[LOSS_THREADS / 64];
   const int tid = threadIdx.x;
+  // auxiliary operands first: their loads travel with the answer loop's
+  const int n_aux = b * aux_dim;
+  const float ax = tid < n_aux ? aux_scores[tid] : 0.f, at = tid < n_aux ? aux_targets[tid] : 0.f;
   // answer loss: binary_cross_entropy_with_logits(x, z, reduction='sum') / B  (loss_helper.py:222-225)
   //   l = max(x, 0) - x z + log(1 + exp(-|x|)),   dl/dx = sigmoid(x) - z
   const float ga = amplify * qa_w / (float)b;
+  const int n = b * num_answers;
   float acc = 0.f;
-  for (int i = tid; i < b * num_answers; i += 256) {
-    const float x = answer_scores[i], z = answer_targets[i];
-    acc += fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));
-    const float sg = 1.f / (1.f + __expf(-x));
-    d_answer[i] = ga * (sg - z);
+  for (int i0 = tid; i0 < n; i0 += 4 * LOSS_THREADS) {
+    float x[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * LOSS_THREADS, n - 1);
+      x[u] = answer_scores[i];
+      z[u] = answer_targets[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * LOSS_THREADS;
+      if (i < n) {
+        acc += fmaxf(x[u], 0.f) - x[u] * z[u] + log1pf(__expf(-fabsf(x[u])));
+        const float sg = 1.f / (1.f + __expf(-x[u]));
+        d_answer[i] = ga * (sg - z[u]);
+      }
+    }
   }
-  const float answer_loss = block_sum_256(acc, s_red) / (float)b;
+  const float answer_loss = block_sum_1024(acc, s_red) / (float)b;
   // auxiliary situation loss: mean over B x 3 position values and B x (aux_dim - 3) rotation values
   const int nrot = aux_dim - 3;
   const float gp = amplify * situation_w * pos_w / (float)(b * 3);
   const float gr = amplify * situation_w * rot_w / (float)(b * nrot);
   float accp = 0.f, accr = 0.f;
-  for (int i = tid; i < b * aux_dim; i += 256) {
+  for (int i = tid; i < n_aux; i += LOSS_THREADS) {
     const int c = i % aux_dim;
-    const float d = aux_scores[i] - aux_targets[i];
+    const float d = i == tid ? ax - at : aux_scores[i] - aux_targets[i];
     const bool is_pos = c < 3;
     if (l1) {
       (is_pos ? accp : accr) += fabsf(d);
@@ -61,8 +92,8 @@ __global__ __launch_bounds__(256) void sqa_loss_kernel(int b, int num_answers, i
       d_aux[i] = (is_pos ? gp : gr) * 2.f * d;
     }
   }
-  const float pos_loss = block_sum_256(accp, s_red) / (float)(b * 3);
-  const float rot_loss = block_sum_256(accr, s_red) / (float)(b * nrot);
+  const float pos_loss = block_sum_1024(accp, s_red) / (float)(b * 3);
+  const float rot_loss = block_sum_1024(accr, s_red) / (float)(b * nrot);
   if (tid == 0) {
     const float aux = pos_w * pos_loss + rot_w * rot_loss;
     losses[0] = amplify * (situation_w * aux + qa_w * answer_loss);
@@ -113,7 +144,7 @@ extern "C" int sig3d_sqa_loss(int b, int num_answers, int aux_dim, int l1, const
                               float qa_w, float situation_w, float pos_w, float rot_w, float amplify, float *losses,
                               float *d_answer, float *d_aux, void *stream_) {
   SIG3D_REQUIRE(b >= 1 && num_answers >= 1 && aux_dim >= 4, "need b >= 1, answers >= 1, aux_dim >= 4");
-  hipLaunchKernelGGL(sqa_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, b, num_answers, aux_dim, l1,
+  hipLaunchKernelGGL(sqa_loss_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream_, b, num_answers, aux_dim, l1,
                      answer_scores, answer_targets, aux_scores, aux_targets, qa_w, situation_w, pos_w, rot_w, amplify,
                      losses, d_answer, d_aux);
   SIG3D_LAUNCH_CHECK("sqa_loss_kernel");

@@ -329,7 +329,7 @@ def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monke
     assert "sig3d_mlp_layer0_gather_fwd" in calls
     if mode == "compact":   # no grouped tensor in either direction
         assert not any(nm.startswith("sig3d_query_group") for nm in calls)
-        assert "sig3d_mlp_layer0_gather_dw" in calls and "sig3d_mlp_layer0_scatter_dx" in calls
+        assert "sig3d_mlp_layer0_gather_dw" in calls and "sig3d_mlp_layer0_scatter_dx_w" in calls
     elif mode == "dense":   # forward without it; the backward re-materialises it (faster than gathering twice more)
         assert calls.index("sig3d_query_group_fused_pm") > calls.index("sig3d_bn_relu_maxpool")
     else:
