@@ -126,6 +126,9 @@ OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
 # which products (bit mask, all by default): 1 query/key/value, 2 attention output, 4 feed-forward up (+ GELU),
 # 8 feed-forward down, 16 d(feed-forward up) (* gelu'), 32 d(feed-forward down) + residual, 64 d(projections) + residual
 OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
+# SIG3D_QF_GEMM_CONFIG: which core / tiling sig3d_gemm16 uses for those products: 0 its own choice among the f32 tilings,
+# 1-3 one of them, 11 / 12 the bf16 x 6 core (gemmx6_core.h: three-term bf16 split, six products, f32-equivalent)
+OWN_CONFIG = int(os.environ.get("SIG3D_QF_GEMM_CONFIG", "0"))
 
 
 def _g16(dev, **kw):
@@ -142,11 +145,11 @@ def _dense_fwd(x2, w, bias, out=None, act=0, aux=None, split=False):
     dev = x2.device
     if out is None:
         out = torch.empty(x2.shape[:-1] + (n,), dtype=torch.float32, device=dev)
-    splits = _lib.gemm16_splits(0, batch, m, n, k, act) if split else 1
+    splits = _lib.gemm16_splits(0, batch, m, n, k, act, OWN_CONFIG) if split else 1
     slabs = torch.empty((splits - 1, batch * m, n), dtype=torch.float32, device=dev) if splits > 1 else None
     _g16(dev, A=x2, lda=k, stride_a=m * k, B=w, ldb=k, stride_b=n * k, C=out, ldc=n, stride_c=m * n, C_slabs=slabs,
          slab_stride=batch * m * n, bias=bias, stride_bias=n, aux=aux, bmode=0, batch=batch, m=m, n=n, k=k, act=act,
-         splits=splits)
+         splits=splits, config=OWN_CONFIG)
     return out, slabs
 
 
@@ -159,10 +162,11 @@ def _dense_dgrad(dy2, w, out=None, addend=None, act=0, aux=None, split=False):
     dev = dy2.device
     if out is None:
         out = torch.empty(dy2.shape[:-1] + (n,), dtype=torch.float32, device=dev)
-    splits = _lib.gemm16_splits(1, batch, m, n, k, act) if split else 1
+    splits = _lib.gemm16_splits(1, batch, m, n, k, act, OWN_CONFIG) if split else 1
     slabs = torch.empty((splits - 1, batch * m, n), dtype=torch.float32, device=dev) if splits > 1 else None
     _g16(dev, A=dy2, lda=k, stride_a=m * k, B=w, ldb=n, stride_b=n * k, C=out, ldc=n, stride_c=m * n, C_slabs=slabs,
-         slab_stride=batch * m * n, addend=addend, aux=aux, bmode=1, batch=batch, m=m, n=n, k=k, act=act, splits=splits)
+         slab_stride=batch * m * n, addend=addend, aux=aux, bmode=1, batch=batch, m=m, n=n, k=k, act=act, splits=splits,
+         config=OWN_CONFIG)
     return out, slabs
 
 

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include "../../situation3d_amd/csrc/gemm16_core.h"
+#include "../../situation3d_amd/csrc/gemmx6_core.h"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -57,6 +58,10 @@ struct Config { const char *name; int id; };
 
 static hipError_t run_config(int id, const gemm16::Problem &p, int bmode, hipStream_t s) {
   switch (id) {
+    case 20: return gemmx6::launch<1, 1, 2, 4, 4>(p, bmode, s);     // bf16 x 6 core: 64 x 128, 8 waves of 32 x 32
+    case 21: return gemmx6::launch<1, 2, 2, 2, 4>(p, bmode, s);     //                64 x 128, 4 waves of 32 x 64
+    case 22: return gemmx6::launch<1, 2, 4, 2, 4>(p, bmode, s);     //                128 x 128, 8 waves of 32 x 64
+    case 23: return gemmx6::launch<1, 2, 2, 4, 4>(p, bmode, s);     //                64 x 256, 8 waves of 32 x 64
 #define X(ID, AB, BB, WGM, WGN, PF, OCC) case ID: return gemm16::launch<AB, BB, WGM, WGN, PF, OCC>(p, bmode, s);
     CONFIGS(X)
 #undef X
@@ -65,6 +70,9 @@ static hipError_t run_config(int id, const gemm16::Problem &p, int bmode, hipStr
 }
 static void config_dims(int id, int *tm, int *tn, int *kw) {
   *kw = 1;
+  if (id == 22) { *tm = 128; *tn = 128; return; }
+  if (id == 23) { *tm = 64; *tn = 256; return; }
+  if (id >= 20) { *tm = 64; *tn = 128; return; }
   switch (id) {
 #define X(ID, AB, BB, WGM, WGN, PF, OCC) case ID: *tm = 16 * AB * WGM; *tn = 16 * BB * WGN; return;
     CONFIGS(X)
@@ -73,6 +81,10 @@ static void config_dims(int id, int *tm, int *tn, int *kw) {
 }
 static std::string config_name(int id) {
   char buf[64];
+  if (id == 20) return "x6 w32x32 g2x4";
+  if (id == 21) return "x6 w32x64 g2x2";
+  if (id == 22) return "x6 w32x64 g4x2";
+  if (id == 23) return "x6 w32x64 g2x4";
   switch (id) {
 #define X(ID, AB, BB, WGM, WGN, PF, OCC) case ID: snprintf(buf, 64, "w%dx%d g%dx%d p%d o%d", 16 * AB, 16 * BB, WGM, WGN, PF, OCC); return buf;
     CONFIGS(X)
@@ -175,8 +187,10 @@ int main(int argc, char **argv) {
     printf("\n== %s  (%.2f GFLOP; tuned library in the step %.1f us; rocBLAS default here %.1f us = %.0f TF)\n", sh.name, gflop,
            sh.lib_us, rb_us, gflop / rb_us * 1e-3 * 1e6 * 1e-3);
 
-    for (int id = 0; id < NCONFIG; ++id) {
+    for (int idx = 0; idx < NCONFIG + 4; ++idx) {
+      const int id = idx < NCONFIG ? idx : 20 + idx - NCONFIG;     // 20, 21: the bf16 x 6 core
       if (one && id != one_cfg) continue;
+      if (quick && idx < NCONFIG && getenv("X6_ONLY")) continue;
       int tm, tn, kw;
       config_dims(id, &tm, &tn, &kw);
       const int tiles = ((sh.M + tm - 1) / tm) * ((sh.N + tn - 1) / tn) * sh.batch;
