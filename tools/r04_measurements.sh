@@ -19,3 +19,7 @@ rm -f gpurun_out/pmc_r04_*/r_kernel_trace.csv
 (cd tools/micro && ./mfma16_rate && ./mfma16_fill) > gpurun_out/r04_mfma16_micro.txt 2>&1
 timeout 600 python bench.py > gpurun_out/r04_bench_full.json 2> gpurun_out/r04_bench_full.err
 timeout 300 python bench.py --force-reducer --no-variants --no-cpu-baseline --no-ops-roofline > gpurun_out/r04_bench_reducer.json 2> gpurun_out/r04_bench_reducer.err
+# late round 4: the bf16 x 6 GEMM core beside the f32 core and the library, product by product; the read + MFMA stream
+timeout 600 python tools/gemmx6_bench.py > gpurun_out/r04_gemmx6_shapes.txt 2>&1
+(cd tools/micro && ./bf16x6_rate) > gpurun_out/r04_bf16x6_micro.txt 2>&1
+bash tools/glue_trace.sh
