@@ -636,6 +636,18 @@ int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, cons
 int sig3d_pos_mlp_bwd_z(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
                         const float *dy, float *dpre, float *grads, void *stream);
 
+/* Weight gradient of a SharedMLP layer as a k-streaming split product on the f32 matrix cores (csrc/gemm16.hip over
+ * gemm16_core.h): dW (cout, cin) = sum_{b, e} dY[b, co, e] * a[b, ci, e], a = x or relu(x * pscale + pshift) as in
+ * sig3d_mlp_layer_dw, both operands read along their rows.  n_act: compact lists (sample i reduces over its first
+ * n_act[i] positions; e stays the row stride), or NULL.  dW is OVERWRITTEN; every (sample, split) pair writes a slab of
+ * `work` (sig3d_mlp_layer_dw_stream_work_floats floats) and one small launch folds them -- fixed order, no atomics.
+ * e % 4 == 0, 16-byte aligned operands; cout * cin % 4 == 0.  1.5-2.5 x faster than sig3d_mlp_layer_dw at the step's
+ * shapes. */
+int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY, const float *x,
+                              const float *pscale, const float *pshift, const int *n_act, float *dW,
+                              float *work, void *stream);
+long sig3d_mlp_layer_dw_stream_work_floats(int b, int cin, int cout, long e);
+
 /* ---- the two MLP heads on the pooled Q-Former output (csrc/heads.hip) ----------------------------------------
  * situation3d/models/sqa_module.py: the fused query tokens are averaged per sample and feed
  *   aux    (b, n_aux) = Linear(hidden, n_aux)(GELU(Linear(hidden, hidden)(pooled)))             [w1a b1a w2a b2a]

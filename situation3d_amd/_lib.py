@@ -37,6 +37,7 @@ SIGNATURES = {
     "sig3d_mlp_layer0_scatter_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer0_scatter_dx_w": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_dx": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer_dw_stream": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
     "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],
@@ -215,7 +216,8 @@ def bq_levels_workspace_bytes(batch, arr):
 
 
 INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes",
-                "sig3d_ball_query_levels_workspace_bytes", "sig3d_pooled_heads_work_floats")
+                "sig3d_ball_query_levels_workspace_bytes", "sig3d_pooled_heads_work_floats",
+                "sig3d_mlp_layer_dw_stream_work_floats")
 
 _lib = None
 
@@ -247,6 +249,8 @@ def load():
     lib.sig3d_ball_query_levels_workspace_bytes.restype = ctypes.c_long
     lib.sig3d_pooled_heads_work_floats.argtypes = [_I, _I]
     lib.sig3d_pooled_heads_work_floats.restype = ctypes.c_long
+    lib.sig3d_mlp_layer_dw_stream_work_floats.argtypes = [_I, _I, _I, ctypes.c_long]
+    lib.sig3d_mlp_layer_dw_stream_work_floats.restype = ctypes.c_long
     _lib = lib
     return lib
 

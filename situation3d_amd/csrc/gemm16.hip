@@ -53,7 +53,89 @@ int choose_splits(const sig3d_gemm16_problem &q, int config) {
   return s < 1 ? 1 : s;
 }
 
+// dW = slab 0 (already in dW) + the other slabs.  64 float4 columns x 4 slab groups per workgroup: a thread folds every
+// fourth slab of its column, eight loads in flight, the four partial sums meet in LDS (one thread per column and 127
+// dependent trips took 14 us for 8 MB that sit in L2).
+__global__ __launch_bounds__(256) void sum_slabs_kernel(int n4, int nslabs, size_t slab4, float4 *__restrict__ dst,
+                                                        const float4 *__restrict__ slabs) {
+  __shared__ float4 s_part[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = min((int)blockIdx.x * 64 + c, n4 - 1);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = g; s0 < nslabs; s0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)min(s0 + 4 * u, nslabs - 1) * slab4 + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + 4 * u < nslabs) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  s_part[g][c] = a;
+  __syncthreads();
+  if (g == 0 && (int)blockIdx.x * 64 + c < n4) {
+    const float4 d = dst[i], p0 = s_part[0][c], p1 = s_part[1][c], p2 = s_part[2][c], p3 = s_part[3][c];
+    dst[i] = make_float4(d.x + ((p0.x + p1.x) + (p2.x + p3.x)), d.y + ((p0.y + p1.y) + (p2.y + p3.y)),
+                         d.z + ((p0.z + p1.z) + (p2.z + p3.z)), d.w + ((p0.w + p1.w) + (p2.w + p3.w)));
+  }
+}
+
+const int SIG3D_DW_STREAM_WGS = getenv("SIG3D_DW_STREAM_WGS") ? atoi(getenv("SIG3D_DW_STREAM_WGS")) : 512;
+
+int dw_stream_splits(int b, int cin, int cout, long e) {
+  const int tiles = sig3d_ceil_div(cout, 64) * sig3d_ceil_div(cin, 64);
+  int s = SIG3D_DW_STREAM_WGS / (tiles * (b > 0 ? b : 1));          // default: two 64 x 64 workgroups per CU
+  const long chunks = (e + 31) / 32;
+  if (s > chunks / 4) s = (int)(chunks / 4);
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
 }  // namespace
+
+// The weight gradient of a SharedMLP layer (pytorch_utils.py:11-36: Conv2d 1x1 backward) as a k-STREAMING product:
+// dW (cout, cin) = sum_b dY[b] a[b]^T, positions as the reduction index, both operands read along their rows in 16-byte
+// requests (mlp_dw_kernel reads one 64-byte run per LANE and row: 1-2.5 TB/s and a tail of f32 atomics; this form is
+// bound by the f32 matrix pipe or by HBM).  a = x, or relu(x * pscale + pshift) applied on the way to LDS.  Every
+// (sample, split) pair writes its own 64 x 64 tiles into a slab; sum_slabs_kernel folds them: fixed order, no atomics.
+// n_act (compact lists): sample i reduces over its first n_act[i] positions only; e stays the row stride.
+// dW is OVERWRITTEN.  work: sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e) floats of scratch.
+extern "C" long sig3d_mlp_layer_dw_stream_work_floats(int b, int cin, int cout, long e) {
+  const long pairs = (long)b * dw_stream_splits(b, cin, cout, e);
+  return (pairs > 1 ? pairs - 1 : 0) * (((long)cout * cin + 3) / 4 * 4);
+}
+
+extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                         const float *pscale, const float *pshift, const int *n_act, float *dW,
+                                         float *work, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 1 && cin >= 1 && cout >= 1 && e >= 4 && e % 4 == 0, "bad size (rows of 16-byte multiples)");
+  SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
+  SIG3D_REQUIRE(dY && x && dW, "null operand");
+  auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
+  SIG3D_REQUIRE(al(dY) && al(x), "operands must be 16-byte aligned");
+  SIG3D_REQUIRE((size_t)cout * e * 4 < (1ull << 31) && (size_t)cin * e * 4 < (1ull << 31), "a sample's operand exceeds 2 GB");
+  const int splits = dw_stream_splits(b, cin, cout, e);
+  const long pairs = (long)b * splits;
+  SIG3D_REQUIRE(pairs == 1 || work != nullptr, "work space missing (sig3d_mlp_layer_dw_stream_work_floats)");
+  const long slab = ((long)cout * cin + 3) / 4 * 4;
+  gemm16::Problem p = {};
+  p.A = dY; p.B = x; p.C = dW; p.Cs = work;
+  p.M = cout; p.N = cin; p.K = (int)e;
+  p.lda = (int)e; p.ldb = (int)e; p.ldc = cin;
+  p.sA = (long)cout * e; p.sB = (long)cin * e; p.sC = 0; p.slab = slab;
+  p.batch = b; p.splits = splits; p.act = 0;
+  p.k_dev = n_act; p.b_scale = pscale; p.b_shift = pshift;
+  hipError_t err = gemm16::launch<1, 2, 4, 2, 4, 2, true>(p, gemm16::B_KC, stream);
+  if (err != hipSuccess) { sig3d_set_error("gemm16_kernel (weight gradient)", err); return (int)err; }
+  if (pairs > 1) {
+    SIG3D_REQUIRE(((size_t)dW & 15) == 0 && ((long)cout * cin) % 4 == 0, "dW: 16-byte aligned, cout * cin a multiple of 4");
+    const int n4 = (int)((long)cout * cin / 4);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(sig3d_ceil_div(n4, 64)), dim3(256), 0, stream, n4, (int)(pairs - 1),
+                       (size_t)(slab / 4), reinterpret_cast<float4 *>(dW), reinterpret_cast<const float4 *>(work));
+    SIG3D_LAUNCH_CHECK("sum_slabs_kernel");
+  }
+  return 0;
+}
 
 extern "C" int sig3d_gemm16_splits(int bmode, int batch, int m, int n, int k, int act, int config) {
   sig3d_gemm16_problem q = {};

@@ -48,6 +48,11 @@ struct Problem {
   int batch, splits;
   int act;                  // 0 none, 1 erf-GELU (splits == 1), 2 times gelu'(aux) (splits == 1)
   int ntm, ntn;
+  // weight-gradient use (launch<..., DW = true>, sig3d_mlp_layer_dw_stream): the reduction length of batch element i is
+  // k_dev[i] (device memory; K is then the row capacity), B rows pass through relu(v * b_scale[n] + b_shift[n]) on their
+  // way to LDS, and every (batch, split) pair writes its own slab: pair 0 to C, pair q to Cs + (q - 1) * slab
+  const int *k_dev;
+  const float *b_scale, *b_shift;
 #ifdef GEMM16_TIMING
   unsigned long long *dbg;  // tools/micro/gemm16_bench.hip: cycle stamps of workgroup 0, wave 0
 #endif
@@ -73,8 +78,9 @@ __device__ __forceinline__ int slot_off(int row, int q) { return row * BK + ((q 
 
 // AB x BB blocks of 16 x 16 per wave, WGM x WGN waves per workgroup, PF >= 3 chunks in flight (register ring,
 // statically indexed: the loop is unrolled PF times), OCC workgroups per CU the register budget is sized for.
-template <int AB, int BB, int WGM, int WGN, int PF, int OCC, int BMODE, bool KEDGE>
+template <int AB, int BB, int WGM, int WGN, int PF, int OCC, int BMODE, bool KEDGE, bool DW = false>
 __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Problem p) {
+  static_assert(!DW || BMODE == B_KC, "the weight-gradient form streams two k-contiguous operands");
   static_assert(PF >= 3, "chunk c + 2 is stored while chunk c + PF is requested into chunk c's slot");
   constexpr int NW = WGM * WGN, NT = 64 * NW;
   constexpr int TM = 16 * AB * WGM, TN = 16 * BB * WGN;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
 
   const float *__restrict__ A = p.A + (size_t)batch * p.sA;
   const float *__restrict__ B = p.B + (size_t)batch * p.sB;
-  const int M = p.M, N = p.N, K = p.K;
+  const int M = p.M, N = p.N, K = (DW && p.k_dev) ? __builtin_amdgcn_readfirstlane(p.k_dev[batch]) : p.K;
   const int nchunks_all = (K + BK - 1) / BK;
   const int c_lo = (int)((long)nchunks_all * z / p.splits), c_hi = (int)((long)nchunks_all * (z + 1) / p.splits);
   const int nchunks = c_hi - c_lo;
@@ -158,6 +164,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
     }
   }
   const int a_step = BK * 4, b_step = (BMODE == B_KC ? BK : BK * p.ldb) * 4;   // bytes per chunk
+  float bsc[B_PER], bsh[B_PER];          // DW: the BatchNorm + ReLU of the previous layer, applied to B rows on load
+  const bool b_pro = DW && p.b_scale != nullptr;
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int u = min(tid + NT * i, BKC_UNITS - 1), row = min(n0 + (u >> 3), N - 1);
+    bsc[i] = b_pro ? p.b_scale[row] : 1.f;
+    bsh[i] = b_pro ? p.b_shift[row] : 0.f;
+  }
 
   f32x4 ring_a[PF][A_PER], ring_b[PF][B_PER];
 #ifndef GEMM16_KO
@@ -210,6 +224,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
       constexpr int u = i - A_PER;
       if (BKC_UNITS % NT != 0 && tid + NT * u >= BKC_UNITS) return;
       f32x4 v = rb[u];
+      if (DW && b_pro) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(0.f, v[e] * bsc[u] + bsh[u]);
+      }
       if (KEDGE) {
         const int k = (c_lo + c) * BK + kb[u];
 #pragma unroll
@@ -337,7 +355,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
   GEMM16_STAMP();
 
   // ---- epilogue.  C/D map of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + register.
-  float *__restrict__ C = (z == 0 ? p.C : p.Cs + (size_t)(z - 1) * p.slab) + (size_t)batch * p.sC;
+  const int pair = batch * p.splits + z;    // DW: every (batch, split) pair has a slab of its own, summed by the caller
+  float *__restrict__ C = DW ? (pair == 0 ? p.C : p.Cs + (size_t)(pair - 1) * p.slab)
+                             : (z == 0 ? p.C : p.Cs + (size_t)(z - 1) * p.slab) + (size_t)batch * p.sC;
   const float *bias = (p.bias && z == 0) ? p.bias + (size_t)batch * p.sBias : nullptr;
   const float *addend = (p.addend && z == 0) ? p.addend + (size_t)batch * p.sC : nullptr;
   float *aux = p.aux ? p.aux + (size_t)batch * p.sC : nullptr;
@@ -385,7 +405,7 @@ constexpr size_t lds_bytes() {
 }
 
 // Launch one configuration.  Returns hipSuccess or the launch error.
-template <int AB, int BB, int WGM, int WGN, int PF, int OCC>
+template <int AB, int BB, int WGM, int WGN, int PF, int OCC, bool DW = false>
 hipError_t launch(Problem p, int bmode, hipStream_t stream) {
   constexpr int TM = 16 * AB * WGM, TN = 16 * BB * WGN;
   constexpr size_t lds = lds_bytes<AB, BB, WGM, WGN>();
@@ -396,7 +416,7 @@ hipError_t launch(Problem p, int bmode, hipStream_t stream) {
   const bool kedge = (p.K % BK) != 0;
 #define GEMM16_GO(BM, KE)                                                                                   \
   do {                                                                                                      \
-    auto kern = gemm16_kernel<AB, BB, WGM, WGN, PF, OCC, BM, KE>;                                           \
+    auto kern = gemm16_kernel<AB, BB, WGM, WGN, PF, OCC, BM, KE, DW>;                                       \
     static bool attr_done = false;                                                                          \
     if (!attr_done && lds > 64 * 1024) {                                                                    \
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
@@ -406,8 +426,13 @@ hipError_t launch(Problem p, int bmode, hipStream_t stream) {
     }                                                                                                       \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WGM * WGN), lds, stream, p);                             \
   } while (0)
-  if (bmode == B_KC) { if (kedge) GEMM16_GO(B_KC, true); else GEMM16_GO(B_KC, false); }
-  else { if (kedge) GEMM16_GO(B_MC, true); else GEMM16_GO(B_MC, false); }
+  if constexpr (DW) {
+    // lengths from device memory (compact lists) are arbitrary: masked chunks; whole 32-deep chunks need no masking
+    if (kedge || p.k_dev) GEMM16_GO(B_KC, true); else GEMM16_GO(B_KC, false);
+  } else {
+    if (bmode == B_KC) { if (kedge) GEMM16_GO(B_KC, true); else GEMM16_GO(B_KC, false); }
+    else { if (kedge) GEMM16_GO(B_MC, true); else GEMM16_GO(B_MC, false); }
+  }
 #undef GEMM16_GO
   return hipGetLastError();
 }

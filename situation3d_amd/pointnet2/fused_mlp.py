@@ -94,6 +94,9 @@ def compact_lists(idx):
     return CompactLists(idx.shape[0], idx.shape[1], idx.shape[2], idx.device).compute(idx.contiguous())
 
 
+# SIG3D_DW_STREAM=0: the layers' weight gradients through mlp_dw_kernel (one 64-byte run per lane and row, f32 atomics)
+# instead of the k-streaming split product of sig3d_mlp_layer_dw_stream
+DW_STREAM = os.environ.get("SIG3D_DW_STREAM", "1") != "0"
 # SIG3D_COMPACT=0 keeps every set-abstraction level dense
 COMPACT = os.environ.get("SIG3D_COMPACT", "1") != "0"
 # levels with at least this many (dense) positions run compact; the others keep the library-GEMM hybrid
@@ -396,6 +399,14 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(g_idx), _lib.ptr(dY), _lib.ptr(dW), 1,
                               _lib.ptr(c_cent if compact is not None else None),
                               _lib.ptr(c_nact if compact is not None else None), stream)
+                elif DW_STREAM and e % 4 == 0:
+                    # k-streaming split product on the f32 matrix cores (gemm16_core.h, weight-gradient form): both
+                    # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
+                    n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
+                    work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_mlp_layer_dw_stream", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
+                              _lib.ptr(ppb), _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dW),
+                              _lib.ptr(work), stream)
                 elif compact is not None:
                     _lib.call("sig3d_mlp_layer_dw_compact", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
                               _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, _lib.ptr(c_nact), stream)

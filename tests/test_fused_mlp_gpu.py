@@ -625,3 +625,51 @@ def test_sa1_reading_the_raw_scan_matches_the_stored_grouped_tensor(mode, monkey
             assert rel < 1e-3, (n1, rel)      # a max-pool winner that leads by an ulp may change (see the gather test)
         for (n1, b1), (_, b2) in zip(sa.named_buffers(), ref.named_buffers()):
             _close(b1.float(), b2.float(), n1, tol=1e-5)
+
+
+@pytest.mark.parametrize("b,cin,cout,e,compact,prologue", [(8, 128, 128, 4096, False, True), (8, 259, 128, 4096, False, False),
+                                                          (8, 131, 128, 8192, False, False), (8, 128, 256, 8192, False, True),
+                                                          (8, 64, 128, 20000, True, True), (3, 64, 64, 1000, True, True),
+                                                          (2, 35, 64, 132, False, True), (8, 128, 128, 2048, True, True),
+                                                          (1, 6, 32, 36, True, False)])
+def test_streaming_weight_gradient_matches_the_row_per_lane_kernel_and_float64(b, cin, cout, e, compact, prologue):
+    """sig3d_mlp_layer_dw_stream (k-streaming split product, slabs folded in a fixed order) against sig3d_mlp_layer_dw /
+    _compact (f32 atomics) and a float64 einsum: dense rows, compact rows with ragged live counts (one of them 0 .. a
+    few positions), with and without the previous layer's BatchNorm + ReLU on load; and it is deterministic."""
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(cin * 7 + cout + e)
+    dY = torch.randn(b, cout, e, generator=g).to(DEV)
+    x = torch.randn(b, cin, e, generator=g).to(DEV)
+    ps = (torch.rand(cin, generator=g) + 0.5).to(DEV) if prologue else None
+    pb = torch.randn(cin, generator=g).to(DEV) if prologue else None
+    n_act = None
+    if compact:
+        live = [e, max(e // 3, 1), 5, 0, e - 1, e // 2, 33, e][:b]
+        n_act = torch.tensor(live, dtype=torch.int32, device=DEV)
+    st = L.stream_ptr(DEV)
+    work = torch.empty(max(int(L.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e)), 4), device=DEV)
+    outs = []
+    with torch.cuda.device(DEV):
+        for _ in range(2):
+            dW = torch.full((cout, cin), float("nan"), device=DEV)
+            L.call("sig3d_mlp_layer_dw_stream", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(n_act),
+                   L.ptr(dW), L.ptr(work), st)
+            outs.append(dW)
+        old = torch.empty(cout, cin, device=DEV)
+        if compact:
+            L.call("sig3d_mlp_layer_dw_compact", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(old), 0,
+                   L.ptr(n_act), st)
+        else:
+            L.call("sig3d_mlp_layer_dw", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(old), 0, st)
+    assert torch.equal(outs[0], outs[1])
+    a = x.double()
+    if prologue:
+        a = torch.relu(a * ps.double()[None, :, None] + pb.double()[None, :, None])
+    d = dY.double()
+    if compact:
+        mask = (torch.arange(e, device=DEV)[None, :] < n_act[:, None]).double()[:, None, :]
+        a, d = a * mask, d * mask
+    ref = torch.einsum("boe,bce->oc", d, a)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((outs[0].double() - ref).abs().max()) < 2e-5 * scale
+    assert float((old.double() - ref).abs().max()) < 1e-4 * scale

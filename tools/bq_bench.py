@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, '.')
 import bench  # noqa: E402
 from situation3d_amd import _lib as L  # noqa: E402
+if len(sys.argv) > 1:      # a variant build of the library (tools only: the product loads its own)
+    L.LIB_PATH = sys.argv[1]
 from situation3d_amd.pointnet2 import _ext  # noqa: E402
 
 dev = torch.device('cuda', 0)
