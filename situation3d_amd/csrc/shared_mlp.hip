@@ -1425,6 +1425,11 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
     return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
   if (forced_nt == 1)
     return dispatch_mlp_fwd<1>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
+  // compact lists: a sample has a few hundred live tiles, i.e. one or two per wave -- the launch then takes as long as
+  // ONE wave needs for a tile, and a 64-channel tile halves that (measured at the step's shapes, 11 % and 36 % / 4 % and
+  // 16 % live: 39 / 19 / 24 us against 46 / 31 / 32 with 128-channel tiles; 100 / 29 / 48 against 98 / 36 / 56)
+  if (tl_n_act != nullptr && cout > 64 && fits(64, 80 * 1024))
+    return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
   if (cout > 64 && fits(128, 80 * 1024))
     return dispatch_mlp_fwd<4>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
   if (cout > 32 && fits(64, 80 * 1024))

@@ -9,12 +9,16 @@ from situation3d_amd.build import FLAGS, CSRC
 tmp = tempfile.mkdtemp()
 so = os.path.join(tmp, "libmlp_timing.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-shared", "-DSIG3D_MLP_TIMING",
-                       os.path.join(CSRC, "shared_mlp.hip"), os.path.join(CSRC, "capi.hip"), "-o", so] + FLAGS)
+                       os.path.join(CSRC, "shared_mlp.hip"), os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "group_points.hip"), "-o", so] + FLAGS)
 lib = ctypes.CDLL(so)
 P, I = ctypes.c_void_p, ctypes.c_int
 lib.sig3d_mlp_layer_fwd.argtypes = [I, I, I, ctypes.c_long] + [P] * 7 + [I, P]
+lib.sig3d_mlp_layer_fwd_compact.argtypes = [I, I, I, ctypes.c_long] + [P] * 7 + [I, P, P, P]
 dev = "cuda:0"
-for name, b, cin, cout, e in [("SA1 L3", 8, 64, 128, 131072), ("SA2 L3", 8, 128, 256, 32768), ("SA2 L2", 8, 128, 128, 32768)]:
+CASES = [("SA1 L3", 8, 64, 128, 131072, 0), ("SA2 L3", 8, 128, 256, 32768, 0), ("SA2 L2", 8, 128, 128, 32768, 0),
+         ("SA1 L2 compact (14 400 live of 131 072)", 8, 64, 64, 131072, 14400),
+         ("SA1 L3 compact", 8, 64, 128, 131072, 14400), ("SA2 L3 compact (1 300 live)", 8, 128, 256, 32768, 1300)]
+for name, b, cin, cout, e, live in CASES:
     x = torch.randn(b, cin, e, device=dev); w = torch.randn(cout, cin, device=dev)
     y = torch.empty(b, cout, e, device=dev); st = torch.empty(2, cout, dtype=torch.float64, device=dev)
     ps, pb = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev)
@@ -22,9 +26,20 @@ for name, b, cin, cout, e in [("SA1 L3", 8, 64, 128, 131072), ("SA2 L3", 8, 128,
     marks = (ctypes.c_ulonglong * 64)(); n = ctypes.c_int(0)
     for it in range(3):
         lib.sig3d_debug_mlp_marks(marks, ctypes.byref(n))
-        lib.sig3d_mlp_layer_fwd(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]), 0,
-                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        t_a, t_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_a.record()
+        if live:
+            n_act = torch.full((b,), live, dtype=torch.int32, device=dev)
+            mult = torch.ones(b, e, device=dev)
+            lib.sig3d_mlp_layer_fwd_compact(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]), 0,
+                                            ptr(n_act), ptr(mult), stream)
+        else:
+            lib.sig3d_mlp_layer_fwd(b, cin, cout, e, ptr(x), ptr(w), ptr(ps), ptr(pb), ptr(y), ptr(st[0]), ptr(st[1]), 0, stream)
+        t_b.record()
         torch.cuda.synchronize()
+        if it == 2:
+            print("   launch: %.1f us" % (t_a.elapsed_time(t_b) * 1e3))
     cyc = (ctypes.c_ulonglong * 64)()
     lib.sig3d_debug_mlp_cycles(cyc)
     lib.sig3d_debug_mlp_marks(marks, ctypes.byref(n))
