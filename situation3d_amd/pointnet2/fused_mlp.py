@@ -96,7 +96,10 @@ def compact_lists(idx):
 
 # SIG3D_DW_STREAM=0: the layers' weight gradients through mlp_dw_kernel (one 64-byte run per lane and row, f32 atomics)
 # instead of the k-streaming split product of sig3d_mlp_layer_dw_stream
-DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 2: the dense levels only
+DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 3: every level, whatever its size
+# dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
+# variant of the bench is 0.15 ms slower with the streaming product there)
+DW_STREAM_MAX_E = int(os.environ.get("SIG3D_DW_STREAM_MAX_E", "16384"))
 # SIG3D_COMPACT=0 keeps every set-abstraction level dense
 COMPACT = os.environ.get("SIG3D_COMPACT", "1") != "0"
 # levels with at least this many (dense) positions run compact; the others keep the library-GEMM hybrid
@@ -399,7 +402,7 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(g_idx), _lib.ptr(dY), _lib.ptr(dW), 1,
                               _lib.ptr(c_cent if compact is not None else None),
                               _lib.ptr(c_nact if compact is not None else None), stream)
-                elif DW_STREAM and e % 4 == 0 and (DW_STREAM != 2 or compact is None):
+                elif DW_STREAM and e % 4 == 0 and (DW_STREAM == 3 or compact is not None or e <= DW_STREAM_MAX_E):
                     # k-streaming split product on the f32 matrix cores (gemm16_core.h, weight-gradient form): both
                     # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
