@@ -108,9 +108,14 @@ extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const
                                          const float *pscale, const float *pshift, const int *n_act, float *dW,
                                          float *work, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SIG3D_REQUIRE(b >= 1 && cin >= 1 && cout >= 1 && e >= 4 && e % 4 == 0, "bad size (rows of 16-byte multiples)");
+  SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0 && e % 4 == 0, "bad size (rows of 16-byte multiples)");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
-  SIG3D_REQUIRE(dY && x && dW, "null operand");
+  SIG3D_REQUIRE(dW, "null operand");
+  if (b == 0 || e == 0) {   // an empty sum
+    SIG3D_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)cout * cin, stream));
+    return 0;
+  }
+  SIG3D_REQUIRE(dY && x, "null operand");
   auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
   SIG3D_REQUIRE(al(dY) && al(x), "operands must be 16-byte aligned");
   SIG3D_REQUIRE((size_t)cout * e * 4 < (1ull << 31) && (size_t)cin * e * 4 < (1ull << 31), "a sample's operand exceeds 2 GB");
