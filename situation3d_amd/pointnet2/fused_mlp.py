@@ -402,7 +402,8 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(g_idx), _lib.ptr(dY), _lib.ptr(dW), 1,
                               _lib.ptr(c_cent if compact is not None else None),
                               _lib.ptr(c_nact if compact is not None else None), stream)
-                elif DW_STREAM and e % 4 == 0 and (DW_STREAM == 3 or compact is not None or e <= DW_STREAM_MAX_E):
+                elif DW_STREAM and e % 4 == 0 and (cout * cin) % 4 == 0 and \
+                        (DW_STREAM == 3 or compact is not None or e <= DW_STREAM_MAX_E):
                     # k-streaming split product on the f32 matrix cores (gemm16_core.h, weight-gradient form): both
                     # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
