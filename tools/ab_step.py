@@ -42,7 +42,7 @@ torch.manual_seed(1234)
 model = SIG3DQFormer(num_answers=bench.NUM_ANSWERS).to(dev).train()
 opt = build_optimizer(model, name="flat_adamw")
 batches = [bench.synthetic_batch(bench.BATCH, bench.N_POINTS, 1234 + i, dev) for i in range(4)]
-work = torch.cuda.Stream(dev)
+work = torch.cuda.Stream(dev, priority=int(os.environ.get("AB_WORK_PRIORITY", "0")))   # -1: a high-priority queue
 steps = {}
 with torch.cuda.stream(work):
     for name, val in (("A", lit(args.a)), ("B", lit(args.b))):
