@@ -596,9 +596,17 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_seg_pm_kernel(int c, int 
   const float *row = y + ((size_t)bi * c + ch) * E;
   float best = -1.f;
   int bt = 0;
-  for (int u = lo; u < hi; ++u) {
-    const float v = fmaxf(0.f, row[u] * sc + sh);
-    if (v > best) { best = v; bt = u - lo; }  // first maximum, like max_pool2d over the padded list
+  // eight elements of the segment requested per trip (clamped, masked): one element per trip made every element a
+  // memory round trip -- 31 us at 7 distinct neighbours per centre, 246 us at 24 (surface-shaped scenes)
+  for (int u0 = lo; u0 < hi; u0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = row[min(u0 + q, hi - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = fmaxf(0.f, t[q] * sc + sh);
+      if (u0 + q < hi && v > best) { best = v; bt = u0 + q - lo; }  // first maximum, like max_pool2d over the padded list
+    }
   }
   tile[cl][pl] = best;
   if (c0 + cl < c && p0 + pl < P) {
@@ -776,9 +784,15 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_seg_kernel(int c, int P, 
   const float *row = y + ((size_t)bi * c + ch) * E;
   float best = -1.f;
   int bt = 0;
-  for (int u = lo; u < hi; ++u) {
-    const float v = fmaxf(0.f, row[u] * sc + sh);
-    if (v > best) { best = v; bt = u - lo; }  // first maximum, like max_pool2d over the padded list
+  for (int u0 = lo; u0 < hi; u0 += 8) {   // eight requests per trip (see bn_relu_maxpool_seg_pm_kernel)
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = row[min(u0 + q, hi - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = fmaxf(0.f, t[q] * sc + sh);
+      if (u0 + q < hi && v > best) { best = v; bt = u0 + q - lo; }  // first maximum, like max_pool2d over the padded list
+    }
   }
   out[((size_t)bi * c + ch) * P + j] = best;
   arg[((size_t)bi * c + ch) * P + j] = bt;
