@@ -543,7 +543,10 @@ int sig3d_gemm_group(int nprob, const sig3d_gemm_problem *problems, void *stream
  *          writes C_slabs + (z-1)*slab_stride (+ i*stride_c, row stride ldc) and the CONSUMER adds the slabs while
  *          it loads them (sig3d_dropout_add_ln_fwd_slabs / _bwd_slabs): no atomics, no zero fill, no fold launch.
  *          act != 0 requires splits == 1.  sig3d_gemm16_splits proposes the count measured best on MI355X.
- * config : 0 = choose; 1 = 64x64 workgroup tiles (8 waves), 2 = 32x64 (4 waves), 3 = 64x128 (8 waves).
+ * config : 0 = choose; 1 = 64x64 workgroup tiles (8 waves), 2 = 32x64 (4 waves), 3 = 64x128 (8 waves);
+ *          11 / 12 = the same product on the bf16 matrix cores (csrc/gemmx6_core.h: every f32 operand split into
+ *          three bf16 terms, six products, f32 accumulation -- f32-equivalent results, not a reduced precision):
+ *          64x128 tiles of 8 waves / of 4 waves.  Never chosen by 0.
  * k % 4 == 0, 16-byte aligned operand rows (n % 4 == 0 for bmode 1); every operand below 2 GB per batch element. */
 typedef struct sig3d_gemm16_problem {
   const float *A; int lda; long stride_a;
