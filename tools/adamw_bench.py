@@ -3,14 +3,16 @@ python tools/adamw_bench.py"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from situation3d_amd import optim
+from situation3d_amd import optim, _lib
+if len(sys.argv) > 1:      # a variant build of the library (tools only)
+    _lib.LIB_PATH = sys.argv[1]
 from situation3d_amd.model import SIG3DQFormer
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = SIG3DQFormer(num_answers=706).to(dev)
 n = sum(p.numel() for p in model.parameters())
-for chunk in (16384, 65536, 262144, 1048576):
+for chunk in (65536, 262144):
     optim._CHUNK = chunk
     opt = optim.FlatAdamW([{"params": list(model.parameters()), "weight_decay": 0.05}], lr=2e-5)
     for p in model.parameters():
