@@ -97,6 +97,8 @@ def compact_lists(idx):
 # SIG3D_DW_STREAM=0: the layers' weight gradients through mlp_dw_kernel (one 64-byte run per lane and row, f32 atomics)
 # instead of the k-streaming split product of sig3d_mlp_layer_dw_stream
 DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 3: every level, whatever its size
+# SIG3D_DW_REGROUP=0: the gathered first layer of a compact level keeps its gathering weight-gradient kernel
+DW_REGROUP = os.environ.get("SIG3D_DW_REGROUP", "1") != "0"
 # dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
 # variant of the bench is 0.15 ms slower with the streaming product there)
 DW_STREAM_MAX_E = int(os.environ.get("SIG3D_DW_STREAM_MAX_E", "16384"))
@@ -396,6 +398,19 @@ class _FusedMLPMax(torch.autograd.Function):
                               ctypes.c_float(f_radius), _lib.ptr(x), _lib.ptr(f_new_xyz), _lib.ptr(f_idx),
                               _lib.ptr(c_cent if compact is not None else None),
                               _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dY), _lib.ptr(dW), 1, stream)
+                elif gather is not None and k == 0 and regroup is None and compact is not None and DW_REGROUP \
+                        and DW_STREAM and e % 4 == 0 and (cout * cin) % 4 == 0:
+                    # compact lists: the grouped tensor of the DISTINCT neighbours is a few MB -- re-materialised here
+                    # (point-major rows in, one launch) and streamed through the split product; the gathering weight-
+                    # gradient kernel walks index -> row round trips (42 / 86 us at 4 % / 16 % distinct neighbours)
+                    rg = torch.empty((b, c_src + 3, e), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_query_group_compact", b, n_src, p, c_src, c_src, s, 1, int(g_norm),
+                              ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(None), _lib.ptr(x),
+                              _lib.ptr(c_cidx), _lib.ptr(c_cent), _lib.ptr(c_nact), _lib.ptr(rg), stream)
+                    n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
+                    work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
+                    _lib.call("sig3d_mlp_layer_dw_stream", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(rg), _lib.ptr(None),
+                              _lib.ptr(None), _lib.ptr(c_nact), _lib.ptr(dW), _lib.ptr(work), stream)
                 elif gather is not None and k == 0 and regroup is None:
                     _lib.call("sig3d_mlp_layer0_gather_dw", b, n_src, p, s, c_src, cout, int(g_norm),
                               ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(x),
