@@ -31,6 +31,7 @@ preallocated buffers.
 Inputs live in static device buffers that are refreshed (device-to-device copy) before each
 replay; outputs (loss, answer_scores, ...) are read from static buffers after it.
 """
+import contextlib
 import os
 
 import torch
@@ -96,7 +97,7 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
                  prefetch_geometry=False, geometry_levels=None, reducer=None, split_backward=True,
-                 prefetch_depth=None):
+                 prefetch_depth=None, update_beside=None):
         """`reducer` (ddp.GradBucketReducer, data parallel): the step becomes graph A (forward +
         backward, gradients accumulated into the reducer's flat buckets) -> eager bucketed RCCL
         all-reduce -> graph B (value clip + AdamW).  No collective is ever captured."""
@@ -294,7 +295,64 @@ class GraphedTrainStep:
         # they are harmless to this capture, so only police the capturing thread
         import torch.distributed as dist
         cap_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
-        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
+        # Single GPU, flat optimizer: the update of everything above the scene tokens (the Q-Former and the heads: 99 % of
+        # the parameters, 0.95 ms of streaming) runs on a stream of its own WHILE the point encoder's backward pass runs --
+        # the first is bound by HBM, the second by latency.  Two graphs (forward + upper backward | encoder backward +
+        # its own small update), one eager AdamW launch between them on the side stream, events at the graph boundaries
+        # (no cross-queue barrier is pending while a graph's kernels are enqueued: tools/probes/fork_penalty.py).
+        if update_beside is None:
+            update_beside = os.environ.get("SIG3D_UPDATE_BESIDE", "0") != "0"
+        self._beside = bool(update_beside and reducer is None and fused_opt and not self._geo_inline
+                            and hasattr(model, "encoder") and hasattr(model, "Qformer"))
+        if self._beside:
+            enc_ids = {id(p) for p in model.encoder.parameters()} | {id(p) for p in model.pos_embed.parameters()}
+            self._upper_params = [p for p in params if id(p) not in enc_ids]
+            self._lower_params = [p for p in params if id(p) in enc_ids]
+            self._side_opt = torch.cuda.Stream(stream.device)
+            self._beside_wgs = int(os.environ.get("SIG3D_UPDATE_BESIDE_WGS", "192"))   # workgroups of the side update
+            self._ev_a, self._ev_u = torch.cuda.Event(), torch.cuda.Event()
+            self.graph_enc = torch.cuda.CUDAGraph()
+            optimizer._tables(1)      # staging buffers of the two parts: pinned allocation is illegal in capture
+            optimizer._tables(2)
+            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
+                timeline.mark("main:start")
+                batch = dict(self.static_batch)
+                batch["_split_backward"] = True
+                batch["_qf_cut"] = None
+                if self.prefetch:
+                    batch["geometry_plan"] = self.plan_cur
+                STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)     # closed in the second graph
+                out = model(batch)
+                self._boundary = out.pop("_boundary")
+                out.pop("_qf_boundary", None)
+                out.pop("_split_backward", None)
+                out.pop("_qf_cut", None)
+                loss, out = get_loss(out)
+                self.static_out = out
+                loss.backward(inputs=self._upper_params + [self._boundary[1]])
+                _flush_deferred(model)
+                optimizer.begin_split_step()
+                self._table_u = optimizer.upload_part(self._upper_params, slot=1)
+                self.static_loss = loss
+                timeline.mark("main:backward done")
+            # the gradients the side stream's update reads stay allocated for good: the second graph (same pool) must not
+            # take their memory while the update may still be reading it
+            self._held_grads = [p.grad for p in self._upper_params if p.grad is not None]
+            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(),
+                                                           capture_error_mode=cap_mode):
+                tokens, leaf = self._boundary
+                tokens.backward(leaf.grad)
+                self._table_l = optimizer.upload_part(self._lower_params, slot=2)
+                optimizer.launch_part(self._table_l)
+                STEP_ZEROS.end_step()
+                timeline.mark("main:end")
+            self._held_grads += [p.grad for p in self._lower_params if p.grad is not None]
+            self._boundary = None
+            for p in params:
+                p.grad = None
+        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode) \
+                if not self._beside else contextlib.nullcontext():
+          if not self._beside:
             # data parallel: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
             # encoder's backward / the exchange / the update -- it gets its own graph on the side stream (below)
             if self._geo_inline:
@@ -378,6 +436,17 @@ class GraphedTrainStep:
                 self.prime(batch)  # pipeline prologue, or the caller broke the announced order
             self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
             self._announced.set(next_batch["point_clouds"], next_token)
+        if self._beside:
+            # forward + upper backward | the upper update on its own stream beside the encoder's backward and update
+            _copy_into(self.static_batch, batch)
+            self.graph.replay()
+            self._ev_a.record(self.stream)
+            self._side_opt.wait_event(self._ev_a)
+            self.optimizer.launch_part(self._table_u, stream=self._side_opt, max_workgroups=self._beside_wgs)
+            self._ev_u.record(self._side_opt)
+            self.graph_enc.replay()
+            self.stream.wait_event(self._ev_u)        # whatever follows on this stream (the next step, a checkpoint) sees
+            return self.static_loss                   # the updated parameters; the encoder's graph above did not wait
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         if self.reducer is not None:

@@ -124,13 +124,14 @@ class FlatAdamW(torch.optim.Optimizer):
             self._slots.append((host, host.numpy().view(_REC), torch.empty_like(self._table)))
         return self._slots[slot]
 
-    def _upload(self, dst_field_from_flat_g=False, slot=0):
-        """Fill the per-step columns of the table (gradient pointers) and push it to the device."""
+    def _upload(self, dst_field_from_flat_g=False, slot=0, only=None):
+        """Fill the per-step columns of the table (gradient pointers) and push it to the device.
+        only: a set of id(parameter) -- the records of every other parameter are empty."""
         gptr = np.zeros(len(self._params), dtype=np.uint64)
         live = np.zeros(len(self._params), dtype=bool)
         for i, (p, gi, off) in enumerate(self._params):
             g = p.grad
-            if g is None:
+            if g is None or (only is not None and id(p) not in only):
                 continue
             if not g.is_contiguous():
                 g = g.contiguous()
@@ -384,16 +385,40 @@ class FlatAdamW(torch.optim.Optimizer):
         b1, b2 = g0["betas"]
         self._launch_table(n, table, stream)
 
-    def _launch_table(self, n, table, stream):
+    def _launch_table(self, n, table, stream, max_workgroups=None):
         g0 = self.param_groups[0]
         b1, b2 = g0["betas"]
         args = [n, _lib.ptr(table), _lib.ptr(self._step), ctypes.c_float(g0["lr"]), _lib.ptr(self._lr_dev),
                 ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(g0["eps"]), ctypes.c_float(self.clip_value)]
-        bound = self.max_workgroups if self.max_workgroups is not None else DEFAULT_MAX_WORKGROUPS
+        bound = max_workgroups if max_workgroups is not None else \
+            (self.max_workgroups if self.max_workgroups is not None else DEFAULT_MAX_WORKGROUPS)
         if not bound:
             _lib.call("sig3d_adamw_table", *args, stream)
         else:
             _lib.call("sig3d_adamw_table_bounded", *args, int(bound), stream)
+
+    # ---- the update in two parts (graph_step.GraphedTrainStep, update_beside): the parameters whose gradients are
+    # complete after the first part of the backward pass are updated on ANOTHER stream while the rest of the backward
+    # pass runs; both launches read the step count advanced by begin_split_step()
+    @torch.no_grad()
+    def begin_split_step(self):
+        self.sync_lr()
+        with torch.cuda.device(self._dev):
+            _lib.call("sig3d_step_increment", _lib.ptr(self._step), _lib.stream_ptr(self._dev))
+
+    @torch.no_grad()
+    def upload_part(self, params, slot):
+        """Chunk table (call site `slot` >= 1) of the parameters in `params` that hold a gradient now -> the device table.
+        Inside a capture this is a memcpy node; the gradient tensors must stay alive as long as the table is used."""
+        return self._upload(slot=slot, only={id(p) for p in params})
+
+    @torch.no_grad()
+    def launch_part(self, table, stream=None, max_workgroups=None):
+        """One AdamW launch over a table of upload_part(), on `stream` (a torch stream) or the current one;
+        max_workgroups: a bounded grid that leaves the other stream's kernels their CU slots."""
+        with torch.cuda.device(self._dev):
+            sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr(self._dev)
+            self._launch_table(len(self._static), table, sp, max_workgroups=max_workgroups)
 
     @torch.no_grad()
     def update_buckets(self, reducer):

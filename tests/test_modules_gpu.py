@@ -798,3 +798,62 @@ def test_fused_bert_embeddings_dropout_and_row_sink():
     out4.square().sum().backward()
     dense = torch.zeros_like(emb.word_embeddings.weight).index_add_(0, ids.reshape(-1), rows)
     torch.testing.assert_close(emb.word_embeddings.weight.grad, dense, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_graphed_step_with_the_upper_update_on_its_own_stream_matches_eager(prefetch):
+    """GraphedTrainStep(update_beside=1): forward + upper backward | FlatAdamW over the Q-Former and the heads on a
+    stream of its own, beside the graph of the point encoder's backward pass and update.  Same trajectory as the eager steps, and the
+    same parameters afterwards as the plain one-graph form (float atomics: tolerance)."""
+    from situation3d_amd.graph_step import GraphedTrainStep
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.trainer import build_optimizer, train_step
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def make():
+        torch.manual_seed(3)
+        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
+
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for i in range(3):
+        b, n = 2, 5000
+        xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+        batches.append({
+            "point_clouds": torch.cat([xyz, torch.rand(b, n, 3, generator=g)], -1).to(DEV),
+            "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * b).to(DEV),
+            "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
+                       "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
+            "answer_cat_scores": torch.zeros(b, 16, device=DEV),
+        })
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        m1, o1 = make()
+        for _ in range(3):
+            train_step(m1, o1, dict(batches[0]))
+        eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(6)]
+        runs = {}
+        for beside in (0, 1):
+            m2, o2 = make()
+            gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=prefetch, update_beside=beside)
+            assert gs._beside == (beside == 1)
+            losses = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(6)]
+            work.synchronize()
+            runs[beside] = (losses, {n_: p.detach().clone() for n_, p in m2.named_parameters()})
+    torch.cuda.synchronize()
+    for beside in (0, 1):
+        torch.testing.assert_close(torch.tensor(runs[beside][0]), torch.tensor(eager), rtol=2e-3, atol=1e-4)
+    # parameters: Adam turns a gradient element that is pure rounding noise into a step of +-lr, so single elements may
+    # differ by a few lr; the parameter vectors as wholes must agree
+    def rel(a, b):
+        num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in a)
+        den = sum(float(b[k].double().pow(2).sum()) for k in a)
+        return (num / den) ** 0.5
+    eager_params = {n_: p.detach() for n_, p in m1.named_parameters()}
+    assert rel(runs[1][1], runs[0][1]) < 2e-3
+    assert rel(runs[1][1], eager_params) < 2e-3
