@@ -33,6 +33,7 @@ import torch
 from . import _lib
 
 _CHUNK = 65536
+_CAPTURE_SLOT = 7        # staging buffers: 0 eager, 1-6 the call sites of a captured step in parts, 7 a captured whole step
 _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
                  ("pad", "f4")])
 
@@ -112,6 +113,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._host_np = self._host.numpy().view(_REC)
         self._table = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev)
         self._slots = [(self._host, self._host_np, self._table)]
+        self._tables(_CAPTURE_SLOT)      # pinned memory cannot be allocated during a capture
         self._gathered = False
 
     # ---- chunk table ------------------------------------------------------------------------
@@ -141,6 +143,11 @@ class FlatAdamW(torch.optim.Optimizer):
         if dst_field_from_flat_g:
             self._live |= self._agree_on_liveness(live)
             self._live[self._external] = True
+        if slot == 0 and torch.cuda.is_current_stream_capturing():
+            # a captured upload is a memcpy node that re-reads its pinned staging buffer at every replay: it gets a
+            # buffer of its own, which an eager step() between two replays (the short last batch of an epoch) does not
+            # rewrite -- with the shared one the next replay walked a table of freed gradient tensors
+            slot = _CAPTURE_SLOT
         host, t, table = self._tables(slot)
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]
@@ -473,8 +480,8 @@ class FlatAdamW(torch.optim.Optimizer):
                                    stream)
                 self._gathered = False
             else:
-                self._upload()
-                self._launch_table(len(self._static), self._table, stream)
+                table = self._upload()
+                self._launch_table(len(self._static), table, stream)
                 for p, _, _ in self._params:
                     p.grad = None
         return loss

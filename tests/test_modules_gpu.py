@@ -857,3 +857,48 @@ def test_graphed_step_with_the_upper_update_on_its_own_stream_matches_eager(pref
     eager_params = {n_: p.detach() for n_, p in m1.named_parameters()}
     assert rel(runs[1][1], runs[0][1]) < 2e-3
     assert rel(runs[1][1], eager_params) < 2e-3
+
+
+def test_an_eager_step_between_two_replays_leaves_the_captured_update_intact():
+    """The short last batch of an epoch runs as an eager train_step between two replays of the graphed step, on the
+    same FlatAdamW.  The captured update uploads its chunk table from a pinned staging buffer at every replay; that
+    buffer must not be the one the eager step rewrites (it was: the next replay then walked a table of freed
+    gradient tensors).  Same trajectory as three eager steps."""
+    from situation3d_amd.graph_step import GraphedTrainStep
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.trainer import build_optimizer, train_step
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def make():
+        torch.manual_seed(5)
+        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
+
+    def batch(b, seed):
+        g = torch.Generator().manual_seed(seed)
+        xyz = torch.rand(b, 5000, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+        return {"point_clouds": torch.cat([xyz, torch.rand(b, 5000, 3, generator=g)], -1).to(DEV),
+                "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * b).to(DEV),
+                "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
+                           "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
+                "answer_cat_scores": torch.zeros(b, 16, device=DEV)}
+
+    full0, full1, short = batch(2, 1), batch(2, 2), batch(1, 3)
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        m1, o1 = make()
+        for _ in range(3):
+            train_step(m1, o1, dict(full0))
+        eager = [float(train_step(m1, o1, dict(bt)).item()) for bt in (full0, short, full1, full0)]
+        m2, o2 = make()
+        gs = GraphedTrainStep(m2, o2, full0)
+        got = [float(gs(full0).item())]
+        got.append(float(train_step(m2, o2, dict(short)).item()))      # eager, another batch size, same optimizer
+        got.append(float(gs(full1).item()))
+        got.append(float(gs(full0).item()))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(torch.tensor(got), torch.tensor(eager), rtol=2e-3, atol=1e-4)
