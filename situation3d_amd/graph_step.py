@@ -174,17 +174,21 @@ class GraphedTrainStep:
             if self.prefetch:
                 batch["geometry_plan"] = self.plan_cur
             STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)   # closed by bwd_encoder()
-            out = model(batch)
-            self._boundary = out.pop("_boundary")
-            self._qf_boundary = out.pop("_qf_boundary", None)
-            out.pop("_split_backward", None)
-            out.pop("_qf_cut", None)
-            loss, out = get_loss(out)
-            self.static_out = out
-            leaves = [self._boundary[1]] + ([self._qf_boundary[1]] if self._qf_boundary is not None else [])
-            loss.backward(inputs=self._upper_params + leaves)
-            _flush_deferred(model)   # weight gradients of the layers above the cut (qformer._WeightGradArena)
-            optimizer.gather_grads(slot=0, zero=True)
+            try:
+                out = model(batch)
+                self._boundary = out.pop("_boundary")
+                self._qf_boundary = out.pop("_qf_boundary", None)
+                out.pop("_split_backward", None)
+                out.pop("_qf_cut", None)
+                loss, out = get_loss(out)
+                self.static_out = out
+                leaves = [self._boundary[1]] + ([self._qf_boundary[1]] if self._qf_boundary is not None else [])
+                loss.backward(inputs=self._upper_params + leaves)
+                _flush_deferred(model)   # weight gradients of the layers above the cut (qformer._WeightGradArena)
+                optimizer.gather_grads(slot=0, zero=True)
+            except BaseException:
+                STEP_ZEROS.end_step()    # a step that died must not leave the zero region open for whoever runs next
+                raise
             return loss
 
         def bwd_lower():
@@ -198,11 +202,13 @@ class GraphedTrainStep:
 
         def bwd_encoder():
             """Split mode, last part: position MLP and point encoder from the tokens' gradient, own gather."""
-            tokens, leaf = self._boundary
-            tokens.backward(leaf.grad)
-            optimizer.gather_grads(slot=2, zero=False)
-            self._boundary = None
-            STEP_ZEROS.end_step()
+            try:
+                tokens, leaf = self._boundary
+                tokens.backward(leaf.grad)
+                optimizer.gather_grads(slot=2, zero=False)
+                self._boundary = None
+            finally:
+                STEP_ZEROS.end_step()
 
         fused_opt = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
         # data parallel + flat storage: AdamW runs bucket by bucket behind that bucket's all-reduce
@@ -314,38 +320,42 @@ class GraphedTrainStep:
             self.graph_enc = torch.cuda.CUDAGraph()
             optimizer._tables(1)      # staging buffers of the two parts: pinned allocation is illegal in capture
             optimizer._tables(2)
-            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
-                timeline.mark("main:start")
-                batch = dict(self.static_batch)
-                batch["_split_backward"] = True
-                batch["_qf_cut"] = None
-                if self.prefetch:
-                    batch["geometry_plan"] = self.plan_cur
-                STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)     # closed in the second graph
-                out = model(batch)
-                self._boundary = out.pop("_boundary")
-                out.pop("_qf_boundary", None)
-                out.pop("_split_backward", None)
-                out.pop("_qf_cut", None)
-                loss, out = get_loss(out)
-                self.static_out = out
-                loss.backward(inputs=self._upper_params + [self._boundary[1]])
-                _flush_deferred(model)
-                optimizer.begin_split_step()
-                self._table_u = optimizer.upload_part(self._upper_params, slot=1)
-                self.static_loss = loss
-                timeline.mark("main:backward done")
-            # the gradients the side stream's update reads stay allocated for good: the second graph (same pool) must not
-            # take their memory while the update may still be reading it
-            self._held_grads = [p.grad for p in self._upper_params if p.grad is not None]
-            with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(),
-                                                           capture_error_mode=cap_mode):
-                tokens, leaf = self._boundary
-                tokens.backward(leaf.grad)
-                self._table_l = optimizer.upload_part(self._lower_params, slot=2)
-                optimizer.launch_part(self._table_l)
-                STEP_ZEROS.end_step()
-                timeline.mark("main:end")
+            try:
+                with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
+                    timeline.mark("main:start")
+                    batch = dict(self.static_batch)
+                    batch["_split_backward"] = True
+                    batch["_qf_cut"] = None
+                    if self.prefetch:
+                        batch["geometry_plan"] = self.plan_cur
+                    STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)     # closed in the second graph
+                    out = model(batch)
+                    self._boundary = out.pop("_boundary")
+                    out.pop("_qf_boundary", None)
+                    out.pop("_split_backward", None)
+                    out.pop("_qf_cut", None)
+                    loss, out = get_loss(out)
+                    self.static_out = out
+                    loss.backward(inputs=self._upper_params + [self._boundary[1]])
+                    _flush_deferred(model)
+                    optimizer.begin_split_step()
+                    self._table_u = optimizer.upload_part(self._upper_params, slot=1)
+                    self.static_loss = loss
+                    timeline.mark("main:backward done")
+                # the gradients the side stream's update reads stay allocated for good: the second graph (same pool) must not
+                # take their memory while the update may still be reading it
+                self._held_grads = [p.grad for p in self._upper_params if p.grad is not None]
+                with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(),
+                                                               capture_error_mode=cap_mode):
+                    tokens, leaf = self._boundary
+                    tokens.backward(leaf.grad)
+                    self._table_l = optimizer.upload_part(self._lower_params, slot=2)
+                    optimizer.launch_part(self._table_l)
+                    STEP_ZEROS.end_step()
+                    timeline.mark("main:end")
+            except BaseException:
+                STEP_ZEROS.end_step()    # a capture that died must not leave the zero region open
+                raise
             self._held_grads += [p.grad for p in self._lower_params if p.grad is not None]
             self._boundary = None
             for p in params:
