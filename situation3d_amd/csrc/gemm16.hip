@@ -81,8 +81,12 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(int n4, int nslabs, size
 
 const int SIG3D_DW_STREAM_WGS = getenv("SIG3D_DW_STREAM_WGS") ? atoi(getenv("SIG3D_DW_STREAM_WGS")) : 512;
 
+// 131 / 259 input channels (3 coordinates in front of 128 / 256 features): 64-wide column tiles would give a third / a
+// fifth of the workgroups 3 live columns; 48-wide ones (4 waves of 16 x 48) waste 9-10 % instead
+inline bool dw_narrow_tiles(int cin) { return cin % 64 != 0 && cin % 64 <= 16 && cin > 64; }
+
 int dw_stream_splits(int b, int cin, int cout, long e) {
-  const int tiles = sig3d_ceil_div(cout, 64) * sig3d_ceil_div(cin, 64);
+  const int tiles = sig3d_ceil_div(cout, 64) * sig3d_ceil_div(cin, dw_narrow_tiles(cin) ? 48 : 64);
   int s = SIG3D_DW_STREAM_WGS / (tiles * (b > 0 ? b : 1));          // default: two 64 x 64 workgroups per CU
   const long chunks = (e + 31) / 32;
   if (s > chunks / 4) s = (int)(chunks / 4);
@@ -130,7 +134,8 @@ extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const
   p.sA = (long)cout * e; p.sB = (long)cin * e; p.sC = 0; p.slab = slab;
   p.batch = b; p.splits = splits; p.act = 0;
   p.k_dev = n_act; p.b_scale = pscale; p.b_shift = pshift;
-  hipError_t err = gemm16::launch<1, 2, 4, 2, 4, 2, true>(p, gemm16::B_KC, stream);
+  hipError_t err = dw_narrow_tiles(cin) ? gemm16::launch<1, 3, 4, 1, 4, 3, true>(p, gemm16::B_KC, stream)
+                                        : gemm16::launch<1, 2, 4, 2, 4, 2, true>(p, gemm16::B_KC, stream);
   if (err != hipSuccess) { sig3d_set_error("gemm16_kernel (weight gradient)", err); return (int)err; }
   if (pairs > 1) {
     SIG3D_REQUIRE(((size_t)dW & 15) == 0 && ((long)cout * cin) % 4 == 0, "dW: 16-byte aligned, cout * cin a multiple of 4");
