@@ -561,6 +561,44 @@ typedef struct sig3d_gemm16_problem {
 int sig3d_gemm16(const sig3d_gemm16_problem *problem, void *stream);
 int sig3d_gemm16_splits(int bmode, int batch, int m, int n, int k, int act, int config);
 
+/* Round 5: the f32 GEMM on the bf16 matrix cores over operands that arrive SPLIT (csrc/gemmp_core.h).  Replaces the
+ * rocBLAS / hipBLASLt launches behind the layer-batched weight gradients dW = dY^T X of the Q-Former's dense layers
+ *   Qformer.py:116-118, :238, :305, :320 (torch: bmm / mm in the backward pass)
+ * and offers the forward (x W^T) and input-gradient (dY W) forms of the same layers.
+ * An f32 matrix X (R rows, C columns, C % 32 == 0) is stored as "chunked planes": x = p1 + p2 + p3 exactly, three bf16
+ * terms (round to nearest even, subtract, repeat), laid out [C / 32][row capacity][3][32] bf16 -- the three planes of 32
+ * consecutive columns of a row are 192 consecutive bytes, rows follow each other, 32-column chunks are `chunk` elements
+ * apart (chunk >= rows * 96).  sig3d_planes_split writes that form (batch matrices; src rows `ld` floats apart).
+ * sig3d_gemmp, for every batch element i < batch (operands advance by their stride_* elements):
+ *     C (m x n, row stride ldc)  =  A * B  [+ bias]  [epilogue]  [+ addend]     (six bf16 products per f32 product,
+ *                                                                  f32 accumulation: f32-equivalent, not reduced)
+ * modes 0: A = planes of x (m, k), B = planes of W (n, k)           y = x W^T        k % 32 == 0
+ *       1: A = planes of dY (m, k), B = planes of W (k, n)          dX = dY W        k % 32 == 0, n % 32 == 0
+ *       2: A = planes of dY (k, m), B = planes of X (k, n)          dW = dY^T X      m % 32 == 0, n % 32 == 0, any k % 8 == 0
+ * (a matrix is stored ONCE: its planes serve with its columns or with its rows as the reduction index).
+ * bytes_a / bytes_b: how many bytes may be read from A / B of one batch element (requests beyond return zeros).
+ * bias / addend / act / aux: as sig3d_gemm16.  C may be NULL when only C_planes (chunked planes of the result after
+ * the epilogue, chunk stride chunk_c, batch stride stride_cp) is wanted.
+ * splits > 1: that many workgroups share a tile's reduction; each parks its partial tile in `work`
+ * (sig3d_gemmp_work_floats floats), the last to arrive adds them in split order and runs the epilogue; `counters` (one
+ * unsigned per tile, zero before the first launch, left zero) order them.  config: 0 choose, 1 = 64 x 64 tiles,
+ * 2 = 64 x 128, 3 = 128 x 128. */
+int sig3d_planes_split(int batch, int rows, int cols, const float *src, int ld, long src_stride, void *planes,
+                       long chunk_stride, long planes_stride, void *stream);
+typedef struct sig3d_gemmp_problem {
+  const void *A; long chunk_a; long stride_a; long bytes_a;
+  const void *B; long chunk_b; long stride_b; long bytes_b;
+  float *C; int ldc; long stride_c;
+  void *C_planes; long chunk_c; long stride_cp;
+  const float *bias; long stride_bias;
+  const float *addend;
+  float *aux;
+  float *work; unsigned *counters;
+  int modes, batch, m, n, k, act, splits, config;
+} sig3d_gemmp_problem;
+int sig3d_gemmp(const sig3d_gemmp_problem *problem, void *stream);
+long sig3d_gemmp_work_floats(int batch, int m, int n, int splits, int config);
+
 /* ---- Q-Former attention ---------------------------------------------------------------- */
 
 /* replaces BertSelfAttention.forward's core

@@ -191,6 +191,55 @@ def gemm16(device, **kw):
         call("sig3d_gemm16", ctypes.byref(p), stream_ptr(device))
 
 
+class GemmpProblem(ctypes.Structure):
+    """struct sig3d_gemmp_problem of include/sig3d_hip.h (field order and types must match)."""
+    _fields_ = [("A", _P), ("chunk_a", ctypes.c_long), ("stride_a", ctypes.c_long), ("bytes_a", ctypes.c_long),
+                ("B", _P), ("chunk_b", ctypes.c_long), ("stride_b", ctypes.c_long), ("bytes_b", ctypes.c_long),
+                ("C", _P), ("ldc", _I), ("stride_c", ctypes.c_long),
+                ("C_planes", _P), ("chunk_c", ctypes.c_long), ("stride_cp", ctypes.c_long),
+                ("bias", _P), ("stride_bias", ctypes.c_long),
+                ("addend", _P), ("aux", _P), ("work", _P), ("counters", _P),
+                ("modes", _I), ("batch", _I), ("m", _I), ("n", _I), ("k", _I), ("act", _I), ("splits", _I),
+                ("config", _I)]
+
+
+SIGNATURES["sig3d_gemmp"] = [ctypes.POINTER(GemmpProblem), _P]
+SIGNATURES["sig3d_planes_split"] = [_I, _I, _I, _P, _I, ctypes.c_long, _P, ctypes.c_long, ctypes.c_long, _P]
+
+
+def gemmp(device, **kw):
+    """C = A B (+ bias) (epilogue) (+ addend) on chunked bf16 planes through sig3d_gemmp; tensors or raw pointers."""
+    p = GemmpProblem()
+    vals = dict(A=None, chunk_a=0, stride_a=0, bytes_a=0, B=None, chunk_b=0, stride_b=0, bytes_b=0, C=None, ldc=0,
+                stride_c=0, C_planes=None, chunk_c=0, stride_cp=0, bias=None, stride_bias=0, addend=None, aux=None,
+                work=None, counters=None, modes=0, batch=1, m=0, n=0, k=0, act=0, splits=1, config=0)
+    vals.update(kw)
+    for name, v in vals.items():
+        setattr(p, name, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    with torch.cuda.device(device):
+        call("sig3d_gemmp", ctypes.byref(p), stream_ptr(device))
+
+
+def gemmp_work_floats(batch, m, n, splits, config=0):
+    f = load().sig3d_gemmp_work_floats
+    f.restype = ctypes.c_long
+    return int(f(batch, m, n, splits, config))
+
+
+def planes_split(src, planes, rows=None, chunk_rows=None):
+    """src (batch, R, C) or (R, C) f32 (rows contiguous) -> chunked bf16 planes (batch, C / 32, chunk_rows, 96) int16;
+    only the first `rows` rows are split."""
+    if src.dim() == 2:
+        src = src.unsqueeze(0)
+    batch, r_all, cols = src.shape
+    rows = r_all if rows is None else rows
+    chunk_rows = planes.shape[-2] if chunk_rows is None else chunk_rows
+    with torch.cuda.device(src.device):
+        call("sig3d_planes_split", batch, rows, cols, ptr(src), src.stride(1), src.stride(0), ptr(planes),
+             chunk_rows * 96, (cols // 32) * chunk_rows * 96, stream_ptr(src.device))
+    return planes
+
+
 class BqLevel(ctypes.Structure):
     """sig3d_bq_level of include/sig3d_hip.h: one ball-query problem of a multi-level launch."""
     _fields_ = [("n", _I), ("m", _I), ("nsample", _I), ("radius", _F), ("xyz", _P), ("new_xyz", _P), ("idx", _P)]
@@ -217,7 +266,7 @@ def bq_levels_workspace_bytes(batch, arr):
 
 INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes",
                 "sig3d_ball_query_levels_workspace_bytes", "sig3d_pooled_heads_work_floats",
-                "sig3d_mlp_layer_dw_stream_work_floats")
+                "sig3d_mlp_layer_dw_stream_work_floats", "sig3d_gemmp_work_floats")
 
 _lib = None
 
