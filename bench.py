@@ -143,6 +143,8 @@ from situation3d_amd.trainer import build_optimizer, get_loss, train_step  # noq
 N_POINTS, BATCH, N_QUERY, N_TEXT, NUM_ANSWERS = 40000, 8, 32, 20, 706
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_F32_PEAK_TFLOPS = 157.3   # same guide: peak FP32 (vector)
+MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: f32-input MFMA runs at the f32 vector rate
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # same guide: dense bf16 matrix peak
 LDS_PEAK_GBS = 150000.0        # same guide: ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
 SA_LEVELS = [(40000, 2048, 64, 3), (2048, 1024, 32, 128), (1024, 512, 16, 256), (512, 256, 16, 256)]
 
@@ -578,6 +580,74 @@ def forward_only_variant(device, bsz=4, reps=20):
             "batch": bsz, "note": "hipGraph replay of one forward; and two geometry chains in flight (serve.PipelinedForward)"}
 
 
+def config5_variant(device, bsz=4, reps=5):
+    """BASELINE config 5 at its single-GPU shape (3D-LLM BLIP-2 point branch, blip2_t5.py:102-129): B = 4 scenes of
+    Nk point tokens of width 1408 -> position embedding -> Q-Former (32 queries, six cross-attention layers) -> t5_proj.
+    The key / value projections of the six cross layers are 94 % of the FLOPs: they run on sig3d_gemmp (six
+    bf16 matrix-core products per f32 product over operands split once) -- timed launch by launch with HIP events --
+    and, for the comparison, on the library (SIG3D_QF_BIG_ROWS=0)."""
+    from situation3d_amd import qformer as qf
+    from situation3d_amd.blip2 import Blip2PointQFormer
+    torch.manual_seed(55)
+    model = Blip2PointQFormer().to(device).eval()
+    out = {}
+    big_rows = qf.BIG_ROWS
+
+    def run(nk, backward, own):
+        qf.BIG_ROWS = big_rows if own else 0
+        g = torch.Generator(device="cpu").manual_seed(77)
+        feat = torch.randn(bsz, nk, 1408, device=device)
+        pc = torch.randint(0, 256, (bsz, nk, 3), generator=g).float().to(device)
+
+        def once():
+            if backward:
+                f = feat.detach().requires_grad_(True)
+                model.zero_grad(set_to_none=True)
+                model({"pc_feat": f, "pc": pc})["inputs_t5"].sum().backward()
+            else:
+                with torch.no_grad():
+                    model({"pc_feat": feat, "pc": pc})
+        for _ in range(2):
+            once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        proj_ms = None
+        if own:     # the projections' launches, bracketed by events on their stream
+            _lib.enable_timing(["sig3d_gemmp"])
+            once()
+            torch.cuda.synchronize()
+            recs = _lib.timing_records()["sig3d_gemmp"]
+            _lib.enable_timing(None)
+            proj_ms = [s_.elapsed_time(e_) for s_, e_, _ in recs]
+        del feat, pc
+        torch.cuda.empty_cache()
+        return dt, proj_ms
+
+    for key, nk, backward in (("forward, Nk=80000", 80000, False), ("forward + backward, Nk=5000", 5000, True)):
+        dt, proj_ms = run(nk, backward, True)
+        dt_lib, _ = run(nk, backward, False)
+        flops = 2.0 * bsz * nk * 1408 * 1536 * 6 * (3 if backward else 1)
+        ach = flops / (sum(proj_ms) * 1e-3) / 1e12
+        out[key] = {
+            "ms": round(dt * 1e3, 3), "value": round(bsz / dt, 2), "unit": "samples/s", "batch": bsz,
+            "library_projections_ms": round(dt_lib * 1e3, 3),
+            "roofline_kv_projection": {
+                "bound": "mfma", "launches": len(proj_ms), "ms": round(sum(proj_ms), 3), "flops": flops,
+                "achieved": round(ach, 1), "unit": "TFLOP/s (f32-equivalent)", "peak": MFMA_F32_PEAK_TFLOPS,
+                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                "issued_bf16": {"achieved": round(6 * ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(6 * ach / MFMA_BF16_PEAK_TFLOPS, 4)},
+                "dtype": "f32 results from six bf16 products per f32 product (three-term split, f32 accumulation)"}}
+    qf.BIG_ROWS = big_rows
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def refuse_probes():
     """Measurement switches (tools/probes/geo_probes.py) skip or replace work inside a captured step; the product reads
     none of them any more, but a bench line produced with one in the environment would invite the question."""
@@ -750,6 +820,8 @@ def main():
         # graph (bound by the 2047 dependent FPS rounds of SA1) and the throughput with geometry chains of two
         # batches in flight (serve.PipelinedForward)
         variants["config 2: forward only, B=4"] = forward_only_variant(device)
+        # BASELINE config 5 at its single-GPU shape: the BLIP-2 point branch over 80 000 / 5000 point tokens per scene
+        variants["config 5: Blip2 point Q-Former, B=4, d_enc 1408"] = config5_variant(device)
         if rank == 0:
             out["variants"] = variants
     if rank == 0 and world == 1 and not args.no_ops_roofline:

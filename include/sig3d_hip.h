@@ -574,9 +574,9 @@ int sig3d_gemm16_splits(int bmode, int batch, int m, int n, int k, int act, int 
  *                                                                  f32 accumulation: f32-equivalent, not reduced)
  * modes 0: A = planes of x (m, k), B = planes of W (n, k)           y = x W^T        k % 32 == 0
  *       1: A = planes of dY (m, k), B = planes of W (k, n)          dX = dY W        k % 32 == 0, n % 32 == 0
- *       2: A = planes of dY (k, m), B = planes of X (k, n)          dW = dY^T X      m % 32 == 0, n % 32 == 0, any k % 8 == 0
+ *       2: A = planes of dY (k, m), B = planes of X (k, n)          dW = dY^T X      m % 32 == 0, n % 32 == 0, any k
  * (a matrix is stored ONCE: its planes serve with its columns or with its rows as the reduction index).
- * bytes_a / bytes_b: how many bytes may be read from A / B of one batch element (requests beyond return zeros).
+ * bytes_a / bytes_b: how many bytes may be read from A / B of one batch element (requests beyond return zeros; < 4 GB).
  * bias / addend / act / aux: as sig3d_gemm16.  C may be NULL when only C_planes (chunked planes of the result after
  * the epilogue, chunk stride chunk_c, batch stride stride_cp) is wanted.
  * splits > 1: that many workgroups share a tile's reduction; each parks its partial tile in `work`

@@ -101,8 +101,8 @@ extern "C" int sig3d_gemmp(const sig3d_gemmp_problem *qp, void *stream_) {
   auto al = [](const void *p) { return ((size_t)p & 15) == 0; };
   SIG3D_REQUIRE(q.A && q.B && al(q.A) && al(q.B) && q.chunk_a % 8 == 0 && q.chunk_b % 8 == 0 && q.stride_a % 8 == 0 &&
                     q.stride_b % 8 == 0, "A / B: 16-byte aligned chunked planes");
-  SIG3D_REQUIRE(q.bytes_a > 0 && q.bytes_b > 0 && q.bytes_a < (1ll << 31) && q.bytes_b < (1ll << 31),
-                "bytes_a / bytes_b: the readable extent of one batch element, below 2 GB");
+  SIG3D_REQUIRE(q.bytes_a > 0 && q.bytes_b > 0 && q.bytes_a < (1ll << 32) - 4096 && q.bytes_b < (1ll << 32) - 4096,
+                "bytes_a / bytes_b: the readable extent of one batch element, below 4 GB");
   SIG3D_REQUIRE(q.C || q.C_planes, "no result requested");
   SIG3D_REQUIRE(!q.C || (al(q.C) && q.ldc % 4 == 0 && q.stride_c % 4 == 0), "C: 16-byte aligned rows");
   SIG3D_REQUIRE(!q.C_planes || (al(q.C_planes) && q.n % 32 == 0 && q.chunk_c >= (long)q.m * 96), "C planes: n in chunks of 32");

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
       k = 0;
     } else {
       const int ccl = j / 384, r = (j % 384) / 12;
-      v = (int)(min(t0 / 32 + ccl, extent / 32 - 1) * cs * 2) + r * ROWB + rem * 16;
+      v = (int)(unsigned)((long)min(t0 / 32 + ccl, extent / 32 - 1) * cs * 2 + r * ROWB + rem * 16);   // < 4 GB
       s = pl * PLANE + lds_base + ccl * CCB + r * 64 + q * 16;
       k = r;
     }
@@ -185,8 +185,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
 #pragma unroll
   for (int i = 0; i < B_PER; ++i)
     place(BMODE, min(tid + NT * i, B_UNITS - 1), TN, n0, N, p.csB, PARTA, vo[A_PER + i], so[A_PER + i], ko[A_PER + i]);
-  const int a_step = AMODE == OP_K ? (int)(p.csA * 2) : BK * ROWB, b_step = BMODE == OP_K ? (int)(p.csB * 2) : BK * ROWB;
-  const int a_first = c_lo * a_step, b_first = c_lo * b_step;
+  // byte offsets are UNSIGNED 32-bit numbers (an operand may be up to 4 GB: 320 000 point tokens x 1408 x 6 bytes)
+  const unsigned a_step = AMODE == OP_K ? (unsigned)(p.csA * 2) : BK * ROWB, b_step = BMODE == OP_K ? (unsigned)(p.csB * 2) : BK * ROWB;
+  const unsigned a_first = (unsigned)c_lo * a_step, b_first = (unsigned)c_lo * b_step;
 
   u32x4 ring[PF][NU];
   if (GEMMP_KO & 1) {
@@ -199,17 +200,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
   static_assert(PF * NLOAD * 4 <= 160, "ring too large: hipcc would move in-flight registers");
 
   // request i of chunk c_ (A pieces first); issued UNCONDITIONALLY (hand-counted vmcnt): beyond the last chunk the
-  // scalar offset points past the operand and the request returns zeros at once
+  // scalar offset points past the operand and the request returns zeros at once (or, wrapping, reads something
+  // inside it that nobody looks at)
   auto load_unit = [&](int c_, auto i_, u32x4 (&rg)[NU]) {
     constexpr int u = decltype(i_)::value;
     (void)vo; (void)rsA; (void)rsB;
     if (GEMMP_KO & 1) return;
     const bool live = c_ < nchunks;
     if constexpr (u < A_PER) {
-      const int s = live ? a_first + c_ * a_step : 0x7ffffff0;
+      const unsigned s = live ? a_first + (unsigned)c_ * a_step : 0xffffff00u;
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rg[u]) : "v"(vo[u]), "s"(rsA), "s"(s) : "memory");
     } else {
-      const int s = live ? b_first + c_ * b_step : 0x7ffffff0;
+      const unsigned s = live ? b_first + (unsigned)c_ * b_step : 0xffffff00u;
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rg[u]) : "v"(vo[u]), "s"(rsB), "s"(s) : "memory");
     }
   };

@@ -147,6 +147,29 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_lds_kernel(
   }
 }
 
+// ---- scenes stay on one XCD ---------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has an L2 of its own (4 MiB).  With
+// the scene in blockIdx.z every scene's workgroups are spread over all eight L2s and each L2 sees the source rows of
+// all eight scenes (8.4 MB at SA3: PMC FETCH 3.7 x the algorithmic reads).  On a 1-D grid, workgroup L (XCD L % 8) takes
+// scene L % 8 (+ 8 per further round of scenes; b = 1, 2, 4: 8 / b XCDs share a scene): a scene's sources are then
+// fetched into ONE L2.  A pure speed choice (guide: placement may change speed only): any other dealing gives the same
+// result.  w is the workgroup's index inside its scene (0 .. per_scene - 1).
+__device__ __forceinline__ void xcd_local_scene(int b, int per_scene, int &scene, int &w) {
+  const int L = blockIdx.x;
+  if ((b & 7) == 0) {
+    const int k = L >> 3;
+    scene = (L & 7) + 8 * (k / per_scene);
+    w = k % per_scene;
+  } else if (b < 8 && 8 % b == 0 && per_scene % (8 / b) == 0) {
+    const int x = L & 7, r = 8 / b;
+    scene = x % b;
+    w = (L >> 3) * r + x / b;
+  } else {
+    scene = L / per_scene;
+    w = L - scene * per_scene;
+  }
+}
+
 // Fused QueryAndGroup tail (pointnet2_utils.py:348-359): channels [0,3) = (xyz[idx] - centre)
 // [/ radius], channels [3, 3+c) = features[idx]; one pass, grouped tensor written once.
 // blockIdx.y == 0 handles the xyz slab (when use_xyz), the others feature slabs.
@@ -160,12 +183,16 @@ __device__ __forceinline__ void gp_store4(float *o, float a, float b, float c, f
 
 template <bool VEC4, bool NT>
 __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
-    int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
+    int b, int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
-  const int bi = blockIdx.z;
   const long total = (long)m * nsample;
-  const long e = ((long)blockIdx.x * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
+  const int tiles_e = (int)(((VEC4 ? total / 4 : total) + GP_THREADS - 1) / GP_THREADS);
+  const int slabs = (use_xyz ? 1 : 0) + (c + GP_CSLAB - 1) / GP_CSLAB;
+  int bi, w;
+  xcd_local_scene(b, tiles_e * slabs, bi, w);
+  const int by = w / tiles_e, bx = w - by * tiles_e;
+  const long e = ((long)bx * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
   if (e >= total) return;
   const int c_total = (use_xyz ? 3 : 0) + c;
   const int *ip = idx + (size_t)bi * total + e;
@@ -177,7 +204,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
     ii[0] = *ip;
   }
   constexpr int V = VEC4 ? 4 : 1;
-  int slab = blockIdx.y;
+  int slab = by;
   if (use_xyz) {
     if (slab == 0) {
       // nsample % 4 == 0 on the vector path, so the four samples share one centre
@@ -236,16 +263,20 @@ constexpr int GPM_C = 128;   // channels per tile
 // back to back, centre_of their centres, n_act[b] how many there are; positions >= n_act[b] are not written.
 template <bool COMPACT>
 __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
-    int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
+    int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
     const int *__restrict__ idx, float *__restrict__ out, const int *__restrict__ centre_of,
     const int *__restrict__ n_act) {
   __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
-  const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stride = m * nsample;                       // positions per (batch, channel) row of out
+  const int tiles_e = (stride + GPM_P - 1) / GPM_P, tiles_c = (c + GPM_C - 1) / GPM_C;
+  int bi, w;
+  xcd_local_scene(b, tiles_e * tiles_c, bi, w);
+  const int by = w / tiles_e, bx = w - by * tiles_e;    // element tile fastest: neighbours share source rows
+  const int c0 = by * GPM_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = COMPACT ? n_act[bi] : stride;       // positions that exist
-  const int e0 = blockIdx.x * GPM_P;
+  const int e0 = bx * GPM_P;
   if (e0 >= total) return;
   const int c_total = (use_xyz ? 3 : 0) + c;
   const int *ip = idx + (size_t)bi * stride;
@@ -270,7 +301,7 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
     s_tile[p * (GPM_C / 4) + (j ^ (p & 7))] = v[r];
   }
   // the xyz slab rides along with the first channel tile: lane p of wave 0 handles element e0 + p
-  if (use_xyz && blockIdx.y == 0 && wave == 0) {
+  if (use_xyz && by == 0 && wave == 0) {
     const int e = e0 + lane;
     if (e < total) {
       const int a = ip[e], jc = COMPACT ? centre_of[(size_t)bi * stride + e] : e / nsample;
@@ -328,12 +359,16 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
 // A half-wave walks 8 consecutive elements and merges runs of equal indices in registers first: ball
 // query pads a short neighbour list with its first hit, so most of a list is one repeated index.
 __global__ __launch_bounds__(GP_THREADS) void group_points_grad_pm_kernel(
-    int n, int c, int ld, int stride, int c_total, int c_off, const float *__restrict__ grad_out,
+    int b, int n, int c, int ld, int stride, int c_total, int c_off, const float *__restrict__ grad_out,
     const int *__restrict__ idx, float *__restrict__ grad_pm, const int *__restrict__ n_act) {
   __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
-  const int bi = blockIdx.z, c0 = blockIdx.y * GPM_C;
+  const int tiles_e = (stride + GPM_P - 1) / GPM_P, tiles_c = (c + GPM_C - 1) / GPM_C;
+  int bi, w;
+  xcd_local_scene(b, tiles_e * tiles_c, bi, w);    // a scene's scattered rows are added in ONE L2
+  const int by = w / tiles_e, bx = w - by * tiles_e;
+  const int c0 = by * GPM_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int e0 = blockIdx.x * GPM_P;
+  const int e0 = bx * GPM_P;
   const int total = n_act ? n_act[bi] : stride;   // compact mode: only the distinct neighbours exist
   if (e0 >= total) return;
   {
@@ -528,14 +563,14 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused: n must be >= 1 when idx is non-empty");
   const bool vec = (nsample % 4 == 0);
-  dim3 grid(sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS),
-            (use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB), b);
+  dim3 grid((unsigned)((long)sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS) *
+                       ((use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB)) * b));   // 1-D: xcd_local_scene
   // the vector path streams the grouped tensor out with nontemporal stores (+4 % on this kernel)
   if (vec)
-    hipLaunchKernelGGL((query_group_fused_kernel<true, true>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+    hipLaunchKernelGGL((query_group_fused_kernel<true, true>), grid, dim3(GP_THREADS), 0, stream, b, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   else
-    hipLaunchKernelGGL((query_group_fused_kernel<false, false>), grid, dim3(GP_THREADS), 0, stream, n, m, c,
+    hipLaunchKernelGGL((query_group_fused_kernel<false, false>), grid, dim3(GP_THREADS), 0, stream, b, n, m, c,
                        nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz, features, idx, out);
   SIG3D_LAUNCH_CHECK("query_group_fused_kernel");
   return 0;
@@ -561,12 +596,12 @@ static int launch_group_pm(int b, int n, int m, int c, int ld, int nsample, int 
   SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused_pm: n must be >= 1 when idx is non-empty");
-  dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
+  dim3 grid((unsigned)(sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b));   // 1-D: xcd_local_scene
   if (n_act != nullptr)
-    hipLaunchKernelGGL(query_group_fused_pm_kernel<true>, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample,
+    hipLaunchKernelGGL(query_group_fused_pm_kernel<true>, grid, dim3(GP_THREADS), 0, stream, b, n, m, c, ld, nsample,
                        use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
   else
-    hipLaunchKernelGGL(query_group_fused_pm_kernel<false>, grid, dim3(GP_THREADS), 0, stream, n, m, c, ld, nsample,
+    hipLaunchKernelGGL(query_group_fused_pm_kernel<false>, grid, dim3(GP_THREADS), 0, stream, b, n, m, c, ld, nsample,
                        use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
   SIG3D_LAUNCH_CHECK("query_group_fused_pm_kernel");
   return 0;
@@ -611,8 +646,8 @@ static int launch_group_grad_pm(int b, int n, int m, int c, int ld, int nsample,
   if (b == 0 || n == 0) return 0;
   if (!zeroed) SIG3D_HIP_TRY(hipMemsetAsync(grad_features_pm, 0, sizeof(float) * (size_t)b * n * ld, stream));
   if (total == 0) return 0;
-  dim3 grid(sig3d_ceil_div(total, GPM_P), sig3d_ceil_div(c, GPM_C), b);
-  hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, n, c, ld, (int)total, c_total,
+  dim3 grid((unsigned)(sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b));   // 1-D: xcd_local_scene
+  hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, b, n, c, ld, (int)total, c_total,
                      c_off, grad_out, idx, grad_features_pm, n_act);
   SIG3D_LAUNCH_CHECK("group_points_grad_pm_kernel");
   return 0;

@@ -25,12 +25,12 @@ torch's Philox (same distribution, different bits); eval mode is deterministic.
 """
 import ctypes
 import math
-import weakref
 import os
 from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib, scratch
 
@@ -129,6 +129,54 @@ OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
 # SIG3D_QF_GEMM_CONFIG: which core / tiling sig3d_gemm16 uses for those products: 0 its own choice among the f32 tilings,
 # 1-3 one of them, 11 / 12 the bf16 x 6 core (gemmx6_core.h: three-term bf16 split, six products, f32-equivalent)
 OWN_CONFIG = int(os.environ.get("SIG3D_QF_GEMM_CONFIG", "0"))
+
+
+# SIG3D_QF_DW: the layer-batched weight-gradient products dW = dY^T X of _WeightGradArena.flush() on sig3d_gemmp
+# (csrc/gemmp_core.h: the f32 product as six bf16 products over operands split ONCE into chunked bf16 planes, both
+# operands read through the LDS transposing read, 128 x 128 tiles) instead of torch.bmm (rocBLAS / hipBLASLt).
+OWN_DW = os.environ.get("SIG3D_QF_DW", "0") != "0"
+
+
+# Cross-attention over MANY encoder tokens (the 3D-LLM shape: B x 5000 ... 80 000 point tokens of width 1408,
+# blip2_t5.py:102-129): the key / value projection of every cross layer, its input gradient and its weight gradient are
+# products with 10^4 ... 10^5 rows -- 94 % of the Q-Former's FLOPs.  From SIG3D_QF_BIG_ROWS source rows on
+# they run on sig3d_gemmp: the encoder tokens are split into chunked bf16 planes ONCE per forward (all cross layers
+# read the same tokens), the stacked [Wk; Wv] per layer; 1.2-2.3 x the library at these shapes (profiles/r05_gemmp.md).
+BIG_ROWS = int(os.environ.get("SIG3D_QF_BIG_ROWS", "8192"))     # 0: never
+
+
+def _planes(t2):
+    """Chunked bf16 planes of a contiguous (rows, cols) f32 matrix: (1, cols / 32, rows, 96) int16."""
+    rows, cols = t2.shape
+    return _lib.planes_split(t2, torch.empty((1, cols // 32, rows, 96), dtype=torch.int16, device=t2.device))
+
+
+class _EncoderPlanes:
+    """The planes of the encoder tokens of ONE forward pass, found again by the tensor OBJECT the cross layers are handed
+    (held weakly: the entry dies with the tensor; a tensor written in place since is split again)."""
+    _cache = WeakIdKeyDictionary()      # keyed by identity: a tensor's == is element-wise
+
+    @classmethod
+    def of(cls, enc):
+        hit = cls._cache.get(enc)
+        if hit is not None and hit[0] == enc._version:
+            return hit[1]
+        with torch.no_grad():
+            pl = _planes(enc.detach().reshape(-1, enc.shape[-1]).contiguous())
+        cls._cache[enc] = (enc._version, pl)
+        return pl
+
+
+def _big_source(enc, width_out):
+    return (BIG_ROWS > 0 and enc is not None and enc.is_cuda and enc.dtype == torch.float32 and enc.dim() == 3
+            and enc.shape[0] * enc.shape[1] >= BIG_ROWS and (enc.shape[0] * enc.shape[1]) % 8 == 0
+            and enc.shape[2] % 32 == 0 and width_out % 32 == 0
+            and enc.shape[0] * enc.shape[1] * max(enc.shape[2], width_out) * 6 < (1 << 32) - 4096)   # 32-bit buffer offsets
+
+
+def _gp(planes, rows_cap=None):
+    """Keyword pieces of a sig3d_gemmp operand: planes (1, cols / 32, rows, 96)."""
+    return planes, planes.shape[2] * 96, planes.numel(), planes.numel() * 2
 
 
 def _g16(dev, **kw):
@@ -399,7 +447,7 @@ class _ProjAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, kv_src, wq, bq, wk, bk, wv, bv, mask, num_heads, p_drop, call_id,
-                layout=None):
+                layout=None, enc_planes=None):
         dev = hidden.device
         if layout is None:
             b, nq, c = hidden.shape
@@ -425,7 +473,15 @@ class _ProjAttentionFn(torch.autograd.Function):
             w_all = _stacked((wk, wv))
             b_all = _stacked((bk, bv))
             proj = torch.addmm(bq, x2, wq.t())                  # (B*N, hd)
-            kvproj = torch.addmm(b_all, e2, w_all.t())          # (B*Nk, 2*hd)
+            if enc_planes is None:
+                kvproj = torch.addmm(b_all, e2, w_all.t())      # (B*Nk, 2*hd)
+            else:   # many encoder tokens: six bf16 products per f32 product over the planes split once per forward
+                w_planes = _planes(w_all)
+                kvproj = torch.empty((b * nk, 2 * hd), dtype=torch.float32, device=dev)
+                pa, ca, sa_, ba = _gp(enc_planes)
+                pb, cb, sb_, bb = _gp(w_planes)
+                _lib.gemmp(dev, A=pa, chunk_a=ca, stride_a=sa_, bytes_a=ba, B=pb, chunk_b=cb, stride_b=sb_, bytes_b=bb,
+                           C=kvproj, ldc=2 * hd, bias=b_all, modes=0, m=b * nk, n=2 * hd, k=e2.shape[1])
             qp, kp, vp, ldq, ldk, ldv = _off(proj, 0), _off(kvproj, 0), _off(kvproj, hd), hd, 2 * hd, 2 * hd
         out = torch.empty((b * nq, hd), dtype=torch.float32, device=dev)
         lse = torch.empty((b, num_heads, nq), dtype=torch.float32, device=dev)
@@ -439,6 +495,7 @@ class _ProjAttentionFn(torch.autograd.Function):
                       _ks, _lib.ptr(_kw), _lib.stream_ptr(dev))
         ctx.save_for_backward(hidden, kv_src, w_all, wq, proj, kvproj, mask, out, lse)
         ctx.cfg = (num_heads, scale, p_drop, call_id, hd, nk, b, nq, seg, kseg)
+        ctx.big = (enc_planes, w_planes) if (kv_src is not None and enc_planes is not None) else None
         # key / value for the reference's "present_key_value" are views of the projections
         if kv_src is None:
             kview, vview = proj[:, hd:2 * hd], proj[:, 2 * hd:]
@@ -484,14 +541,37 @@ class _ProjAttentionFn(torch.autograd.Function):
             gw = dproj.t().mm(x2)          # (3*hd, c)
             gb = colsum(dproj)
             return (g_hidden, None, gw[:hd], gb[:hd], gw[hd:2 * hd], gb[hd:2 * hd], gw[2 * hd:], gb[2 * hd:],
-                    None, None, None, None, None)
+                    None, None, None, None, None, None)
         e2 = kv_src.reshape(b * nk, kv_src.shape[2])
         g_hidden = dproj.mm(wq).view(hidden.shape)
         gwq, gbq = dproj.t().mm(x2), colsum(dproj)
-        g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
-        gwkv, gbkv = dkv.t().mm(e2), colsum(dkv)
+        if ctx.big is None:
+            g_enc = dkv.mm(w_all).view(kv_src.shape) if ctx.needs_input_grad[1] else None
+            gwkv = dkv.t().mm(e2)
+        else:   # both gradients of the key / value projection on sig3d_gemmp; dkv is split once for the two
+            enc_planes, w_planes = ctx.big
+            c_enc = e2.shape[1]
+            pd, cd, sd_, bd = _gp(_planes(dkv))
+            g_enc = None
+            if ctx.needs_input_grad[1]:     # dX = dkv [Wk; Wv]: the weight's planes read with their rows as reduction index
+                g_enc = torch.empty((b * nk, c_enc), dtype=torch.float32, device=dev)
+                pb, cb, sb_, bb = _gp(w_planes)
+                _lib.gemmp(dev, A=pd, chunk_a=cd, stride_a=sd_, bytes_a=bd, B=pb, chunk_b=cb, stride_b=sb_, bytes_b=bb,
+                           C=g_enc, ldc=c_enc, modes=1, m=b * nk, n=c_enc, k=2 * hd)
+                g_enc = g_enc.view(kv_src.shape)
+            # dW = dkv^T enc: 12 x 11 tiles and a reduction over every token -> the reduction is split
+            gwkv = torch.empty((2 * hd, c_enc), dtype=torch.float32, device=dev)
+            tiles = -(-2 * hd // 128) * -(-c_enc // 128)
+            splits = max(1, min(16, 512 // tiles, (b * nk) // 128))
+            work = torch.empty(_lib.gemmp_work_floats(1, 2 * hd, c_enc, splits, 3), dtype=torch.float32, device=dev)
+            counters = torch.zeros(tiles, dtype=torch.int32, device=dev)
+            pe, ce, se_, be = _gp(enc_planes)
+            _lib.gemmp(dev, A=pd, chunk_a=cd, stride_a=sd_, bytes_a=bd, B=pe, chunk_b=ce, stride_b=se_, bytes_b=be,
+                       C=gwkv, ldc=c_enc, work=work, counters=counters, modes=2, m=2 * hd, n=c_enc, k=b * nk,
+                       splits=splits, config=3)
+        gbkv = colsum(dkv)
         return (g_hidden, g_enc, gwq, gbq, gwkv[:hd], gbkv[:hd], gwkv[hd:], gbkv[hd:], None, None, None,
-                None, None)
+                None, None, None)
 
 
 class _WeightGradArena:
@@ -596,6 +676,7 @@ class _WeightGradArena:
         # stack (the consumer is known to look here); whatever is left when the last block is done is an error.
         self.slabs_ok = OWN_GEMM
         self._slabs = {}
+        self._pl = {}                   # chunked bf16 planes of the operand buffers (OWN_DW), made in flush()
 
     def put_slabs(self, grad, slabs, slab_rows):
         self._slabs[grad.data_ptr()] = (slabs, slab_rows)
@@ -735,35 +816,85 @@ class _WeightGradArena:
             torch.cuda.current_stream().wait_stream(self.side_stream)
             self._forked = False
 
+    # ---- the products on sig3d_gemmp ----------------------------------------------------------------------
+    def _planes_of(self, name, lo, hi, live=None):
+        """Chunked bf16 planes of layers [lo, hi) of the operand buffer `name` ((layers, rows, cols) or (rows, cols)),
+        made now (sig3d_planes_split; the first `live` rows): (hi - lo, cols / 32, rows, 96) int16."""
+        t = getattr(self, name)
+        t3 = t if t.dim() == 3 else t.unsqueeze(0)
+        if name not in self._pl:
+            self._pl[name] = torch.empty((t3.shape[0], t3.shape[2] // 32, t3.shape[1], 96), dtype=torch.int16, device=t.device)
+        pl = self._pl[name][lo:hi]
+        _lib.planes_split(t3[lo:hi], pl, rows=live)
+        return pl
+
+    @staticmethod
+    def _dw(pa, pb, out, k, row0=0, col0=0, m=None):
+        """out (batch, M, N) = A^T B over the rows [row0, row0 + k) of the planes pa (batch, Ma / 32, rows, 96) --
+        columns [col0, col0 + m) of A -- and pb (batch, N / 32, rows, 96)."""
+        batch, _, rows_a, _ = pa.shape
+        rows_b = pb.shape[2]
+        m = pa.shape[1] * 32 - col0 if m is None else m
+        n = pb.shape[1] * 32
+        off_a = (col0 // 32) * rows_a * 96 + row0 * 96
+        off_b = row0 * 96
+        _lib.gemmp(out.device, A=pa.data_ptr() + 2 * off_a, chunk_a=rows_a * 96, stride_a=pa[0].numel(),
+                   bytes_a=(pa[0].numel() - off_a) * 2, B=pb.data_ptr() + 2 * off_b, chunk_b=rows_b * 96,
+                   stride_b=pb[0].numel(), bytes_b=(pb[0].numel() - off_b) * 2, C=out, ldc=out.stride(-2),
+                   stride_c=out.stride(0) if out.dim() == 3 else 0, modes=2, batch=batch, m=m, n=n, k=k)
+
+    def _dense_products_own(self, lo, hi, js):
+        P, L, rq, H = self.P, self.L, self.rq, self.H
+        pdy, pact = self._planes_of("dyo_ffn", lo, hi), self._planes_of("act", lo, hi)
+        pg, px = self._planes_of("gpre", lo, hi), self._planes_of("x_ffn", lo, hi)
+        for half in range(2):      # (query branch, text branch): rows [0, P) and [P, 2P) of every layer's matrices
+            self._dw(pdy, pact, self.gw2[lo:hi, half], P, row0=half * P)
+            self._dw(pg, px, self.gw1[lo:hi, half], P, row0=half * P)
+        self._dw(self._planes_of("dyo_attn", lo, hi), self._planes_of("att", lo, hi), self.gwo[lo:hi], L)
+        self._dw(self._planes_of("dproj", lo, hi), self._planes_of("x_attn", lo, hi, live=L), self.gwqkv[lo:hi], L)
+        if js:
+            j0, j1 = js[0], js[-1] + 1
+            self._dw(self._planes_of("dyo_x", j0, j1), self._planes_of("att_x", j0, j1), self.gwo_x[j0:j1], rq)
+            self._dw(self._planes_of("dq_x", j0, j1), self._planes_of("sa_out", j0, j1, live=rq), self.gwq_x[j0:j1], rq)
+            pkv, penc = self._planes_of("dkv", 0, 1), self._planes_of("enc2", 0, 1)
+            self._dw(pkv, penc, self.gwkv[j0 * 2 * H:j1 * 2 * H], self.enc2.shape[0], col0=j0 * 2 * H, m=(j1 - j0) * 2 * H)
+
     @torch.no_grad()
     def _products(self, lo, hi):
         n = hi - lo
         P, H, I, L, rq = self.P, self.H, self.I, self.L, self.rq
+        own = OWN_DW and H % 32 == 0 and I % 32 == 0 and (not self.cross or self.enc2.shape[1] % 32 == 0)
+        js = [j for j, l in enumerate(self.cross) if lo <= l < hi]
+        if own:
+            self._dense_products_own(lo, hi, js)
         # feed-forward pair: (query branch, text branch) x n layers
-        torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
-                  out=self.gw2[lo:hi].view(2 * n, H, I))
-        torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
-                  out=self.gw1[lo:hi].view(2 * n, I, H))
+        if not own:
+            torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
+                      out=self.gw2[lo:hi].view(2 * n, H, I))
+            torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
+                      out=self.gw1[lo:hi].view(2 * n, I, H))
         _colsum(self.gpre[lo:hi].view(2 * n * P, I), parts=2 * n, out=self.gb1[lo:hi])
         # self-attention
-        torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
-        torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
+        if not own:
+            torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
+            torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
         _colsum(self.dproj[lo:hi].view(n * L, 3 * H), parts=n, out=self.gbqkv[lo:hi])
         # LayerNorm tails: (layer, part) x blocks-per-part partial rows -> [d gamma | d beta | d bias]
         bf, ba = self.ln_blocks_ffn, self.ln_blocks_attn
         _colsum(self.ln_work_ffn[lo:hi].view(n * bf, 3 * H), parts=2 * n, out=self.ln_ffn[lo:hi].view(2 * n, 3 * H))
         _colsum(self.ln_work_attn[lo:hi].view(n * ba, 3 * H), parts=n, out=self.ln_attn[lo:hi].view(n, 3 * H))
         # cross-attention layers inside the range
-        js = [j for j, l in enumerate(self.cross) if lo <= l < hi]
         if js:
             j0, j1 = js[0], js[-1] + 1
             m = j1 - j0
-            torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
-            torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
+            if not own:
+                torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
+                torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
             _colsum(self.dq_x[j0:j1].view(m * rq, H), parts=m, out=self.gbq_x[j0:j1])
             _colsum(self.ln_work_x[j0:j1].view(m * ba, 3 * H), parts=m, out=self.ln_x[j0:j1].view(m, 3 * H))
             cols = slice(j0 * 2 * H, j1 * 2 * H)
-            torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
+            if not own:
+                torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
             if m == len(self.cross):
                 _colsum(self.dkv, out=self.gbkv)
             else:
@@ -1284,10 +1415,13 @@ class BertSelfAttention(nn.Module):
             nk = kv_src.shape[1]
             mask = _key_mask(attention_mask, hidden_states.shape[0], nk)
             p_drop = self.dropout.p if self.training else 0.0
+            enc_planes = None
+            if is_cross_attention and _big_source(encoder_hidden_states, 2 * self.all_head_size):
+                enc_planes = _EncoderPlanes.of(encoder_hidden_states)
             context_layer, key, value = _ProjAttentionFn.apply(
                 hidden_states, encoder_hidden_states if is_cross_attention else None,
                 self.query.weight, self.query.bias, self.key.weight, self.key.bias, self.value.weight,
-                self.value.bias, mask, self.num_attention_heads, float(p_drop), self._call_id)
+                self.value.bias, mask, self.num_attention_heads, float(p_drop), self._call_id, None, enc_planes)
             return (context_layer, (self.transpose_for_scores(key), self.transpose_for_scores(value)))
         key = linear(self.key, kv_src)
         value = linear(self.value, kv_src)

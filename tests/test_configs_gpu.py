@@ -271,17 +271,20 @@ def test_config5_blip2_shape_nk80000_forward_backward_matches_oracle():
     assert n >= 6 * 5
 
 
-@pytest.mark.parametrize("own_gemm", [False, True])
-def test_full_size_qformer_forward_backward_matches_oracle(own_gemm, monkeypatch):
+@pytest.mark.parametrize("own_gemm,own_dw", [(False, False), (True, False), (False, True)])
+def test_full_size_qformer_forward_backward_matches_oracle(own_gemm, own_dw, monkeypatch):
     """768 wide / 12 layers / 12 heads / 6 cross-attention layers, B = 8, 32 queries + 20 question tokens,
     256 scene tokens of width 256: the Q-Former the bench times, two-segment layout, against qformer_ref --
     last hidden state, per-parameter gradients of every layer, gradient of the scene tokens.
     own_gemm: the dense layers on sig3d_gemm16 (SIG3D_QF_GEMM=1: split reductions, slabs added by the LayerNorm
-    tails, slabs handed from block to block in the backward pass) instead of the vendor library -- same bounds."""
+    tails, slabs handed from block to block in the backward pass) instead of the vendor library -- same bounds.
+    own_dw: the layer-batched weight gradients on sig3d_gemmp (SIG3D_QF_DW=1: operands split into chunked bf16 planes,
+    six bf16 products per f32 product) instead of torch.bmm -- same bounds."""
     from oracle import qformer_ref
     from situation3d_amd import qformer as qformer_mod
     from situation3d_amd.qformer import init_Qformer
     monkeypatch.setattr(qformer_mod, "OWN_GEMM", own_gemm)
+    monkeypatch.setattr(qformer_mod, "OWN_DW", own_dw)
     torch.manual_seed(61)
     qf, query_tokens = init_Qformer(32, 256)
     qf.eval()

@@ -41,6 +41,10 @@ static const Shape shapes[] = {
     {"dW  wqkv   12x 2304x768 r416", 2, 12, 2304, 768, 416, 0, false, false, false, 0},
     {"dW  wkv     9216x256 r2048", 2, 1, 9216, 256, 2048, 0, false, false, false, 0},
     {"dW  tail   3x 768x768 r208 (B = 4: ragged reduction)", 2, 3, 768, 768, 208, 0, false, false, false, 0},
+    // config 5 (3D-LLM shape, d_enc 1408): key / value projection of one cross layer over 40 000 of the 320 000 point tokens
+    {"fwd cfg5 K/V  40000x1536x1408 +b", 0, 1, 40000, 1536, 1408, 0, true, false, false, 0},
+    {"dX  cfg5 g_enc 40000x1408x1536", 1, 1, 40000, 1408, 1536, 0, false, false, false, 0},
+    {"dW  cfg5 wkv  1536x1408 r40000", 2, 1, 1536, 1408, 40000, 0, false, false, false, 0},
 };
 
 #ifndef CONFIGS
@@ -242,7 +246,7 @@ int main(int argc, char **argv) {
       const int tiles = ((sh.M + tm - 1) / tm) * ((sh.N + tn - 1) / tn) * sh.batch;
       for (int splits = 1; splits <= 8; ++splits) {
       const int wgs = tiles * splits;
-      if (splits > 1 && (wgs > 600 || sh.K / 32 / splits < 3)) break;
+      if (splits > 1 && (wgs > 1100 || sh.K / 32 / splits < 3)) break;
       if (splits > 1 && wgs < 100) continue;
       if ((size_t)wgs * tm * tn * 4 > (256u << 20)) break;
       p.splits = splits;
