@@ -371,7 +371,7 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
             dt = time.perf_counter() - t0
             final_loss = float(loss.item())
             if graphed is not None and graphed.handshake_timed_out():
-                # a geometry chain gave up waiting for its ticket (30 s) and ran on coordinates that may not have been
+                # a geometry chain gave up waiting for its ticket (20 minutes: geometry.py) and ran on coordinates that may not have been
                 # staged: the numbers of this run would be those of a broken pipeline
                 raise RuntimeError("a geometry chain timed out waiting for its start ticket (sig3d_ticket_wait)")
             comm, bq_tests = None, None
@@ -648,6 +648,27 @@ def config5_variant(device, bsz=4, reps=5):
     return out
 
 
+def comm_model(world, bytes_per_step, single_gpu_ms=7.5):
+    """DESIGN.md section 6, stated so that a measured line falsifies or confirms it: the gradient exchange of one step
+    over xGMI (point-to-point links, 76.8 GB/s per direction each; every GPU has a direct link to each of its N - 1
+    peers), a ring / mesh all-reduce moving 2 (N - 1) / N x S bytes per rank over those links, on the wire from the end
+    of the Q-Former's backward pass (70 % of a single-GPU step) on and hidden under the encoder's backward pass and the
+    bucket-by-bucket update; + 0.3 ms of RCCL kernels sharing the CUs.  N = 8 also with RCCL's measured ~180 GB/s of
+    algorithm bandwidth on this class of node instead of the 7-link ideal."""
+    if world <= 1:
+        return {"wire_ms": 0.0, "predicted_ms_per_step": None, "note": "no wire at world size 1"}
+    link = 76.8e9
+    wire = 2.0 * (world - 1) / world * bytes_per_step / ((world - 1) * link) * 1e3
+    out = {"links_per_gpu": world - 1, "link_gbs_per_direction": 76.8, "wire_ms": round(wire, 3),
+           "assumed_single_gpu_ms": single_gpu_ms,
+           "predicted_ms_per_step": round(max(single_gpu_ms + 0.3, 0.7 * single_gpu_ms + wire + 0.1), 3)}
+    if world == 8:
+        wire_rccl = bytes_per_step / 180e9 * 1e3
+        out["wire_ms_at_rccl_180_gbs"] = round(wire_rccl, 3)
+        out["predicted_ms_per_step_at_rccl_180_gbs"] = round(max(single_gpu_ms + 0.3, 0.7 * single_gpu_ms + wire_rccl + 0.1), 3)
+    return out
+
+
 def refuse_probes():
     """Measurement switches (tools/probes/geo_probes.py) skip or replace work inside a captured step; the product reads
     none of them any more, but a bench line produced with one in the environment would invite the question."""
@@ -709,19 +730,19 @@ def main():
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
         traffic, traffic_commit, traffic_stale = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_group_pair.json")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r03_pmc_group_pair.json")
-        if os.path.exists(pmc):
-            j = json.load(open(pmc))
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_group_pair.json"))
+        if pmcs:
+            j = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))
             traffic, traffic_commit = round(j["traffic_bytes_per_step"]), j.get("commit")
-            # true when a kernel source changed after the commit the counters were read at (null: no git here)
-            try:
-                diff = subprocess.run(["git", "-C", ROOT, "diff", "--name-only", str(traffic_commit), "HEAD", "--",
-                                       "situation3d_amd/csrc"], capture_output=True, text=True, timeout=20)
-                traffic_stale = bool(diff.stdout.strip()) if diff.returncode == 0 else None
-            except Exception:
-                traffic_stale = None
+            # stale = a source that decides the pair's launches or their traffic (kernels, the SA modules' Python, the
+            # geometry plan) differs from the tree the counters were read in; by content hash (no git on the GPU box),
+            # null for files of rounds that stored no hashes
+            if j.get("source_hashes"):
+                import hashlib
+                traffic_stale = any(
+                    not os.path.exists(os.path.join(ROOT, f)) or
+                    hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] != h
+                    for f, h in j["source_hashes"].items())
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),
@@ -800,7 +821,8 @@ def main():
         }
         if head["comm"] is not None:
             # data-parallel form (N > 1, or --force-reducer): what the gradient exchange costs the step (ddp.CommStats)
-            out["comm"] = head["comm"]
+            out["comm"] = dict(head["comm"])
+            out["comm"]["model"] = comm_model(world, head["comm"]["bytes_per_step"])
     # ---- beside the headline (N = 1): the same step with every level dense, and on surface-shaped scenes
     if world == 1 and not args.no_variants:
         vsteps, vwarm = min(args.steps, 10), min(args.warmup, 3)

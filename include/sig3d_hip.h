@@ -41,6 +41,9 @@ const char *sig3d_last_error(void);       /* thread-local message of the last fa
 int sig3d_ticket_signal(unsigned int *ticket, void *stream);
 int sig3d_ticket_wait(const unsigned int *ticket, unsigned int *consumed, long long timeout_us, int *error,
                       void *stream);
+/* one wave that sleeps for hold_us on `stream`: two streams served by ONE hardware queue run two of these in a row,
+ * streams on different queues side by side (situation3d_amd/streams.py: run_concurrently, stream_beside). */
+int sig3d_queue_hold(int hold_us, void *stream);
 
 /* ---- PointNet++ ops: lib/pointnet2/_ext_src ------------------------------------------ */
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "sig3d_stream_create_with_cu_mask": [_I, _P, _P],
     "sig3d_stream_destroy": [_P],
     "sig3d_whereami": [_P, _I, _I, _I, _P],
+    "sig3d_queue_hold": [_I, _P],
     "sig3d_qformer_embed_fwd": [_I, _I, _I, _I, _I, _P, ctypes.c_long, _P, _P, _I, _P, _I, _I, _P, _P, _F, _F,
                                 ctypes.c_uint, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_qformer_embed_bwd": [_I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P,

@@ -118,6 +118,23 @@ extern "C" int sig3d_stream_destroy(void *stream) {
 }
 
 namespace {
+__global__ void queue_hold_kernel(unsigned long long hold_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < hold_ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+// One wave that sleeps for hold_us on `stream`.  Two of them on two streams take hold_us in total when the streams are
+// served by different hardware queues and 2 x hold_us when HIP put them on one (streams.run_concurrently: the geometry
+// pipeline draws streams until its chains run BESIDE the step).
+extern "C" int sig3d_queue_hold(int hold_us, void *stream_) {
+  SIG3D_REQUIRE(hold_us >= 0 && hold_us <= 100000, "hold_us out of range");
+  hipLaunchKernelGGL(queue_hold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (unsigned long long)hold_us * 100ull);
+  SIG3D_LAUNCH_CHECK("queue_hold_kernel");
+  return 0;
+}
+
+namespace {
 __global__ void whereami_kernel(unsigned int *slots, unsigned long long hold_ticks) {
   unsigned int hw, xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
