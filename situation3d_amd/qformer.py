@@ -26,6 +26,7 @@ torch's Philox (same distribution, different bits); eval mode is deterministic.
 import ctypes
 import math
 import os
+import weakref
 from types import SimpleNamespace
 
 import torch
