@@ -50,7 +50,10 @@ def parse_args(argv=None):
     ap.add_argument("--surface", action="store_true",
                     help="time the step on surface-shaped scenes (the 'synthetic-surface data' variant) INSTEAD of the "
                          "SURVEY 8d headline distribution -- for profiles; the line says so in `data`")
-    ap.add_argument("--geo-depth", type=int, default=int(os.environ.get("SIG3D_GEO_DEPTH", "1")),
+    # round 5: THREE chains in flight.  Since the main chain lost another ~0.5 ms in round 4 the step waited for its
+    # geometry in every step (tools/probes/chain_slack.py: +0.05 ... +0.18 ms); with the chain two more steps ahead it
+    # does not: -0.065 ms at depth 2, -0.094 at depth 3, +0.01 from 2 to 4 (tools/ab_step.py env:SIG3D_GEO_DEPTH)
+    ap.add_argument("--geo-depth", type=int, default=int(os.environ.get("SIG3D_GEO_DEPTH", "3")),
                     help="geometry chains in flight beside the step (geometry.GeometryPipeline; 1 = round 2's one-ahead)")
     return ap.parse_args(argv)
 

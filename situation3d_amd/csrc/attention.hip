@@ -950,6 +950,223 @@ __global__ __launch_bounds__(AT_WAVES * 64, 1) void attention_bwd_kernel(
   AT_MARK(1, 11);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// backward, SMALL problems (round 5): the 52 x 52 self-attention (32 queries + 20 question tokens) and the 32 x 256
+// cross-attention of the SQA3D shape, 18 launches per step.  The generic kernel above runs them as one wave per SIMD
+// on 96 / 192 workgroups whose waves re-read Q, dO and K from memory in the transposed operand layout (~224 load
+// instructions per wave: 21-25 us per launch, 3-6 % of the matrix pipe: profiles/r03_pmc_attention_mfma.md).  Here a
+// workgroup of EIGHT waves owns one (batch, head) -- and, for many keys, one chunk of 32 NKB keys -- and everything
+// it needs sits in LDS once: Q, dO (32 NQB rows), K, V (32 NKB rows), read from memory in 256-byte rows.
+//   phase 1: the 2 NQB NKB blocks of S = Q K^T and dP = dO V^T, one per wave (NQB NKB = 4);
+//   phase 2: P = exp(S scale + mask - lse), dropout bits regenerated, dS = P (dP' - D), element by element in LDS;
+//   phase 3: dV = P'^T dO, dK = dS^T Q, dQ = dS K as 32 x 32 blocks dealt over the waves (dQ of the many-key shape in
+//            four key slices per block, summed through LDS), stored from the accumulators as 128-byte runs.
+// Operand reads are conflict-free by construction: a block's A / B operand is either 32 consecutive floats of one LDS
+// row, or one 8-byte pair per row with row strides of 66 / 32 NKB + 2 floats (2 banks per row, 64 banks).
+template <int NQB, int NKB>
+__global__ __launch_bounds__(512, 1) void attention_bwd_small_kernel(
+    int h, int nq, int nk, int q_seg, int k_seg, int q_base2, int k_base2, int q_rows, int k_rows, int ldq, int ldk,
+    int ldv, float scale, int atomic_dq, float p_drop, unsigned call_id, const unsigned *__restrict__ rng_counter,
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ mask, const float *__restrict__ out, const float *__restrict__ lse,
+    const float *__restrict__ grad_out, float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv) {
+  static_assert(NQB * NKB == 4, "eight waves: one S block and one dP block each");
+  constexpr int D = 64, RQ = 32 * NQB, RK = 32 * NKB, LD = 66, LP = RK + 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *sQ = sm, *sdO = sQ + RQ * LD, *sK = sdO + RQ * LD, *sV = sK + RK * LD;
+  float *sP = sV + RK * LD, *sdP = sP + RQ * LP, *sD = sdP + RQ * LP, *sL = sD + RQ, *sM = sL + RQ;
+  float *sRed = sM + RK;   // NQB == 1: [8 waves][16][64] partial dQ blocks
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = blockIdx.x, kc = blockIdx.y, bi = blockIdx.z;
+  const int key0 = kc * RK, nkl = min(RK, nk - key0);
+  if (kc == 0 && bi == 0) {
+    zero_pad_rows<D>(dq, (unsigned)ldq, hi, gridDim.z, nq, q_seg, q_base2, q_rows);
+    zero_pad_rows<D>(dk, (unsigned)ldk, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+    zero_pad_rows<D>(dv, (unsigned)ldv, hi, gridDim.z, nk, k_seg, k_base2, k_rows);
+  }
+  const size_t bh = (size_t)(bi * h + hi);
+  const unsigned ostride = (unsigned)h * D;
+  const float *Q = q + hi * D, *K = k + hi * D, *V = v + hi * D, *O = out + hi * D, *dO = grad_out + hi * D;
+  auto qrow = [&](int i) { return tok_row(i, bi, nq, q_seg, q_base2); };
+  auto krow_of = [&](int j) { return tok_row(j, bi, nk, k_seg, k_base2); };
+
+  // ---- phase 0: everything into LDS.  Sixteen lanes per 256-byte row; every request is issued before the first store
+  // (rows beyond the problem are clamped and zeroed at store time); D = rowsum(dO O) falls out of the same loads.
+  {
+    constexpr int QI = RQ * 16 / 512, KI = RK * 16 / 512;
+    float4 aq[QI], ag[QI], ao[QI], ak[KI], av[KI];
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, c4 = (i & 15) * 4;
+      const unsigned rr = qrow(min(row, nq - 1));
+      aq[j] = *reinterpret_cast<const float4 *>(Q + rr * (unsigned)ldq + c4);
+      ag[j] = *reinterpret_cast<const float4 *>(dO + rr * ostride + c4);
+      ao[j] = *reinterpret_cast<const float4 *>(O + rr * ostride + c4);
+    }
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, c4 = (i & 15) * 4;
+      const unsigned rr = krow_of(min(key0 + row, nk - 1));
+      ak[j] = *reinterpret_cast<const float4 *>(K + rr * (unsigned)ldk + c4);
+      av[j] = *reinterpret_cast<const float4 *>(V + rr * (unsigned)ldv + c4);
+    }
+    if (tid < RQ) sL[tid] = tid < nq ? lse[bh * nq + tid] : 0.f;
+    if (tid < RK) sM[tid] = (mask && tid < nkl) ? mask[(size_t)bi * nk + key0 + tid] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < QI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, c4 = (i & 15) * 4;
+      const bool ok = row < nq;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 x = ok ? aq[j] : z, g = ok ? ag[j] : z, o = ok ? ao[j] : z;
+      *reinterpret_cast<float2 *>(sQ + row * LD + c4) = make_float2(x.x, x.y);
+      *reinterpret_cast<float2 *>(sQ + row * LD + c4 + 2) = make_float2(x.z, x.w);
+      *reinterpret_cast<float2 *>(sdO + row * LD + c4) = make_float2(g.x, g.y);
+      *reinterpret_cast<float2 *>(sdO + row * LD + c4 + 2) = make_float2(g.z, g.w);
+      const float part = row_allreduce_sum_f32(g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w);   // 16 lanes = one row
+      if ((i & 15) == 0) sD[row] = part;
+    }
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+      const int i = tid + 512 * j, row = i >> 4, c4 = (i & 15) * 4;
+      const bool ok = row < nkl;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 x = ok ? ak[j] : z, y = ok ? av[j] : z;
+      *reinterpret_cast<float2 *>(sK + row * LD + c4) = make_float2(x.x, x.y);
+      *reinterpret_cast<float2 *>(sK + row * LD + c4 + 2) = make_float2(x.z, x.w);
+      *reinterpret_cast<float2 *>(sV + row * LD + c4) = make_float2(y.x, y.y);
+      *reinterpret_cast<float2 *>(sV + row * LD + c4 + 2) = make_float2(y.z, y.w);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: wave w < 4: S block (qb, kb) -> P; wave w >= 4: dP block.  Reduction index of step (j, e):
+  // d = 4 j + 2 half + e -- the same map for both operands, read as 8-byte pairs.
+  {
+    const int blk = wave & 3, qb = blk / NKB, kb = blk % NKB;
+    const bool is_s = wave < 4;
+    const float *A = (is_s ? sQ : sdO) + (32 * qb + l31) * LD + 2 * half;
+    const float *B = (is_s ? sK : sV) + (32 * kb + l31) * LD + 2 * half;
+    f32x16 acc = {0};
+#pragma unroll
+    for (int j = 0; j < D / 4; ++j) {
+      const float2 a2 = *reinterpret_cast<const float2 *>(A + 4 * j), b2 = *reinterpret_cast<const float2 *>(B + 4 * j);
+      acc = mfma32(a2.x, b2.x, acc);
+      acc = mfma32(a2.y, b2.y, acc);
+    }
+    const int key = 32 * kb + l31;
+    const bool key_ok = key < nkl;
+    const float mk = sM[key];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = 32 * qb + mfma_row(r, half);
+      float val = acc[r];
+      if (is_s) {
+        const float row_lse = sL[qq];   // fully fill-masked rows attend uniformly (see the generic kernel)
+        const float e = row_lse < -1e8f ? 1.f / (float)nk : __expf(val * scale + mk - row_lse);
+        val = (key_ok && qq < nq) ? e : 0.f;
+      }
+      (is_s ? sP : sdP)[qq * LP + key] = val;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: P' = P keep / (1 - p) (for dV), dS = P (dP keep / (1 - p) - D), in place
+  {
+    const AttnDropout drop = make_dropout(p_drop, call_id, rng_counter);
+#pragma unroll
+    for (int j = 0; j < RQ * RK / 512; ++j) {
+      const int e = tid + 512 * j, qq = e / RK, key = e - qq * RK;
+      const float p = sP[qq * LP + key];
+      float dp = sdP[qq * LP + key], pd = p;
+      if (drop.on) {
+        const unsigned row_base = ((unsigned)((bi * h + hi) * nq + qq)) * (unsigned)((nk + 1) >> 1);
+        const bool keep = at_keep(drop, row_base, key0 + key);
+        dp = keep ? dp * drop.inv_keep : 0.f;
+        pd = keep ? p * drop.inv_keep : 0.f;
+      }
+      float ds = p * (dp - sD[qq]);
+      if (sL[qq] < -1e8f) ds = 0.f;
+      sP[qq * LP + key] = pd;
+      sdP[qq * LP + key] = ds;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3.  dV / dK block (kb, db): rows = keys, A = P' / dS column slice (32 consecutive keys of one query row),
+  // B = dO / Q row slice; dQ block (qb, db): rows = queries, A = dS read as 8-byte pairs along the keys, B = K rows.
+  auto keys_block = [&](const float *A_, const float *B_, int kb, int db, float f, float *dst, int ld_) {
+    f32x16 acc = {0};
+    const float *a = A_ + 32 * kb + l31, *b = B_ + 32 * db + l31;
+#pragma unroll
+    for (int s = 0; s < RQ / 2; ++s) acc = mfma32(a[(2 * s + half) * LP], b[(2 * s + half) * LD], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 32 * kb + mfma_row(r, half);
+      if (key < nkl) dst[krow_of(key0 + key) * (unsigned)ld_ + hi * D + 32 * db + l31] = acc[r] * f;
+    }
+  };
+  auto dq_slice = [&](int qb, int db, int k_lo, int k_n) {
+    f32x16 acc = {0};
+    const float *a = sdP + (32 * qb + l31) * LP + k_lo + 2 * half, *b = sK + (k_lo + 2 * half) * LD + 32 * db + l31;
+    for (int j = 0; j < k_n / 4; ++j) {
+      const float2 a2 = *reinterpret_cast<const float2 *>(a + 4 * j);
+      acc = mfma32(a2.x, b[(4 * j) * LD], acc);
+      acc = mfma32(a2.y, b[(4 * j + 1) * LD], acc);
+    }
+    return acc;
+  };
+  auto dq_store = [&](const f32x16 &acc, int qb, int db) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = 32 * qb + mfma_row(r, half);
+      if (qq < nq) {
+        float *dst = dq + qrow(qq) * (unsigned)ldq + hi * D + 32 * db + l31;
+        if (atomic_dq) unsafeAtomicAdd(dst, acc[r] * scale);
+        else *dst = acc[r] * scale;
+      }
+    }
+  };
+  if constexpr (NQB == 2) {        // 12 blocks over 8 waves: dV 0-3, dK 4-7, dQ 8-11
+    for (int it = wave; it < 12; it += 8) {
+      const int kind = it >> 2, b2 = it & 3;
+      if (kind == 0) keys_block(sP, sdO, b2 >> 1, b2 & 1, 1.f, dv, ldv);
+      else if (kind == 1) keys_block(sdP, sQ, b2 >> 1, b2 & 1, scale, dk, ldk);
+      else dq_store(dq_slice(b2 >> 1, b2 & 1, 0, RK), b2 >> 1, b2 & 1);
+    }
+  } else {                         // one query block, four key blocks: dV and dK block w each, a quarter of a dQ block
+    keys_block(sP, sdO, wave >> 1, wave & 1, 1.f, dv, ldv);
+    keys_block(sdP, sQ, wave >> 1, wave & 1, scale, dk, ldk);
+    const f32x16 part = dq_slice(0, wave & 1, 32 * (wave >> 1), 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[(wave * 16 + r) * 64 + lane] = part[r];
+    __syncthreads();
+    if (wave < 2) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[r] = (sRed[((wave + 0) * 16 + r) * 64 + lane] + sRed[((wave + 2) * 16 + r) * 64 + lane]) +
+                 (sRed[((wave + 4) * 16 + r) * 64 + lane] + sRed[((wave + 6) * 16 + r) * 64 + lane]);
+      dq_store(acc, 0, wave);
+    }
+  }
+}
+
+template <int NQB, int NKB>
+constexpr size_t attention_bwd_small_lds() {
+  constexpr int RQ = 32 * NQB, RK = 32 * NKB;
+  return sizeof(float) * (2 * RQ * 66 + 2 * RK * 66 + 2 * RQ * (RK + 2) + 2 * RQ + RK + (NQB == 1 ? 8 * 16 * 64 : 0));
+}
+
+// read per call (host side, once per launch or capture): tools/ab_step.py env:SIG3D_ATTN_BWD_SMALL 0 1 builds both steps
+inline bool attn_bwd_small_enabled() {
+  const char *e = getenv("SIG3D_ATTN_BWD_SMALL");
+  return e == nullptr || atoi(e) != 0;
+}
+
 }  // namespace
 
 #ifdef SIG3D_ATTN_TIMING
@@ -1040,6 +1257,37 @@ static int attention_bwd_impl(int b, int h, int nq, int nk, int d, int q_seg, in
   SIG3D_REQUIRE((long)(b * nq + q_base2 + q_rows) * ldq < (1L << 31) && (long)(b * nk + k_base2 + k_rows) * ldk < (1L << 31) &&
                     (long)(b * nk + k_base2 + k_rows) * ldv < (1L << 31),
                 "operand extents must stay below 2^31 floats (32-bit addressing inside the kernel)");
+  SIG3D_REQUIRE(ldq >= h * d && ldk >= h * d && ldv >= h * d && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0,
+                "row strides must be >= h*d and multiples of 4 floats");
+  // small problems: one eight-wave workgroup per (batch, head[, chunk of 128 keys]) with everything in LDS
+  if (attn_bwd_small_enabled() && d == 64 && ((nq <= 64 && nk <= 64) || (nq <= 32 && nk <= 1024))) {
+    const bool self_like = nq > 32 || nk <= 64;
+    const int chunks = self_like ? 1 : (nk + 127) / 128;
+    if (chunks > 1 && !dq_zeroed) {  // dq is accumulated with atomics across key chunks
+      const int q_extent = (q_seg > 0 && q_seg < nq) ? q_base2 + b * (nq - q_seg) : b * nq;
+      SIG3D_HIP_TRY(hipMemset2DAsync(dq, sizeof(float) * ldq, 0, sizeof(float) * h * d,
+                                     (size_t)(q_rows > q_extent ? q_rows : q_extent), stream));
+    }
+    constexpr size_t lds22 = attention_bwd_small_lds<2, 2>(), lds14 = attention_bwd_small_lds<1, 4>();
+    static bool small_attr = false;
+    if (!small_attr) {
+      SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_small_kernel<2, 2>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds22));
+      SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_small_kernel<1, 4>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds14));
+      small_attr = true;
+    }
+    if (self_like)
+      hipLaunchKernelGGL((attention_bwd_small_kernel<2, 2>), dim3(h, 1, b), dim3(512), lds22, stream,
+                         h, nq, nk, q_seg, k_seg, q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale, 0, p_drop, call_id,
+                         rng_counter, q, k, v, mask, out, lse, grad_out, dq, dk, dv);
+    else
+      hipLaunchKernelGGL((attention_bwd_small_kernel<1, 4>), dim3(h, chunks, b), dim3(512), lds14,
+                         stream, h, nq, nk, q_seg, k_seg, q_base2, k_base2, q_rows, k_rows, ldq, ldk, ldv, scale,
+                         chunks > 1 ? 1 : 0, p_drop, call_id, rng_counter, q, k, v, mask, out, lse, grad_out, dq, dk, dv);
+    SIG3D_LAUNCH_CHECK("attention_bwd_small_kernel");
+    return 0;
+  }
   const int ntiles = (nk + 31) / 32;
   // enough workgroups to cover the chip, but at least AT_WAVES tiles per workgroup
   int splits = 1;
