@@ -30,6 +30,9 @@
 #include <type_traits>
 #include "gemm16_core.h"
 
+#ifndef GEMMP_VARIANT
+#define GEMMP_VARIANT 0   // measurement builds: 1 no scheduling barriers between the MFMA slots, 2 MFMA waves at raised priority
+#endif
 #ifndef GEMMP_KO
 #define GEMMP_KO 0   // measurement builds: 1 no global loads, 2 no LDS stores, 4 no LDS reads, 8 no barrier, 16 no MFMAs (wrong results)
 #endif
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
 #define GEMMP_STAMP() do { } while (0)
 #endif
   GEMMP_STAMP();
+  if (GEMMP_VARIANT & 2) { if (wv & 1) __builtin_amdgcn_s_setprio(1); }
   // ---- prologue: PF chunks requested, chunks 0 and 1 staged, K-step 0 of chunk 0 in registers
   static_for<0, PF>([&](auto d_) {
     constexpr int d = decltype(d_)::value;
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
           else if constexpr (k < NF + NS0) store_unit(st2, c + 2, std::integral_constant<int, k - NF>(), ring[d2]);
           else load_unit(c + PF, std::integral_constant<int, k - NF - NS0>(), ring[d]);
         });
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(GEMMP_VARIANT & 1)) __builtin_amdgcn_sched_barrier(0);
       });
       static_for<0, H>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemmp_kernel(const Proble
           if constexpr (k < NS1) store_unit(st2, c + 2, std::integral_constant<int, NS0 + k>(), ring[d2]);
           else read_frag(st1, I0(), std::integral_constant<int, k - NS1>());
         });
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(GEMMP_VARIANT & 1)) __builtin_amdgcn_sched_barrier(0);
       });
       if (!(GEMMP_KO & 8)) __syncthreads();
       GEMMP_STAMP();

@@ -114,6 +114,8 @@ class GraphedTrainStep:
         self.graph_opt = torch.cuda.CUDAGraph() if reducer is not None else None
         if reducer is not None:
             reducer.hooks_enabled = False
+            if getattr(optimizer, "process_group", None) is None:
+                optimizer.process_group = reducer.group   # liveness agreed on the reducer's group from the first gather on
         self.prefetch = bool(prefetch_geometry)
         # Where the geometry chains run.  Default: geometry.GeometryPipeline -- the chains of the next
         # `prefetch_depth` batches (default 1; bench.py runs 2) as graphs of their own on streams of their own, beside

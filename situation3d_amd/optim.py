@@ -33,7 +33,8 @@ import torch
 from . import _lib
 
 _CHUNK = 65536
-_CAPTURE_SLOT = 7        # staging buffers: 0 eager, 1-6 the call sites of a captured step in parts, 7 a captured whole step
+_CAPTURE_SLOT = 7        # staging buffers: 0 eager, 1-6 the call sites of a captured step in parts, 7 ... a captured whole step
+_MAX_CAPTURES = 8        # ... one per capture (graphs that are alive together must not share a pinned table)
 _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
                  ("pad", "f4")])
 
@@ -113,7 +114,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._host_np = self._host.numpy().view(_REC)
         self._table = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev)
         self._slots = [(self._host, self._host_np, self._table)]
-        self._tables(_CAPTURE_SLOT)      # pinned memory cannot be allocated during a capture
+        self._tables(_CAPTURE_SLOT + _MAX_CAPTURES - 1)      # pinned memory cannot be allocated during a capture
         self._gathered = False
 
     # ---- chunk table ------------------------------------------------------------------------
@@ -147,7 +148,15 @@ class FlatAdamW(torch.optim.Optimizer):
             # a captured upload is a memcpy node that re-reads its pinned staging buffer at every replay: it gets a
             # buffer of its own, which an eager step() between two replays (the short last batch of an epoch) does not
             # rewrite -- with the shared one the next replay walked a table of freed gradient tensors
-            slot = _CAPTURE_SLOT
+            # ... and every CAPTURE gets its own: two live graphs over one optimizer (a step rebuilt after a BatchNorm
+            # momentum change while the old one is still replayed; tools/ab_step.py's A and B) would otherwise share one
+            # pinned table, and a replay of the first would walk the second's gradient pointers
+            n_cap = self.__dict__.setdefault("_captures", [0])
+            if n_cap[0] >= _MAX_CAPTURES:
+                raise RuntimeError("FlatAdamW: more than %d captured steps over one optimizer (each holds a pinned gradient "
+                                   "table of its own); build a new optimizer object" % _MAX_CAPTURES)
+            slot = _CAPTURE_SLOT + n_cap[0]
+            n_cap[0] += 1
         host, t, table = self._tables(slot)
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]

@@ -149,6 +149,8 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     if fused:
         pass  # gradients were zeroed by the previous step() (and start at zero)
     elif reducer is not None:
+        if getattr(optimizer, "process_group", None) is None:
+            optimizer.process_group = reducer.group   # FlatAdamW agrees on live parameters among the ranks that average them
         reducer.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=False)

@@ -18,24 +18,27 @@ batches = [bench.synthetic_batch(bench.BATCH, bench.N_POINTS, 1234 + i, dev) for
 work = torch.cuda.Stream(dev)
 recs = []
 with torch.cuda.stream(work):
-    g = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True)
+    depth = int(os.environ.get("SIG3D_GEO_DEPTH", "1"))
+    g = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True, prefetch_depth=depth)
     pipe = g._pipe
-    slot = pipe.slots[0]
     orig = pipe.advance
-    state = {"done": None}
+    state = {"done": [], "n": 0}
 
     def advance(pc, upcoming, token=None, upcoming_tokens=None):
         ready = torch.cuda.Event(enable_timing=True); ready.record(work)
-        prev_done = state["done"]
+        # the chain consumed NOW was launched `depth` calls ago (round-robin over the slots)
+        prev_done = state["done"][-depth] if len(state["done"]) >= depth else None
         orig(pc, upcoming, token, upcoming_tokens)
+        slot = pipe.slots[(pipe.calls - 1) % pipe.depth]
         done = torch.cuda.Event(enable_timing=True); done.record(slot["stream"])     # end of the chain launched NOW
         start = torch.cuda.Event(enable_timing=True); start.record(work)
         if prev_done is not None:
             recs.append((ready, prev_done, start))
-        state["done"] = done
+        state["done"].append(done)
     pipe.advance = advance
     for i in range(120):
-        g(batches[i % 4], batches[(i + 1) % 4])
+        up = [batches[(i + 1 + k) % 4] for k in range(depth)]
+        g(batches[i % 4], upcoming=up)
     torch.cuda.synchronize()
 wait = [r.elapsed_time(d) for r, d, s in recs[20:]]          # ready -> chain done (ms); > 0: the step waited
 print("steps %d: chain done minus step ready: mean %+.3f ms, min %+.3f, max %+.3f; steps that waited: %d (%.0f %%), mean wait %.3f ms"
