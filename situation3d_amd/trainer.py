@@ -146,11 +146,11 @@ def train_step(model, optimizer, data_dict, max_grad_value=1.0, reducer=None):
     """One Solver iteration (solver.py:374-402, 618-627).  With a GradBucketReducer the gradient
     all-reduce is launched bucket by bucket from inside backward and joined before clipping."""
     fused = getattr(optimizer, "flat_grad_buffers", None) is not None  # optim.FlatAdamW
+    if fused and reducer is not None and getattr(optimizer, "process_group", None) is None:
+        optimizer.process_group = reducer.group   # FlatAdamW agrees on live parameters among the ranks that average them
     if fused:
         pass  # gradients were zeroed by the previous step() (and start at zero)
     elif reducer is not None:
-        if getattr(optimizer, "process_group", None) is None:
-            optimizer.process_group = reducer.group   # FlatAdamW agrees on live parameters among the ranks that average them
         reducer.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=False)
