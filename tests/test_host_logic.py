@@ -199,12 +199,14 @@ def test_qformer_state_dict_keys_match_reference():
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
-    """The ctypes mirrors of the C-ABI structs (sig3d_bq_level, sig3d_gemm_problem) must agree with what a C compiler
-    makes of include/sig3d_hip.h: size and every field offset, checked by compiling a probe with gcc."""
+    """The ctypes mirrors of the C-ABI structs (sig3d_bq_level, sig3d_gemm_problem, sig3d_gemm16_problem,
+    sig3d_gemmp_problem) must agree with what a C compiler makes of include/sig3d_hip.h: size and every field offset,
+    checked by compiling a probe with gcc."""
     import ctypes
     import subprocess
     from situation3d_amd import _lib
-    structs = {"sig3d_bq_level": _lib.BqLevel, "sig3d_gemm_problem": _lib.GemmProblem}
+    structs = {"sig3d_bq_level": _lib.BqLevel, "sig3d_gemm_problem": _lib.GemmProblem,
+               "sig3d_gemm16_problem": _lib.Gemm16Problem, "sig3d_gemmp_problem": _lib.GemmpProblem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sig3d_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -243,6 +245,30 @@ def test_point_major_twins_and_scan_attachment_are_validated():
     feats = fused_mlp.attach_scan(pc[..., 3:].transpose(1, 2), pc)
     assert feats._points_pm is pc and not feats.is_contiguous()
     assert fused_mlp.first_layer_scan(None, pc[..., :3], feats, True) is None      # CPU: never the HIP path
+
+
+def test_gemmp_work_space_and_argument_checks_are_host_arithmetic():
+    """sig3d_gemmp_work_floats sizes the partial tiles of a split reduction from the tiling the launcher will choose
+    (no GPU call); sig3d_gemmp refuses inconsistent problems before it touches a device pointer."""
+    from situation3d_amd import _lib
+    assert _lib.gemmp_work_floats(1, 416, 2304, 1) == 0
+    assert _lib.gemmp_work_floats(1, 416, 2304, 2, 2) == 2 * 7 * 18 * 64 * 128          # 64 x 128 tiles
+    assert _lib.gemmp_work_floats(1, 1536, 1408, 4, 3) == 4 * 12 * 11 * 128 * 128       # 128 x 128 tiles
+    lib = _lib.load()
+    q = _lib.GemmpProblem()
+    q.A, q.B, q.C = 4096, 8192, 16384            # never dereferenced: the checks come first
+    q.chunk_a = q.chunk_b = 64 * 96
+    q.stride_a = q.stride_b = 64 * 96 * 4
+    q.bytes_a = q.bytes_b = 64 * 96 * 4 * 2
+    q.ldc, q.batch, q.m, q.n, q.k, q.splits = 64, 1, 64, 64, 100, 1
+    import ctypes
+    assert lib.sig3d_gemmp(ctypes.byref(q), None) != 0 and b"multiple of 32" in lib.sig3d_last_error()
+    q.k, q.modes = 128, 3
+    assert lib.sig3d_gemmp(ctypes.byref(q), None) != 0 and b"modes" in lib.sig3d_last_error()
+    q.modes, q.splits = 0, 2
+    assert lib.sig3d_gemmp(ctypes.byref(q), None) != 0 and b"work space" in lib.sig3d_last_error()
+    q.splits, q.bytes_a = 1, 1 << 33
+    assert lib.sig3d_gemmp(ctypes.byref(q), None) != 0 and b"4 GB" in lib.sig3d_last_error()
 
 
 def test_ball_query_levels_workspace_is_host_arithmetic():
