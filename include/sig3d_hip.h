@@ -674,6 +674,12 @@ int sig3d_attention_bwd_z(int b, int h, int nq, int nk, int d, int q_seg, int k_
  * memset, filled with float atomics).  The residual's gradient is dy itself. */
 int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const float *x, const float *w1, const float *b1,
                       const float *w2, const float *b2, const float *residual, float *pre, float *out, void *stream);
+/* _posed: the situational re-encode of the token positions (situation3d/utils/temp.py:86-97; sig3d_situational_transform)
+ * folded into the launch: x (b*tokens, 3) = R(q_b)^T (points - t_b) [inverse != 0] or R(q_b) points + t_b, formed from
+ * pose (b,7) and points (b*tokens,3) with the transform's own arithmetic, written to x_out and fed to the MLP. */
+int sig3d_pos_mlp_fwd_posed(int b, int tokens, int hid, int cout, int inverse, const float *pose, const float *points,
+                            float *x_out, const float *w1, const float *b1, const float *w2, const float *b2,
+                            const float *residual, float *pre, float *out, void *stream);
 int sig3d_pos_mlp_bwd(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
                       const float *dy, float *dpre, float *grads, void *stream);
 /* _z: grads arrives ZEROED and is accumulated into (no memset here). */

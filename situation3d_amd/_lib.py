@@ -64,6 +64,7 @@ SIGNATURES = {
     "sig3d_sa_first_layer_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_sa_first_layer_dw": [_I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sig3d_pos_mlp_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_pos_mlp_fwd_posed": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_pos_mlp_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_pooled_heads_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, ctypes.c_uint, _P, _P, _P, _P, _P,
                                _P, _P],

@@ -7,6 +7,7 @@
 //     channel), and two backward launches (input-side: dH = dY W2, dPre, dW1, db1; weight-side: dW2 = dY^T H, db2
 //     with H recomputed from the stored pre-activation).
 #include "sig3d_common.h"
+#include "situational_pose.h"
 
 namespace {
 
@@ -50,7 +51,13 @@ __device__ __forceinline__ void sg_steps(SgAcc &a, const float (*As)[SG_LD], con
 
 // forward: out[m][n] = residual + b2[n] + sum_k gelu(pre[m][k]) w2[n][k],  pre[m][k] = b1[k] + sum_c w1[k][c] x[m][c]
 // grid (row tiles, column tiles); column tile 0 also writes pre (kept for the backward pass).  hid <= 128: one staging.
-__global__ __launch_bounds__(256) void pos_mlp_fwd_kernel(int rows, int cin, int hid, int cout,
+// pose != null (cin == 3): x is not read but FORMED here -- the situational re-encode of the token positions,
+// x[m] = R(q_b)^T (points[m] - t_b), b = m / tokens (situational_pose.h: the arithmetic of sig3d_situational_transform,
+// bit for bit) -- and written to x_out by the first column tile: the transform rides in this launch (temp.py:86-97 +
+// sqa_module.py:274-278, 319-321 as one kernel).
+__global__ __launch_bounds__(256) void pos_mlp_fwd_kernel(int rows, int cin, int hid, int cout, int tokens, int inverse,
+                                                          const float *__restrict__ pose, const float *__restrict__ points,
+                                                          float *__restrict__ x_out,
                                                           const float *__restrict__ x, const float *__restrict__ w1,
                                                           const float *__restrict__ b1, const float *__restrict__ w2,
                                                           const float *__restrict__ b2, const float *__restrict__ residual,
@@ -67,9 +74,24 @@ __global__ __launch_bounds__(256) void pos_mlp_fwd_kernel(int rows, int cin, int
   for (int i = 0; i < 8; ++i)
     wv[i] = (n0 + rn < cout && kq + 4 * i < hid) ? *reinterpret_cast<const float4 *>(w2 + (size_t)(n0 + rn) * hid + kq + 4 * i)
                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < SG_T * PE_MAXCIN; i += 256) {
-    const int r = i / PE_MAXCIN, c = i % PE_MAXCIN;
-    s_x[r][c] = (m0 + r < rows && c < cin) ? x[(size_t)(m0 + r) * cin + c] : 0.f;
+  if (pose != nullptr) {
+    if (tid < SG_T) {
+      const int m = m0 + tid;
+      float o[3] = {0.f, 0.f, 0.f};
+      if (m < rows) {
+        const Pose P = load_pose(pose + (size_t)(m / tokens) * 7);
+        const float *pt = points + (size_t)m * 3;
+        if (inverse) apply_pose<true>(P, pt[0], pt[1], pt[2], o);
+        else apply_pose<false>(P, pt[0], pt[1], pt[2], o);
+        if (blockIdx.y == 0) { x_out[(size_t)m * 3 + 0] = o[0]; x_out[(size_t)m * 3 + 1] = o[1]; x_out[(size_t)m * 3 + 2] = o[2]; }
+      }
+      s_x[tid][0] = o[0]; s_x[tid][1] = o[1]; s_x[tid][2] = o[2]; s_x[tid][3] = 0.f;
+    }
+  } else {
+    for (int i = tid; i < SG_T * PE_MAXCIN; i += 256) {
+      const int r = i / PE_MAXCIN, c = i % PE_MAXCIN;
+      s_x[r][c] = (m0 + r < rows && c < cin) ? x[(size_t)(m0 + r) * cin + c] : 0.f;
+    }
   }
   for (int i = tid; i < hid * (PE_MAXCIN + 1); i += 256) {
     const int k = i / (PE_MAXCIN + 1), c = i % (PE_MAXCIN + 1);
@@ -242,19 +264,38 @@ __global__ __launch_bounds__(256) void pos_mlp_bwd_w_kernel(int rows, int hid, i
 
 }  // namespace
 
-extern "C" int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const float *x, const float *w1, const float *b1,
-                                 const float *w2, const float *b2, const float *residual, float *pre, float *out,
-                                 void *stream_) {
+static int pos_mlp_fwd_impl(int rows, int cin, int hid, int cout, int tokens, int inverse, const float *pose,
+                            const float *points, float *x_out, const float *x, const float *w1, const float *b1,
+                            const float *w2, const float *b2, const float *residual, float *pre, float *out, void *stream_) {
   SIG3D_REQUIRE(rows >= 0 && cin >= 1 && cin <= PE_MAXCIN && hid >= 4 && hid <= PE_MAXHID && hid % 4 == 0 && cout >= 4 && cout % 4 == 0,
                 "pos_mlp: 1 <= cin <= 4, hid <= 128, hid and cout multiples of 4");
-  SIG3D_REQUIRE(x && w1 && b1 && w2 && b2 && pre && out, "null argument");
+  SIG3D_REQUIRE((x || pose) && w1 && b1 && w2 && b2 && pre && out, "null argument");
   if (rows == 0) return 0;
   const size_t lds = sizeof(float) * 2 * SG_K * SG_LD;   // 68 KB of operand tiles
   SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)pos_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(pos_mlp_fwd_kernel, dim3(sig3d_ceil_div(rows, SG_T), sig3d_ceil_div(cout, SG_T)), dim3(256), lds,
-                     (hipStream_t)stream_, rows, cin, hid, cout, x, w1, b1, w2, b2, residual, pre, out);
+                     (hipStream_t)stream_, rows, cin, hid, cout, tokens, inverse, pose, points, x_out, x, w1, b1, w2, b2,
+                     residual, pre, out);
   SIG3D_LAUNCH_CHECK("pos_mlp_fwd_kernel");
   return 0;
+}
+
+extern "C" int sig3d_pos_mlp_fwd(int rows, int cin, int hid, int cout, const float *x, const float *w1, const float *b1,
+                                 const float *w2, const float *b2, const float *residual, float *pre, float *out,
+                                 void *stream_) {
+  SIG3D_REQUIRE(x != nullptr, "null argument");
+  return pos_mlp_fwd_impl(rows, cin, hid, cout, 1, 0, nullptr, nullptr, nullptr, x, w1, b1, w2, b2, residual, pre, out, stream_);
+}
+
+// The situational re-encode folded in: x = R(q)^T (points - t) (inverse != 0) or R(q) points + t, formed from pose
+// (b, 7) and points (b * tokens, 3) inside the launch and written to x_out (b * tokens, 3); then as sig3d_pos_mlp_fwd.
+extern "C" int sig3d_pos_mlp_fwd_posed(int b, int tokens, int hid, int cout, int inverse, const float *pose,
+                                       const float *points, float *x_out, const float *w1, const float *b1,
+                                       const float *w2, const float *b2, const float *residual, float *pre, float *out,
+                                       void *stream_) {
+  SIG3D_REQUIRE(b >= 0 && tokens >= 1 && pose && points && x_out, "bad arguments");
+  return pos_mlp_fwd_impl(b * tokens, 3, hid, cout, tokens, inverse, pose, points, x_out, nullptr, w1, b1, w2, b2, residual,
+                          pre, out, stream_);
 }
 
 static int pos_mlp_bwd_impl(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,

@@ -16,7 +16,7 @@ from .pointnet2.fused_mlp import attach_scan, point_major_of
 from .pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 from .qformer import init_Qformer
 from .situational import gaussian_localisation_target, situational_transform
-from .small_mlp import pos_embed_add
+from .small_mlp import pos_embed_add, posed_pos_embed_add
 from . import heads
 
 
@@ -112,11 +112,16 @@ class SIG3DQFormer(nn.Module):
 
         # situational re-encode: token positions in the agent's frame, R(q)^T (p - t)
         pose = data_dict["auxiliary_task"]
-        sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
-        data_dict["situational_positions"] = sit_xyz
         data_dict["auxiliary_task_loc_gt"] = gaussian_localisation_target(tok_xyz, pose)   # reads pose[:, :2]
-        # tok_feat + Linear(GELU(Linear(position))): one launch (small_mlp.pos_embed_add; torch path off the GPU)
-        tokens = pos_embed_add(self.pos_embed, sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2], tok_feat)
+        # re-encode + tok_feat + Linear(GELU(Linear(position))) as ONE launch (small_mlp.posed_pos_embed_add: the
+        # transform is formed inside the positional MLP's kernel); two launches / the torch path where that is not covered
+        fused = posed_pos_embed_add(self.pos_embed, pose, tok_xyz, tok_feat, inverse=True) if self.pos_embed_dim == 3 else None
+        if fused is not None:
+            tokens, sit_xyz = fused
+        else:
+            sit_xyz = situational_transform(pose, tok_xyz, inverse=True)
+            tokens = pos_embed_add(self.pos_embed, sit_xyz if self.pos_embed_dim == 3 else tok_xyz[..., :2], tok_feat)
+        data_dict["situational_positions"] = sit_xyz
         if data_dict.get("_split_backward"):
             # data-parallel step (graph_step.py): the backward pass is cut at the visual tokens (and, with
             # `_qf_cut`, once more inside the Q-Former) so that the gradient all-reduce of everything

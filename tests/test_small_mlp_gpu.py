@@ -51,3 +51,36 @@ def test_pos_embed_add_falls_back_for_what_the_kernels_do_not_cover():
     cpu = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, 256))
     assert not _covered(cpu, x.cpu(), res.cpu())
     torch.testing.assert_close(pos_embed_add(cpu, x.cpu(), res.cpu()), res.cpu() + cpu(x.cpu()))
+
+
+def test_situational_transform_folded_into_the_positional_mlp_is_bit_identical():
+    """sig3d_pos_mlp_fwd_posed forms x = R(q)^T (p - t) inside the positional MLP's launch (temp.py:86-97 +
+    sqa_module.py:274-278, 319-321 as one kernel): the re-encoded positions and the tokens must equal the two-launch
+    path bit for bit, forward and (parameter) gradients; with a gradient wanted for the pose the fold steps aside."""
+    import torch
+    from situation3d_amd.model import build_pos_embed
+    from situation3d_amd.situational import situational_transform
+    from situation3d_amd.small_mlp import pos_embed_add, posed_pos_embed_add
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    b, t = 8, 256
+    pose = torch.randn(b, 7, generator=g).to(dev)
+    pts = (torch.rand(b, t, 3, generator=g) * 8).to(dev)
+    feat = torch.randn(b, t, 256, generator=g).to(dev).requires_grad_(True)
+    mlp = build_pos_embed(3, 256).to(dev)
+    sit = situational_transform(pose, pts, inverse=True)
+    ref = pos_embed_add(mlp, sit, feat)
+    G = torch.randn(b, t, 256, generator=g).to(dev)
+    (ref * G).sum().backward()
+    ref_grads = [p.grad.clone() for p in mlp.parameters()] + [feat.grad.clone()]
+    mlp.zero_grad(set_to_none=True)
+    feat.grad = None
+    fused = posed_pos_embed_add(mlp, pose, pts, feat, inverse=True)
+    assert fused is not None
+    tokens, sit2 = fused
+    assert torch.equal(sit2, sit) and torch.equal(tokens, ref)
+    (tokens * G).sum().backward()
+    for a, r in zip([p.grad for p in mlp.parameters()] + [feat.grad], ref_grads):
+        assert torch.allclose(a, r, rtol=1e-5, atol=1e-5)            # float atomics in the weight gradients
+    assert posed_pos_embed_add(mlp, pose.clone().requires_grad_(True), pts, feat) is None
+    assert posed_pos_embed_add(build_pos_embed(2, 256).to(dev), pose, pts, feat) is None
