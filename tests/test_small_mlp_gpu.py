@@ -81,6 +81,6 @@ def test_situational_transform_folded_into_the_positional_mlp_is_bit_identical()
     assert torch.equal(sit2, sit) and torch.equal(tokens, ref)
     (tokens * G).sum().backward()
     for a, r in zip([p.grad for p in mlp.parameters()] + [feat.grad], ref_grads):
-        assert torch.allclose(a, r, rtol=1e-5, atol=1e-5)            # float atomics in the weight gradients
+        assert float((a - r).norm() / r.norm()) < 1e-5              # float atomics: the order of the sums varies
     assert posed_pos_embed_add(mlp, pose.clone().requires_grad_(True), pts, feat) is None
     assert posed_pos_embed_add(build_pos_embed(2, 256).to(dev), pose, pts, feat) is None
