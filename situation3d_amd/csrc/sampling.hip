@@ -594,12 +594,19 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
         // waves beside the training step (-0.06 ms per step, tools/ab_step.py); 16 x 256 x 10: 2.29 us/round alone and
         // +1.4 ms per step, 32 x 128 x 10: 3.03 (more peers per hop); 4 x 256 x 40 and 8 x 128 x 40 (234 VGPRs): 2.18 / 2.15
         // us/round and +0.23 / +0.44 ms per step (the chain becomes the critical path).  SIG3D_FPS_SHAPE = 0 / 1 / 2
-        // selects the first three.
+        // selects the first three.  Round 5, three chains in flight (the chain has two steps of slack, so only what the
+        // kernel costs the step beside it counts: 0.31 of the chain's 0.40 ms): 16 x 256 x 10 +0.14 ms, 32 x 128 x 10
+        // +2.3, 16 x 128 x 20 (shape 4) +0.34, 32 x 64 x 20 (5) +2.1, 4 x 512 x 20 (6) +0.16, 2 x 1024 x 20 (7) +0.51:
+        // neither thinner over more CUs nor fatter on fewer beats 8 x 256 x 20 (tools/ab_step.py env:SIG3D_FPS_SHAPE).
         const char *shape = getenv("SIG3D_FPS_SHAPE");
         const int sh = shape ? atoi(shape) : 3;
         if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);
         else if (sh == 2) rc = launch_fps_coop<128, 10, 32>(bc, n, m, L, ds, tp, ix, stream);
         else if (sh == 0) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 4) rc = launch_fps_coop<128, 20, 16>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 5) rc = launch_fps_coop<64, 20, 32>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 6) rc = launch_fps_coop<512, 20, 4>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 7) rc = launch_fps_coop<1024, 20, 2>(bc, n, m, L, ds, tp, ix, stream);
         else rc = launch_fps_coop<256, 20, 8>(bc, n, m, L, ds, tp, ix, stream);
       }
       else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);
