@@ -130,6 +130,9 @@ int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, vo
  * (b, levels sizes) since it was last written by anyone else: the per-centre counters are then zero (the rank kernel
  * zeroes each one it reads) and the memset in front of the launch pair is skipped.  flags = 0 is always safe. */
 #define SIG3D_BQ_CLEAN 1
+/* SIG3D_BQ_SHARED_TABLE: a pre-pass (one workgroup per scene of a big level) builds the table of the scene's centres
+ * once and the scatter workgroups copy it, instead of every workgroup sorting the centres itself. */
+#define SIG3D_BQ_SHARED_TABLE 4
 int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                                long workspace_bytes, int flags, void *stream);
 /* The same call, counting its work: *stats (a device word the caller zeroes) += the centre-point distance tests the

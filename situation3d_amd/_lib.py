@@ -251,6 +251,7 @@ SIGNATURES["sig3d_ball_query_levels"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ct
 SIGNATURES["sig3d_ball_query_levels_ex"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P]
 SIGNATURES["sig3d_ball_query_levels_stats"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P, _P]
 BQ_CLEAN = 1
+BQ_SHARED_TABLE = 4
 
 
 def bq_levels(problems):

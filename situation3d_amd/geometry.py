@@ -48,6 +48,11 @@ class Announced:
         return tensor is self.tensor and tensor._version == self.version
 
 
+# SIG3D_BQ_TABLE=1: the table of a scene's centres is built once by a pre-pass and copied by the scene's scatter workgroups
+# (csrc/ball_query.hip: SIG3D_BQ_SHARED_TABLE) instead of being sorted by each of them; measured, not the default
+BQ_TABLE_FLAG = _lib.BQ_SHARED_TABLE if os.environ.get("SIG3D_BQ_TABLE", "0") == "1" else 0
+
+
 class GeometryPlan:
     """levels: list of (npoint, radius, nsample) from the first SA layer down."""
 
@@ -125,7 +130,7 @@ class GeometryPlan:
                 self._bq_clean = False   # a new workspace / problem list: the next call zeroes the counters itself
             # after one completed call the workspace's counters are zero again (the rank kernel cleans up): no memset
             _lib.call("sig3d_ball_query_levels_ex", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
-                      self._bq_work.numel(), _lib.BQ_CLEAN if self._bq_clean else 0, s)
+                      self._bq_work.numel(), (_lib.BQ_CLEAN if self._bq_clean else 0) | BQ_TABLE_FLAG, s)
             # the flag describes the workspace as the DEVICE will find it at the next call: only a call that was
             # really issued (not one recorded into a graph that may never be replayed) leaves the counters zero
             self._bq_clean = not torch.cuda.is_current_stream_capturing()
