@@ -22,6 +22,10 @@
 // case return index 0 as the reference does (best = -1, besti = 0).
 #include "sig3d_common.h"
 
+#ifndef SIG3D_FPS_PROBE
+#define SIG3D_FPS_PROBE 0   // measurement builds only (wrong results): 1 = the cooperative kernel sweeps half of a thread's points per round
+#endif
+
 namespace {
 
 __device__ __forceinline__ unsigned fps_key(unsigned k, int L, unsigned bsmask) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
     float best = -1.f;
     int bslot = 0;
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
+    for (int s = 0; s < (SIG3D_FPS_PROBE == 1 ? PPT / 2 : PPT); ++s) {
       const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
       const float t = fminf(d, pt[s]);
       pt[s] = t;
