@@ -352,11 +352,17 @@ constexpr int FPS_SLOT_U64 = 128;  // per scene: 2 parities x W <= 32 workgroups
 // scenes whose cooperative FPS gave up waiting for a peer workgroup (see the poison path below)
 __device__ unsigned g_fps_timeouts = 0;
 
-template <int NT, int PPT, int W, bool PACK>
+// BLOCKED: a wave owns a spatially compact block of the scene (`order`: the scene's point numbers along a Morton curve,
+// fps_morton_order_kernel) instead of a stride of storage order, and sits a round out when the new sample is farther
+// from its block's bounding box than its largest running distance: no point of the block can change then, and its
+// candidate of the round before stands.  Same results (the tie key travels with each point, and a thread keeps its
+// points in key order); the sweep is the VALU work the kernel takes from whatever runs beside it.
+template <int NT, int PPT, int W, bool PACK, bool BLOCKED>
 __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L,
                                                       const float *__restrict__ dataset_all,
                                                       u64 *__restrict__ slots_all,
-                                                      int *__restrict__ idxs_all) {
+                                                      int *__restrict__ idxs_all,
+                                                      const unsigned short *__restrict__ order_all) {
   constexpr int NW = NT / 64;
   __shared__ int s_val[2][NW];
   __shared__ unsigned s_key[2][NW];
@@ -376,9 +382,31 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   constexpr int G = NT * W / 512;
   const int g_id = w * NT + tid, r_slot = g_id & 511, grp = g_id >> 9;
   float px[PPT], py[PPT], pz[PPT], pt[PPT];
+  unsigned pkey[BLOCKED ? PPT : 1];
+  if (BLOCKED) {
+    // wave number wb of the scene's W * NW takes positions [wb * per, (wb + 1) * per) of the Morton order.  A thread's
+    // strict `>` sweep picks its lowest slot among equal distances, so it keeps its points in key order: the keys are
+    // sorted (odd-even transposition, a min and a max per exchange) before the coordinates are fetched
+    const int per = (n + W * NW - 1) / (W * NW);
+    const unsigned short *order = order_all + (size_t)scene * n;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+      const int in_block = s * 64 + lane, pos = (w * NW + wave) * per + in_block;
+      pkey[s] = (in_block < per && pos < n) ? fps_key((unsigned)order[pos], L, bsmask) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int pass = 0; pass < PPT; ++pass) {
+#pragma unroll
+      for (int s = pass & 1; s + 1 < PPT; s += 2) {
+        const unsigned ka = pkey[s], kb = pkey[s + 1];
+        pkey[s] = min(ka, kb); pkey[s + 1] = max(ka, kb);
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
-    const int k = r_slot + 512 * (s * G + grp);
+    int k = r_slot + 512 * (s * G + grp);
+    if (BLOCKED) k = pkey[s] == 0xFFFFFFFFu ? n : (int)fps_unkey(pkey[s], L);
     float x = 0.f, y = 0.f, z = 0.f, t = -1.f;
     if (k < n) {
       x = dataset[3 * k + 0];
@@ -389,6 +417,24 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
     }
     px[s] = x; py[s] = y; pz[s] = z; pt[s] = t;
   }
+  float lo_x = 0.f, lo_y = 0.f, lo_z = 0.f, hi_x = 0.f, hi_y = 0.f, hi_z = 0.f;
+  if (BLOCKED) {
+    // the block's bounding box over the points that take part (the others never change)
+    float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s)
+      if (pt[s] >= 0.f) {
+        ax = fminf(ax, px[s]); ay = fminf(ay, py[s]); az = fminf(az, pz[s]);
+        bx = fmaxf(bx, px[s]); by = fmaxf(by, py[s]); bz = fmaxf(bz, pz[s]);
+      }
+    for (int o = 32; o >= 1; o >>= 1) {
+      ax = fminf(ax, __shfl_xor(ax, o)); ay = fminf(ay, __shfl_xor(ay, o)); az = fminf(az, __shfl_xor(az, o));
+      bx = fmaxf(bx, __shfl_xor(bx, o)); by = fmaxf(by, __shfl_xor(by, o)); bz = fmaxf(bz, __shfl_xor(bz, o));
+    }
+    lo_x = ax; lo_y = ay; lo_z = az; hi_x = bx; hi_y = by; hi_z = bz;
+  }
+  int held_v = 0x7F800000;   // the wave's candidate of its last sweep (+inf: the first round always sweeps)
+  unsigned held_k = 0xFFFFFFFFu;
 
   int old = 0;
   if (tid == 0 && w == 0) idxs[0] = 0;
@@ -396,22 +442,40 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
 
   for (int j = 1; j < m; ++j) {
     const float x1 = dataset[3 * old + 0], y1 = dataset[3 * old + 1], z1 = dataset[3 * old + 2];
-    float best = -1.f;
-    int bslot = 0;
-#pragma unroll
-    for (int s = 0; s < (SIG3D_FPS_PROBE == 1 ? PPT / 2 : PPT); ++s) {
-      const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
-      const float t = fminf(d, pt[s]);
-      pt[s] = t;
-      const bool gt = t > best;
-      best = gt ? t : best;
-      bslot = gt ? s : bslot;
+    int wv;
+    unsigned wk;
+    bool sit_out = false;
+    if (BLOCKED) {
+      // squared distance from the sample to the block's box, shrunk by more than any rounding of either side: every
+      // point's individually rounded distance is then >= its running distance (NaN compares false: sweep)
+      const float ex = fmaxf(fmaxf(lo_x - x1, x1 - hi_x), 0.f), ey = fmaxf(fmaxf(lo_y - y1, y1 - hi_y), 0.f);
+      const float ez = fmaxf(fmaxf(lo_z - z1, z1 - hi_z), 0.f);
+      const float d_box = (ex * ex + ey * ey + ez * ez) * 0.99998f;
+      sit_out = held_v < 0 || d_box > __builtin_bit_cast(float, held_v);
+      sit_out = __builtin_amdgcn_readfirstlane((int)sit_out) != 0;
     }
-    const int bk = r_slot + 512 * (bslot * G + grp);
-    const int myv = __builtin_bit_cast(int, best);
-    const int wv = wave_allreduce_max_i32(myv);
-    const unsigned mykey = (myv == wv) ? fps_key((unsigned)bk, L, bsmask) : 0xFFFFFFFFu;
-    const unsigned wk = wave_allreduce_min_u32(mykey);
+    if (!sit_out) {
+      float best = -1.f;
+      int bslot = 0;
+      unsigned bkey = BLOCKED ? pkey[0] : 0u;
+#pragma unroll
+      for (int s = 0; s < (SIG3D_FPS_PROBE == 1 ? PPT / 2 : PPT); ++s) {
+        const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
+        const float t = fminf(d, pt[s]);
+        pt[s] = t;
+        const bool gt = t > best;
+        best = gt ? t : best;
+        if (BLOCKED) bkey = gt ? pkey[s] : bkey;
+        else bslot = gt ? s : bslot;
+      }
+      const int myv = __builtin_bit_cast(int, best);
+      wv = wave_allreduce_max_i32(myv);
+      if (!BLOCKED) bkey = fps_key((unsigned)(r_slot + 512 * (bslot * G + grp)), L, bsmask);
+      wk = wave_allreduce_min_u32((myv == wv) ? bkey : 0xFFFFFFFFu);
+      held_v = wv; held_k = wk;
+    } else {
+      wv = held_v; wk = held_k;
+    }
     const int par = j & 1;
     if (lane == 0) {
       s_val[par][wave] = wv;
@@ -492,20 +556,103 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   }
 }
 
-template <int NT, int PPT, int W>
+// The scene's point numbers in the order of a Morton curve over a 32 x 32 x 8 grid of its bounding box (8 x 8 x 8 cells
+// interleaved bit by bit, the 4 x 4 such cubes in x and y above them): a counting
+// sort in LDS, one workgroup per scene.  Which of a cell's points comes first is left to the atomics -- the sampling
+// result does not depend on the order, only how compact a wave's block is.  n <= 65535 (16-bit point numbers).
+__device__ __forceinline__ unsigned fps_spread3(unsigned v) {
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+constexpr int FPS_CELLS = 32 * 32 * 8;
+
+__global__ __launch_bounds__(1024) void fps_morton_order_kernel(int n, const float *__restrict__ dataset_all,
+                                                                unsigned short *__restrict__ order_all) {
+  __shared__ int s_bin[FPS_CELLS];
+  __shared__ float s_box[6][16];
+  __shared__ int s_scan[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *dataset = dataset_all + (size_t)blockIdx.x * n * 3;
+  unsigned short *order = order_all + (size_t)blockIdx.x * n;
+  float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+  for (int k = tid; k < n; k += 1024) {
+    const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+    ax = fminf(ax, x); ay = fminf(ay, y); az = fminf(az, z);
+    bx = fmaxf(bx, x); by = fmaxf(by, y); bz = fmaxf(bz, z);
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    ax = fminf(ax, __shfl_xor(ax, o)); ay = fminf(ay, __shfl_xor(ay, o)); az = fminf(az, __shfl_xor(az, o));
+    bx = fmaxf(bx, __shfl_xor(bx, o)); by = fmaxf(by, __shfl_xor(by, o)); bz = fmaxf(bz, __shfl_xor(bz, o));
+  }
+  if (lane == 0) {
+    s_box[0][wave] = ax; s_box[1][wave] = ay; s_box[2][wave] = az;
+    s_box[3][wave] = bx; s_box[4][wave] = by; s_box[5][wave] = bz;
+  }
+  for (int i = tid; i < FPS_CELLS; i += 1024) s_bin[i] = 0;
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    ax = fminf(ax, s_box[0][i]); ay = fminf(ay, s_box[1][i]); az = fminf(az, s_box[2][i]);
+    bx = fmaxf(bx, s_box[3][i]); by = fmaxf(by, s_box[4][i]); bz = fmaxf(bz, s_box[5][i]);
+  }
+  const float sx = 32.f / (bx - ax), sy = 32.f / (by - ay), sz = 8.f / (bz - az);
+  // NaN, infinities and a flat box all land in a valid cell: fmaxf(NaN, 0) = 0
+  auto cell_of = [&](int k) {
+    const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+    const unsigned ix = (unsigned)fminf(fmaxf((x - ax) * sx, 0.f), 31.f);
+    const unsigned iy = (unsigned)fminf(fmaxf((y - ay) * sy, 0.f), 31.f);
+    const unsigned iz = (unsigned)fminf(fmaxf((z - az) * sz, 0.f), 7.f);
+    const unsigned hx = ix >> 3, hy = iy >> 3;
+    const unsigned hi = (hx & 1u) | ((hy & 1u) << 1) | ((hx & 2u) << 1) | ((hy & 2u) << 2);
+    return (int)(fps_spread3(ix & 7u) | (fps_spread3(iy & 7u) << 1) | (fps_spread3(iz) << 2) | (hi << 9));
+  };
+  for (int k = tid; k < n; k += 1024) atomicAdd(&s_bin[cell_of(k)], 1);
+  __syncthreads();
+  // exclusive scan: 8 consecutive cells per thread
+  constexpr int CPT = FPS_CELLS / 1024;
+  int c[CPT], sum = 0;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) { c[i] = s_bin[tid * CPT + i]; sum += c[i]; }
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  int base = inc - sum;
+  for (int i = 0; i < wave; ++i) base += s_scan[i];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) { s_bin[tid * CPT + i] = base; base += c[i]; }
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) {
+    const int pos = atomicAdd(&s_bin[cell_of(k)], 1);
+    if (pos >= 0 && pos < n) order[pos] = (unsigned short)k;
+  }
+}
+
+template <int NT, int PPT, int W, bool BLOCKED = false>
 int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
                     hipStream_t stream) {
   // one packed granule per workgroup and round when the key fits 16 bits (SIG3D_FPS_PACK=0: the two-granule form)
   const char *pk = getenv("SIG3D_FPS_PACK");
   const bool pack = n <= 65536 && m <= 65536 && L >= 6 && L <= 16 && !(pk && atoi(pk) == 0);
-  // the granule slots live at the front of the caller's temp scratch (b*n floats >= b*128)
+  // the granule slots live at the front of the caller's temp scratch (b*n floats >= b*128), the Morton order of the
+  // blocked form behind them (b * n 16-bit numbers: b * 1024 + 2 b n <= 4 b n bytes from n = 512)
   SIG3D_HIP_TRY(hipMemsetAsync(temp, 0, sizeof(u64) * (size_t)b * FPS_SLOT_U64, stream));
+  unsigned short *order = nullptr;
+  if (BLOCKED) {
+    order = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(temp) + sizeof(u64) * (size_t)b * FPS_SLOT_U64);
+    hipLaunchKernelGGL(fps_morton_order_kernel, dim3(b), dim3(1024), 0, stream, n, dataset, order);
+    SIG3D_LAUNCH_CHECK("fps_morton_order_kernel");
+  }
   if (pack)
-    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, true>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
-                       dataset, (u64 *)temp, idxs);
+    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, true, BLOCKED>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
+                       dataset, (u64 *)temp, idxs, order);
   else
-    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, false>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
-                       dataset, (u64 *)temp, idxs);
+    hipLaunchKernelGGL((fps_coop_kernel<NT, PPT, W, false, BLOCKED>), dim3(b * W), dim3(NT), 0, stream, b, n, m, L,
+                       dataset, (u64 *)temp, idxs, order);
   SIG3D_LAUNCH_CHECK("fps_coop_kernel");
   return 0;
 }
@@ -602,6 +749,10 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
         // kernel costs the step beside it counts: 0.31 of the chain's 0.40 ms): 16 x 256 x 10 +0.14 ms, 32 x 128 x 10
         // +2.3, 16 x 128 x 20 (shape 4) +0.34, 32 x 64 x 20 (5) +2.1, 4 x 512 x 20 (6) +0.16, 2 x 1024 x 20 (7) +0.51:
         // neither thinner over more CUs nor fatter on fewer beats 8 x 256 x 20 (tools/ab_step.py env:SIG3D_FPS_SHAPE).
+        // Late round 5, the blocked form (fps_coop_kernel BLOCKED: waves own a compact block of the scene and sit out the
+        // rounds that cannot change it): alone 1.72 us/round as before (the exchange bounds a round), beside the step
+        // -0.144 ms (7.673 -> 7.529, tools/ab_step.py env:SIG3D_FPS_SHAPE 8 3).  Blocked 8 x 512 x 10 (shape 9, blocks
+        // of half the size) +0.11 ms against it, 16 x 256 x 10 (10) +0.57, 4 x 512 x 20 (11) +0.12.
         const char *shape = getenv("SIG3D_FPS_SHAPE");
         const int sh = shape ? atoi(shape) : 3;
         if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);
@@ -611,7 +762,11 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
         else if (sh == 5) rc = launch_fps_coop<64, 20, 32>(bc, n, m, L, ds, tp, ix, stream);
         else if (sh == 6) rc = launch_fps_coop<512, 20, 4>(bc, n, m, L, ds, tp, ix, stream);
         else if (sh == 7) rc = launch_fps_coop<1024, 20, 2>(bc, n, m, L, ds, tp, ix, stream);
-        else rc = launch_fps_coop<256, 20, 8>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 8) rc = launch_fps_coop<256, 20, 8>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 9) rc = launch_fps_coop<512, 10, 8, true>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 10) rc = launch_fps_coop<256, 10, 16, true>(bc, n, m, L, ds, tp, ix, stream);
+        else if (sh == 11) rc = launch_fps_coop<512, 20, 4, true>(bc, n, m, L, ds, tp, ix, stream);
+        else rc = launch_fps_coop<256, 20, 8, true>(bc, n, m, L, ds, tp, ix, stream);   // blocks that sit rounds out
       }
       else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 98304) rc = launch_fps_coop<512, 24, 8>(bc, n, m, L, ds, tp, ix, stream);

@@ -59,21 +59,42 @@ def test_fps_all_skipped_and_m_gt_n(hip_ext, oracle):
                        oracle.furthest_point_sampling(xyz, 60))
 
 
-@pytest.mark.parametrize("shape", ["0", "1", "2", "3", "3-two-granules"])
+@pytest.mark.parametrize("shape", ["0", "1", "2", "3", "3-two-granules", "8", "9", "10", "11"])
 def test_fps_workgroup_shapes_keep_the_reference_tie_order(hip_ext, oracle, shape, monkeypatch):
-    """SIG3D_FPS_SHAPE: 8 x 512 x 10, 16 x 256 x 10, 32 x 128 x 10 and 8 x 256 x 20 (the default) threads x points
-    per scene at 24 577-40 960 points.  A thread's points always share one slot of the reference's 512-thread block
-    (k = r + 512 (s G + grp)), so exact ties (duplicated points, a grid) and the zero tail resolve as in the reference
-    whatever the shape; read at launch time."""
+    """SIG3D_FPS_SHAPE: 8 x 512 x 10, 16 x 256 x 10, 32 x 128 x 10 and 8 x 256 x 20 threads x points per scene at
+    24 577-40 960 points, where a thread's points share one slot of the reference's 512-thread block
+    (k = r + 512 (s G + grp)); 3 (the default) and 9-11: waves that own a compact block of the scene's Morton order and
+    sit rounds out, where a thread keeps its points sorted by tie key.  Exact ties (duplicated points, a grid) and the
+    zero tail resolve as in the reference whatever the shape; read at launch time."""
     if shape.endswith("two-granules"):       # SIG3D_FPS_PACK=0: {round, value} + {round, key} instead of one packed granule
         monkeypatch.setenv("SIG3D_FPS_PACK", "0")
-    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape[0])
+    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape.split("-")[0])
     _fps_case(hip_ext, oracle, 2, 40000, 600, seed=21, dup=4000, zero_tail=900)
     _fps_case(hip_ext, oracle, 1, 24577, 300, seed=22, dup=2000, zero_tail=100)
     g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1)
     xyz = (g.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()          # 32 000 grid points: massive exact ties
     ref = oracle.furthest_point_sampling(xyz, 400)
     assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 400).cpu(), ref)
+
+
+def test_fps_blocked_degenerate_boxes(hip_ext, oracle):
+    """The blocked kernel's Morton order and its sit-out test on boxes that break a grid: a flat scene (one extent 0),
+    all points in one spot plus a far outlier, two tight clusters (most waves sit out from round 3), and a scene whose
+    first rounds tie everywhere."""
+    g = torch.Generator().manual_seed(5)
+    flat = torch.rand(1, 30000, 3, generator=g) * 6 + 0.5
+    flat[..., 2] = 1.25
+    spot = torch.full((1, 26000, 3), 2.0)
+    spot[0, 17] = torch.tensor([9.0, 2.0, 2.0])
+    spot[0, 5000:5100] += torch.rand(100, 3, generator=g) * 1e-3
+    two = torch.cat([torch.rand(1, 20000, 3, generator=g) * 0.2 + 1.0, torch.rand(1, 20000, 3, generator=g) * 0.2 + 7.0], 1)
+    two = two[:, torch.randperm(40000, generator=g)]
+    line = torch.zeros(1, 32768, 3)
+    line[0, :, 0] = (torch.arange(32768) % 4096) * 0.01 + 1.0           # 8 copies of each of 4096 collinear points
+    for cloud, m in ((flat, 500), (spot, 300), (two, 700), (line, 300)):
+        cloud = cloud.contiguous()
+        ref = oracle.furthest_point_sampling(cloud, m)
+        assert torch.equal(hip_ext.furthest_point_sampling(cloud.to(DEV), m).cpu(), ref)
 
 
 def test_fps_scene_40k(hip_ext, oracle):
