@@ -490,51 +490,8 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
 
 /* ---- Q-Former dense layers -------------------------------------------------------------- */
 
-/* Exact-f32 MFMA GEMM with the epilogues of the Q-Former's nn.Linear layers
- *   3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py:116-118, 238, 305, 320 (forward: x W^T + b),
- * and of their backward products (dX = dY W, dW = dY^T X, db = column sums of dY).  For every batch
- * element i < batch (operands advance by their stride_* elements):
- *     C (m x n, row stride ldc)  =  A (m x k) * B (k x n)   [+ bias]  [epilogue]  [+ C]
- * amode 0: A(i,l) = A[i*lda + l] (k-contiguous)    amode 1: A(i,l) = A[l*lda + i] (m-contiguous)
- * bmode 0: B(l,j) = B[j*ldb + l] (k-contiguous: an nn.Linear weight in the forward product)
- * bmode 1: B(l,j) = B[l*ldb + j] (n-contiguous);   (amode 1, bmode 0) is not instantiated.
- * bias   : (n) added per column, or NULL.
- * act    : 0 none;  1 C = gelu_erf(acc + bias), and aux (same shape / ldc as C, may be NULL) receives the
- *          pre-activation acc + bias;  2 C = (acc + bias) * gelu_erf'(aux)  (BertIntermediate backward).
- * accumulate != 0: C += result (the caller's C holds the addend, e.g. the residual path's gradient).
- * rowsum : (m) or NULL; amode 1 only: rowsum[i] = sum_l A(i,l) -- the bias gradient of a dW product,
- *          taken from the A operand while it is staged.  With ksplit == 1 it is OVERWRITTEN; with a split K
- *          (ksplit > 1, which also requires accumulate != 0) the K slices ADD their partial sums with float
- *          atomics, so the CALLER MUST ZERO rowsum before the launch -- exactly as it initialises C.
- * tile   : 0 = choose; 1..4 = workgroup tile 64x64 / 32x128 / 64x128 / 128x64 (rows x columns of C).
- * ksplit : 0 = choose; s > 1 splits K over s workgroups per tile which meet through float atomics on C --
- *          only with act == 0 and accumulate != 0 (C initialised by the caller), else it is forced to 1. */
-int sig3d_gemm(int amode, int bmode, int batch, int m, int n, int k, const float *A, int lda,
-               long stride_a, const float *B, int ldb, long stride_b, float *C, int ldc, long stride_c,
-               const float *bias, long stride_bias, int act, float *aux, int accumulate, float *rowsum,
-               long stride_rowsum, int tile, int ksplit, void *stream);
-
-/* The same products as a GROUP: up to four independent problems in ONE launch (their workgroups share the
- * grid) -- e.g. the dX and the dW product of one layer, which depend on the same dY only.  Fields as the
- * arguments of sig3d_gemm; in addition a batch may be RAGGED: elements 0 .. batch-2 have m rows, the last one
- * m_last <= m rows and a contraction of k_last <= k (the query branch and the shorter text branch of BertLayer's
- * feed-forward, Qformer.py:396-405, as a batch of two without padding rows: m_last in the forward and dX
- * products, k_last in the dW products, whose contraction runs over the rows).  All problems of a group use the
- * tile of the first one. */
-typedef struct sig3d_gemm_problem {
-  int amode, bmode, batch, m, n, k, m_last, k_last;
-  const float *A; int lda; long stride_a;
-  const float *B; int ldb; long stride_b;
-  float *C; int ldc; long stride_c;
-  const float *bias; long stride_bias;
-  int act; float *aux; int accumulate;
-  float *rowsum; long stride_rowsum;
-  int tile, ksplit;
-} sig3d_gemm_problem;
-int sig3d_gemm_group(int nprob, const sig3d_gemm_problem *problems, void *stream);
-
-/* Round 4: the exact-f32 MFMA GEMM the step RUNS on (csrc/gemm16_core.h; sig3d_gemm above is round 2's family,
- * kept as a tested entry point).  Replaces the rocBLAS / hipBLASLt launches behind
+/* Round 4: the exact-f32 MFMA GEMM the step RUNS on (csrc/gemm16_core.h; round 2's first family, sig3d_gemm /
+ * sig3d_gemm_group, left the library in round 5: nothing called it).  Replaces the rocBLAS / hipBLASLt launches behind
  *   Qformer.py:116-118 (query / key / value: x W^T + b), :238 and :320 (the dense halves of BertSelfOutput /
  *   BertOutput), :305-313 (BertIntermediate: dense + erf-GELU) and the input-gradient products dX = dY W of
  *   their backward passes (torch: F.linear / addmm / bmm / mm).

@@ -111,8 +111,6 @@ SIGNATURES = {
     "sig3d_adamw_table": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _P],
     "sig3d_adamw_table_bounded": [_I, _P, _P, _F, _P, _F, _F, _F, _F, _I, _P],
     "sig3d_gather_table": [_I, _P, _P],
-    "sig3d_gemm": [_I, _I, _I, _I, _I, _I, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long, _P, _I, ctypes.c_long,
-                   _P, ctypes.c_long, _I, _P, _I, _P, ctypes.c_long, _I, _I, _P],
     "sig3d_attention_fwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _F,
                             ctypes.c_uint, _P, _I, _P, _P],
     "sig3d_attention_bwd": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
@@ -121,43 +119,6 @@ SIGNATURES = {
                               _F, ctypes.c_uint, _P, _P],
 }
 
-
-class GemmProblem(ctypes.Structure):
-    """struct sig3d_gemm_problem of include/sig3d_hip.h (field order and types must match)."""
-    _fields_ = [("amode", _I), ("bmode", _I), ("batch", _I), ("m", _I), ("n", _I), ("k", _I), ("m_last", _I), ("k_last", _I),
-                ("A", _P), ("lda", _I), ("stride_a", ctypes.c_long),
-                ("B", _P), ("ldb", _I), ("stride_b", ctypes.c_long),
-                ("C", _P), ("ldc", _I), ("stride_c", ctypes.c_long),
-                ("bias", _P), ("stride_bias", ctypes.c_long),
-                ("act", _I), ("aux", _P), ("accumulate", _I),
-                ("rowsum", _P), ("stride_rowsum", ctypes.c_long),
-                ("tile", _I), ("ksplit", _I)]
-
-
-SIGNATURES["sig3d_gemm_group"] = [_I, ctypes.POINTER(GemmProblem), _P]
-
-
-def gemm_problem(**kw):
-    """A GemmProblem with tensors given as tensors; m_last / k_last default to m / k."""
-    p = GemmProblem()
-    vals = dict(amode=0, bmode=0, batch=1, m=0, n=0, k=0, m_last=None, k_last=None, A=None, lda=0, stride_a=0,
-                B=None, ldb=0, stride_b=0, C=None, ldc=0, stride_c=0, bias=None, stride_bias=0, act=0, aux=None,
-                accumulate=0, rowsum=None, stride_rowsum=0, tile=0, ksplit=0)
-    vals.update(kw)
-    if vals["m_last"] is None:
-        vals["m_last"] = vals["m"]
-    if vals["k_last"] is None:
-        vals["k_last"] = vals["k"]
-    for name, v in vals.items():
-        setattr(p, name, v.data_ptr() if hasattr(v, "data_ptr") else v)
-    return p
-
-
-def gemm_group(device, *problems):
-    """One launch for up to four independent products (sig3d_gemm_group)."""
-    arr = (GemmProblem * len(problems))(*problems)
-    with torch.cuda.device(device):
-        call("sig3d_gemm_group", len(problems), arr, stream_ptr(device))
 
 class Gemm16Problem(ctypes.Structure):
     """struct sig3d_gemm16_problem of include/sig3d_hip.h (field order and types must match)."""

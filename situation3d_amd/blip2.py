@@ -38,57 +38,9 @@ def sinusoid_table(n_pos=256, channels=1408 // 3):
     return emb[:, :channels].contiguous()
 
 
-class _LinearRowsFn(torch.autograd.Function):
-    """`t5_proj` (blip2_t5.py:91,128) on the hand-written f32-MFMA GEMM family (csrc/gemm.hip): the forward is ONE
-    launch with the bias in the epilogue, reading the Q-Former's query rows where its last LayerNorm tail left
-    them; the backward is ONE grouped launch for dX = dY W, dW = dY^T X and db (column sums taken from the dY
-    operand while it is staged) -- the library path is an addmm plus two mm, a sum and their transposes."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        rows = x.reshape(-1, x.shape[-1])
-        if not rows.is_contiguous():
-            rows = rows.contiguous()
-        m, k = rows.shape
-        n = weight.shape[0]
-        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
-        _lib.gemm_group(x.device, _lib.gemm_problem(m=m, n=n, k=k, A=rows, lda=k, B=weight, ldb=k, C=out, ldc=n,
-                                                    bias=bias))
-        ctx.save_for_backward(rows, weight)
-        ctx.shape = x.shape
-        return out.view(*x.shape[:-1], n)
-
-    @staticmethod
-    def backward(ctx, grad):
-        rows, weight = ctx.saved_tensors
-        m, k = rows.shape
-        n = weight.shape[0]
-        dy = grad.reshape(m, n)
-        if not dy.is_contiguous():
-            dy = dy.contiguous()
-        dx = torch.empty_like(rows)
-        dw = torch.empty_like(weight)
-        db = torch.empty(n, dtype=torch.float32, device=rows.device)
-        _lib.gemm_group(
-            rows.device,
-            _lib.gemm_problem(amode=0, bmode=1, m=m, n=k, k=n, A=dy, lda=n, B=weight, ldb=k, C=dx, ldc=k),
-            _lib.gemm_problem(amode=1, bmode=1, m=n, n=k, k=m, A=dy, lda=n, B=rows, ldb=k, C=dw, ldc=k, rowsum=db))
-        return dx.view(ctx.shape), dw, db
-
-
-def linear_rows(x, linear):
-    """nn.Linear through _LinearRowsFn when it can run there (CUDA, float32), else the module itself."""
-    if x.is_cuda and x.dtype == torch.float32 and linear.bias is not None:
-        return _LinearRowsFn.apply(x, linear.weight, linear.bias)
-    return linear(x)
-
-
-# Measured (tools/linear_rows_bench.py, forward + backward, hipGraph-timed): 128 x 768 -> 2048 (B = 4, the t5_proj
-# shape) 110 us on the hand-written family against 31.6 us on the tuned library kernels; 512 rows: 117 vs 70.
-# With 24-64 workgroups and K loops of 768-2048 the hand-written tiles are latency-bound exactly as DESIGN.md 4b
-# found for the Q-Former's own layers, so the module's library path is the default and the single-launch form is
-# opt-in (SIG3D_T5_PROJ_HANDWRITTEN=1; parity-tested either way).
-T5_PROJ_HANDWRITTEN = os.environ.get("SIG3D_T5_PROJ_HANDWRITTEN", "0") == "1"
+# `t5_proj` (blip2_t5.py:91,128) stays on the library: 128 x 768 -> 2048 forward + backward is 31.6 us there; a
+# single-launch form on round 2's hand-written f32 tiles took 110 us (24-64 workgroups, K loops of 768-2048: latency
+# bound) and left the library with that family in round 5.
 
 
 class _PosEmbedAdd(torch.autograd.Function):
@@ -132,7 +84,7 @@ class Blip2PointQFormer(nn.Module):
         query_output = self.Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=pc_embeds,
                                          encoder_attention_mask=image_atts, return_dict=True)
         hidden = query_output.last_hidden_state
-        inputs_t5 = linear_rows(hidden, self.t5_proj) if T5_PROJ_HANDWRITTEN else self.t5_proj(hidden)
+        inputs_t5 = self.t5_proj(hidden)
         atts_t5 = torch.ones(inputs_t5.size()[:-1], dtype=torch.long, device=pc_embeds.device)
         loss = None
         if self.language_head is not None:

@@ -51,25 +51,3 @@ def test_blip2_point_qformer_forward_samples_contract():
     out["loss"].backward()
     assert m.query_tokens.grad is not None and torch.isfinite(m.query_tokens.grad).all()
     assert m.t5_proj.weight.grad.abs().sum() > 0
-
-
-@pytest.mark.parametrize("shape,n", [((4, 32, 768), 2048), ((2, 8, 128), 64), ((1, 5, 96), 33)])
-def test_t5_proj_on_the_hand_written_gemm_family(shape, n):
-    """blip2.linear_rows (t5_proj, blip2_t5.py:128): one launch forward (bias epilogue), one grouped launch
-    backward (dX, dW, db) through csrc/gemm.hip; against nn.Linear in float64, 1e-4."""
-    from situation3d_amd.blip2 import linear_rows
-    torch.manual_seed(n)
-    lin = torch.nn.Linear(shape[-1], n).to(DEV)
-    x = torch.randn(*shape, device=DEV, requires_grad=True)
-    go = torch.randn(*shape[:-1], n, device=DEV)
-    y = linear_rows(x, lin)
-    y.backward(go)
-    got = [y.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
-    ref_lin = torch.nn.Linear(shape[-1], n).double().to(DEV)
-    ref_lin.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
-    xr = x.detach().double().requires_grad_(True)
-    yr = ref_lin(xr)
-    yr.backward(go.double())
-    for g, r in zip(got, [yr.detach(), xr.grad, ref_lin.weight.grad, ref_lin.bias.grad]):
-        assert g.shape == r.shape
-        assert (g.double() - r).abs().max() <= 1e-4 * max(1.0, float(r.abs().max()))
