@@ -15,7 +15,9 @@ plain `torch.zeros`.  Slices are only valid until the next `begin_step`: nothing
 may come from here.
 
 Only the step's own stream may use it: the geometry chains of the NEXT batch run beside the step on their own
-streams (geometry.GeometryPipeline) and keep their own buffers.
+streams (geometry.GeometryPipeline) and keep their own buffers.  The region remembers the stream that opened the step; a
+request made with another stream current gets a plain `torch.zeros` (not the thread: autograd runs the backward pass
+of the same step on its own thread, with the forward's stream current).
 """
 import os
 
@@ -38,6 +40,7 @@ class StepZeros:
         self.grads_ok = False     # may slices become `.grad` of a parameter?  (begin_step: the caller's promise)
         self.hits = 0
         self.misses = 0
+        self._owner = None        # the stream of the step that is open
 
     def begin_step(self, device, grads_ok=False):
         """On the step's stream, before its first kernel: zero the region (one fill).
@@ -48,6 +51,7 @@ class StepZeros:
         self._cursor = self._demand = 0
         self._zeroed = 0
         self._active = ENABLED and device.type == "cuda"
+        self._owner = torch.cuda.current_stream(device) if self._active else None
         if not self._active or self._want == 0:
             return
         if self._buf is None or self._buf.device != device or self._buf.numel() < self._want:
@@ -63,6 +67,7 @@ class StepZeros:
         if self._active:
             self._want = self._demand
         self._active = False
+        self._owner = None
         self.grads_ok = False
 
     def zeros(self, shape, dtype, device):
@@ -73,6 +78,8 @@ class StepZeros:
         for s in shape:
             n *= int(s)
         nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if self._active and self._owner != torch.cuda.current_stream(self._owner.device):
+            return torch.zeros(shape, dtype=dtype, device=device)      # not the step: a side stream (geometry chain, ...)
         if not self._active or self._buf is None or torch.device(device) != self._buf.device:
             if self._active:
                 self._demand += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN

@@ -43,6 +43,26 @@ def test_region_is_sized_from_the_previous_step_and_falls_back_when_it_does_not_
     assert not z.owns(a3)                                      # closed: nothing is promised any more
 
 
+def test_only_the_stream_that_opened_the_step_is_served_from_the_region():
+    """A request with another stream current (a geometry chain beside the step) gets its own torch.zeros: the region
+    is ordered with the step's stream only and is zeroed again at the next begin_step."""
+    from situation3d_amd.scratch import StepZeros
+    z = StepZeros()
+    for _ in range(2):
+        z.begin_step(DEV)
+        z.zeros((1024,), torch.float32, DEV)
+        z.end_step()
+    z.begin_step(DEV)
+    mine = z.zeros((256,), torch.float32, DEV)
+    side = torch.cuda.Stream(DEV)
+    with torch.cuda.stream(side):
+        other = z.zeros((256,), torch.float32, DEV)
+    again = z.zeros((256,), torch.float32, DEV)
+    assert z.owns(mine) and z.owns(again) and not z.owns(other)
+    assert float(other.abs().sum()) == 0
+    z.end_step()
+
+
 def test_a_captured_step_keeps_its_region_when_a_later_step_outgrows_it():
     from situation3d_amd.scratch import StepZeros
     z = StepZeros()
