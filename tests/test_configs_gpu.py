@@ -271,7 +271,7 @@ def test_config5_blip2_shape_nk80000_forward_backward_matches_oracle():
     assert n >= 6 * 5
 
 
-@pytest.mark.parametrize("own_gemm,own_dw", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("own_gemm,own_dw", [(0, False), (64, False), (127, False), (0, True)])
 def test_full_size_qformer_forward_backward_matches_oracle(own_gemm, own_dw, monkeypatch):
     """768 wide / 12 layers / 12 heads / 6 cross-attention layers, B = 8, 32 queries + 20 question tokens,
     256 scene tokens of width 256: the Q-Former the bench times, two-segment layout, against qformer_ref --
@@ -283,7 +283,8 @@ def test_full_size_qformer_forward_backward_matches_oracle(own_gemm, own_dw, mon
     from oracle import qformer_ref
     from situation3d_amd import qformer as qformer_mod
     from situation3d_amd.qformer import init_Qformer
-    monkeypatch.setattr(qformer_mod, "OWN_GEMM", own_gemm)
+    monkeypatch.setattr(qformer_mod, "OWN_GEMM", own_gemm != 0)      # 0: the library; 64: the default products; 127: all
+    monkeypatch.setattr(qformer_mod, "OWN_MASK", own_gemm if own_gemm else 127)
     monkeypatch.setattr(qformer_mod, "OWN_DW", own_dw)
     torch.manual_seed(61)
     qf, query_tokens = init_Qformer(32, 256)
