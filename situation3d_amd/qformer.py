@@ -117,21 +117,19 @@ def advance_dropout_seed(device):
         _lib.call("sig3d_counter_increment", _lib.ptr(c), _lib.stream_ptr(device))
 
 
-# The Q-Former's dense products on sig3d_gemm16 (csrc/gemm16_core.h: exact-f32 MFMA, bias / GELU / gelu' / residual-gradient
-# epilogues, split reductions whose slabs the LayerNorm tails add while loading), product by product (bit mask):
+# SIG3D_QF_GEMM=1: the Q-Former's dense products on sig3d_gemm16 (csrc/gemm16_core.h: exact-f32 MFMA, bias / GELU / gelu' /
+# residual-gradient epilogues, split reductions whose slabs the LayerNorm tails add while loading), product by product
+# (SIG3D_QF_GEMM_MASK, all by default):
 #   1 query/key/value, 2 attention output, 4 feed-forward up (+ GELU), 8 feed-forward down, 16 d(feed-forward up) (* gelu'),
 #   32 d(feed-forward down) + residual, 64 d(projections) + residual.
-# All of them are correct at every golden and full-size parity test and level with rocBLAS's default picks kernel by
-# kernel (tools/micro/gemm16_bench.hip).  INSIDE the training step (tools/ab_step.py, paired, +-0.003 ms, round 5):
-#   64 alone -0.090 ms against the tuned library (the input gradient of the fused query/key/value projection is a
-#   416 x 768 product over k = 2304 -- 168 library tiles with a long loop, 30.7 us; here the reduction is split over the
-#   chip and the block below adds the slabs in its LayerNorm-tail backward);
-#   1 -0.013, 2 -0.001, 4 -0.027, 8 -0.013, 16 -0.017, 32 +0.012 alone; 64 + any one of them -0.005 ... -0.036, 64 + 4 + 16
-#   +0.049, all but 32 +0.091, all +0.131: the wins do not add up (more slab traffic through the LayerNorm tails).
-# Default: product 64 on the own kernel, the rest on the vendor library (rocBLAS / hipBLASLt through torch);
-# SIG3D_QF_GEMM=0 puts everything on the library, SIG3D_QF_GEMM_MASK=127 everything on sig3d_gemm16.
-OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "1") != "0"
-OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "64"))
+# Correct at every golden and full-size parity test and level with rocBLAS's default picks kernel by kernel
+# (tools/micro/gemm16_bench.hip) -- but INSIDE the training step the tuned library is not beaten: all products +0.13 ms
+# (round 4: 7.85-7.98 against 8.18-8.28 ms), and no single product pays either (round 5, tools/ab_step.py with four step
+# objects per arm: product 64 alone +0.010 +- 0.009 ms; a first pass with ONE object per arm had shown -0.090 for it and
+# -0.03 ... +0.01 for the others -- the spread of two identical arms, as a null switch showed).  Default: the vendor
+# library (rocBLAS / hipBLASLt through torch); this switch is the A/B.
+OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
+OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
 # SIG3D_QF_GEMM_CONFIG: which core / tiling sig3d_gemm16 uses for those products: 0 its own choice among the f32 tilings,
 # 1-3 one of them, 11 / 12 the bf16 x 6 core (gemmx6_core.h: three-term bf16 split, six products, f32-equivalent)
 OWN_CONFIG = int(os.environ.get("SIG3D_QF_GEMM_CONFIG", "0"))

@@ -1,7 +1,13 @@
-"""Same-process A/B of the graphed training step: two GraphedTrainStep objects over ONE model / optimizer, built with a
+"""Same-process A/B of the graphed training step: GraphedTrainStep objects over ONE model / optimizer, built with a
 module-level switch at value A and at value B, replayed alternately (A B B A ...) in blocks of `--replays` steps timed
 with events.  Box-to-box spread (+-0.1 ms) and the warm-up drift of one box (8.05 -> 8.27 ms within a minute) cancel in
-the paired differences; effects of ~0.02 ms become visible.
+the paired differences.
+
+WHAT THE +- DOES NOT COVER (found late in round 5 with a null switch: `env:SIG3D_NULL_SWITCH 0 1` gave +0.077 +- 0.005 and
+-0.055 +- 0.002 ms for two IDENTICAL arms): every built step object has its own persistent offset of up to +-0.07 ms (where
+its buffers and queues landed), the same in every replay.  One build per arm therefore resolves ~0.1 ms, not 0.003.
+`--builds N` (default 3) builds N objects per arm, alternately, and reports the arm means with the standard error ACROSS
+builds; a difference counts when it exceeds that.  SIG3D_GEO_DEPTH (chains in flight) defaults to 3 as in bench.py.
 
 python tools/ab_step.py situation3d_amd.qformer.FUSED_EMBED False True [--rounds 24] [--replays 10]
 python tools/ab_step.py env:SIG3D_GEO_HANDSHAKE 0 1
@@ -25,6 +31,7 @@ ap.add_argument("switch", help="module.ATTRIBUTE, e.g. situation3d_amd.qformer.F
 ap.add_argument("a"); ap.add_argument("b")
 ap.add_argument("--rounds", type=int, default=24)
 ap.add_argument("--replays", type=int, default=10)
+ap.add_argument("--builds", type=int, default=3, help="step objects per arm (their spread is the real uncertainty)")
 args = ap.parse_args()
 if args.switch.startswith("env:"):        # an environment variable read when the step is BUILT (graph_step / geometry)
     class _Env:
@@ -44,11 +51,14 @@ opt = build_optimizer(model, name="flat_adamw")
 batches = [bench.synthetic_batch(bench.BATCH, bench.N_POINTS, 1234 + i, dev) for i in range(4)]
 work = torch.cuda.Stream(dev, priority=int(os.environ.get("AB_WORK_PRIORITY", "0")))   # -1: a high-priority queue
 steps = {}
+names = []
 with torch.cuda.stream(work):
-    for name, val in (("A", lit(args.a)), ("B", lit(args.b))):
-        setattr(mod, attr, val)
-        steps[name] = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True,
-                                       prefetch_depth=int(os.environ.get("SIG3D_GEO_DEPTH", "1")))
+    for i in range(args.builds):
+        for arm, val in (("A", lit(args.a)), ("B", lit(args.b))):
+            setattr(mod, attr, val)
+            steps[arm + str(i)] = GraphedTrainStep(model, opt, batches[0], prefetch_geometry=True,
+                                                   prefetch_depth=int(os.environ.get("SIG3D_GEO_DEPTH", "3")))
+            names.append(arm + str(i))
     k = [0]
 
     def block(name):
@@ -64,17 +74,19 @@ with torch.cuda.stream(work):
         e.synchronize()
         return s.elapsed_time(e) / args.replays
 
-    for name in "ABBA":
+    for name in names + names[::-1]:
         block(name)                             # warm-up
-    ta, tb = [], []
+    t = {n: [] for n in names}
     for r in range(args.rounds):
-        order = "ABBA" if r % 2 == 0 else "BAAB"
-        t = {"A": [], "B": []}
+        order = names + names[::-1] if r % 2 == 0 else names[::-1] + names
         for name in order:
             t[name].append(block(name))
-        ta.append(sum(t["A"]) / 2); tb.append(sum(t["B"]) / 2)
-diff = [b - a for a, b in zip(ta, tb)]
-sd = statistics.stdev(diff) / len(diff) ** 0.5
-print("%s: A=%s %.3f ms   B=%s %.3f ms   B - A = %+.3f ms +- %.3f (paired, %d rounds x 2 x %d replays)"
-      % (args.switch, args.a, statistics.mean(ta), args.b, statistics.mean(tb), statistics.mean(diff), sd, args.rounds,
-         args.replays))
+per = {n: statistics.mean(v) for n, v in t.items()}
+arm = {x: [per[n] for n in names if n[0] == x] for x in "AB"}
+mean = {x: statistics.mean(arm[x]) for x in "AB"}
+se = {x: (statistics.stdev(arm[x]) / len(arm[x]) ** 0.5 if len(arm[x]) > 1 else float("nan")) for x in "AB"}
+print("%s: A=%s %.3f ms [%s]   B=%s %.3f ms [%s]   B - A = %+.3f ms +- %.3f (standard error across %d builds per arm; "
+      "%d rounds x 2 x %d replays each)"
+      % (args.switch, args.a, mean["A"], " ".join("%.3f" % v for v in arm["A"]), args.b, mean["B"],
+         " ".join("%.3f" % v for v in arm["B"]), mean["B"] - mean["A"], (se["A"] ** 2 + se["B"] ** 2) ** 0.5, args.builds,
+         args.rounds, args.replays))
