@@ -751,8 +751,8 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
         // neither thinner over more CUs nor fatter on fewer beats 8 x 256 x 20 (tools/ab_step.py env:SIG3D_FPS_SHAPE).
         // Late round 5, the blocked form (fps_coop_kernel BLOCKED: waves own a compact block of the scene and sit out the
         // rounds that cannot change it): alone 1.72 us/round as before (the exchange bounds a round), beside the step
-        // -0.144 ms (7.673 -> 7.529, tools/ab_step.py env:SIG3D_FPS_SHAPE 8 3).  Blocked 8 x 512 x 10 (shape 9, blocks
-        // of half the size) +0.11 ms against it, 16 x 256 x 10 (10) +0.57, 4 x 512 x 20 (11) +0.12.
+        // -0.062 +- 0.008 ms (tools/ab_step.py env:SIG3D_FPS_SHAPE 8 3 --builds 4).  Blocked 8 x 512 x 10 (shape 9, blocks
+        // of half the size) level with it (+0.018 +- 0.025), 16 x 256 x 10 (10) +0.57, 4 x 512 x 20 (11) +0.12.
         const char *shape = getenv("SIG3D_FPS_SHAPE");
         const int sh = shape ? atoi(shape) : 3;
         if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);
