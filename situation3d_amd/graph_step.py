@@ -118,7 +118,7 @@ class GraphedTrainStep:
                 optimizer.process_group = reducer.group   # liveness agreed on the reducer's group from the first gather on
         self.prefetch = bool(prefetch_geometry)
         # Where the geometry chains run.  Default: geometry.GeometryPipeline -- the chains of the next
-        # `prefetch_depth` batches (default 1; bench.py runs 2) as graphs of their own on streams of their own, beside
+        # `prefetch_depth` batches (default 1; bench.py runs 3) as graphs of their own on streams of their own, beside
         # the step's graph, which stays ONE linear chain.  SIG3D_GEO_FORK=inline (single GPU only): rounds 1-2's
         # branch forked inside the step's graph and joined at its end -- every kernel node enqueued while another
         # queue holds a blocked barrier costs ~1.7 us extra on this runtime (tools/probes/fork_penalty.py).

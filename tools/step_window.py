@@ -34,3 +34,8 @@ if "--gaps" in sys.argv:
     print("main queue %s: idle between launches %.3f ms; largest gaps:" % (main, sum(g[0] for g in gaps if g[0] > 0) / 1e3))
     for g in sorted(gaps, reverse=True)[:15]:
         print("   %8.1f us  %s -> %s" % g)
+if "--sequence" in sys.argv:
+    print("launch order (us since the previous AdamW's end, duration, name):")
+    for r in rows[a + 1:b + 1]:
+        print("   %9.1f %7.1f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                      r["Kernel_Name"][:110]))
