@@ -23,7 +23,7 @@
 #include "sig3d_common.h"
 
 #ifndef SIG3D_FPS_PROBE
-#define SIG3D_FPS_PROBE 0   // measurement builds only (wrong results): 1 = the cooperative kernel sweeps half of a thread's points per round
+#define SIG3D_FPS_PROBE 0   // measurement builds only: 1 = the cooperative kernel sweeps half of a thread's points per round (wrong results); 2 = it claims 256 VGPRs a lane (same results)
 #endif
 
 namespace {
@@ -367,9 +367,15 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   __shared__ int s_val[2][NW];
   __shared__ unsigned s_key[2][NW];
   __shared__ int s_win[2][2];
+  // BLOCKED: the tie keys of a thread's points live here, not in 20 registers -- what the kernel holds of a SIMD's
+  // register file is what library kernels beside it cannot use (claiming 256 VGPRs instead of 150 cost the step 0.12 ms)
+  __shared__ unsigned s_pkey[BLOCKED ? PPT : 1][BLOCKED ? NT : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scene = blockIdx.x % b, w = blockIdx.x / b;
+#if SIG3D_FPS_PROBE == 2
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
   const float *dataset = dataset_all + (size_t)scene * n * 3;
   int *idxs = idxs_all + (size_t)scene * m;
   gu64 *slots = (gu64 *)(slots_all + (size_t)scene * FPS_SLOT_U64);
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   constexpr int G = NT * W / 512;
   const int g_id = w * NT + tid, r_slot = g_id & 511, grp = g_id >> 9;
   float px[PPT], py[PPT], pz[PPT], pt[PPT];
-  unsigned pkey[BLOCKED ? PPT : 1];
   if (BLOCKED) {
+    unsigned pkey[PPT];
     // wave number wb of the scene's W * NW takes positions [wb * per, (wb + 1) * per) of the Morton order.  A thread's
     // strict `>` sweep picks its lowest slot among equal distances, so it keeps its points in key order: the keys are
     // sorted (odd-even transposition, a min and a max per exchange) before the coordinates are fetched
@@ -402,11 +408,16 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
         pkey[s] = min(ka, kb); pkey[s + 1] = max(ka, kb);
       }
     }
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) s_pkey[s][tid] = pkey[s];      // (read back by this thread only: no barrier)
   }
 #pragma unroll
   for (int s = 0; s < PPT; ++s) {
     int k = r_slot + 512 * (s * G + grp);
-    if (BLOCKED) k = pkey[s] == 0xFFFFFFFFu ? n : (int)fps_unkey(pkey[s], L);
+    if (BLOCKED) {
+      const unsigned key = s_pkey[s][tid];
+      k = key == 0xFFFFFFFFu ? n : (int)fps_unkey(key, L);
+    }
     float x = 0.f, y = 0.f, z = 0.f, t = -1.f;
     if (k < n) {
       x = dataset[3 * k + 0];
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
       ax = fminf(ax, __shfl_xor(ax, o)); ay = fminf(ay, __shfl_xor(ay, o)); az = fminf(az, __shfl_xor(az, o));
       bx = fmaxf(bx, __shfl_xor(bx, o)); by = fmaxf(by, __shfl_xor(by, o)); bz = fmaxf(bz, __shfl_xor(bz, o));
     }
-    lo_x = ax; lo_y = ay; lo_z = az; hi_x = bx; hi_y = by; hi_z = bz;
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    lo_x = uniform(ax); lo_y = uniform(ay); lo_z = uniform(az); hi_x = uniform(bx); hi_y = uniform(by); hi_z = uniform(bz);
   }
   int held_v = 0x7F800000;   // the wave's candidate of its last sweep (+inf: the first round always sweeps)
   unsigned held_k = 0xFFFFFFFFu;
@@ -457,7 +469,6 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
     if (!sit_out) {
       float best = -1.f;
       int bslot = 0;
-      unsigned bkey = BLOCKED ? pkey[0] : 0u;
 #pragma unroll
       for (int s = 0; s < (SIG3D_FPS_PROBE == 1 ? PPT / 2 : PPT); ++s) {
         const float d = sq_dist3(px[s], py[s], pz[s], x1, y1, z1);
@@ -465,12 +476,11 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
         pt[s] = t;
         const bool gt = t > best;
         best = gt ? t : best;
-        if (BLOCKED) bkey = gt ? pkey[s] : bkey;
-        else bslot = gt ? s : bslot;
+        bslot = gt ? s : bslot;
       }
       const int myv = __builtin_bit_cast(int, best);
       wv = wave_allreduce_max_i32(myv);
-      if (!BLOCKED) bkey = fps_key((unsigned)(r_slot + 512 * (bslot * G + grp)), L, bsmask);
+      const unsigned bkey = BLOCKED ? s_pkey[bslot][tid] : fps_key((unsigned)(r_slot + 512 * (bslot * G + grp)), L, bsmask);
       wk = wave_allreduce_min_u32((myv == wv) ? bkey : 0xFFFFFFFFu);
       held_v = wv; held_k = wk;
     } else {
