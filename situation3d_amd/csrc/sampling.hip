@@ -23,7 +23,7 @@
 #include "sig3d_common.h"
 
 #ifndef SIG3D_FPS_PROBE
-#define SIG3D_FPS_PROBE 0   // measurement builds only: 1 = the cooperative kernel sweeps half of a thread's points per round (wrong results); 2 = it claims 256 VGPRs a lane (same results)
+#define SIG3D_FPS_PROBE 0   // measurement builds only: 1 = the cooperative kernel sweeps half of a thread's points per round (wrong results); 2 = it claims 256 VGPRs a lane (same results); 3 = a round's sample coordinates are made up instead of loaded (wrong results; 3.49 -> 3.34 ms alone: the dependent load is 0.08 of a 1.72 us round)
 #endif
 
 namespace {
@@ -453,7 +453,11 @@ __global__ __launch_bounds__(NT) void fps_coop_kernel(int b, int n, int m, int L
   bool dead = false;
 
   for (int j = 1; j < m; ++j) {
+#if SIG3D_FPS_PROBE == 3
+    const float x1 = 0.5f + 1e-3f * (float)(old & 1023), y1 = 0.25f, z1 = 0.125f;   // no dependent load (wrong results)
+#else
     const float x1 = dataset[3 * old + 0], y1 = dataset[3 * old + 1], z1 = dataset[3 * old + 2];
+#endif
     int wv;
     unsigned wk;
     bool sit_out = false;
