@@ -657,6 +657,7 @@ int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *tem
   SIG3D_HIP_TRY(hipMemsetAsync(temp, 0, sizeof(u64) * (size_t)b * FPS_SLOT_U64, stream));
   unsigned short *order = nullptr;
   if (BLOCKED) {
+    SIG3D_REQUIRE(n >= 512 && n <= 65535, "the blocked cooperative FPS numbers a scene's points in 16 bits (512 <= n <= 65535)");
     order = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(temp) + sizeof(u64) * (size_t)b * FPS_SLOT_U64);
     hipLaunchKernelGGL(fps_morton_order_kernel, dim3(b), dim3(1024), 0, stream, n, dataset, order);
     SIG3D_LAUNCH_CHECK("fps_morton_order_kernel");
