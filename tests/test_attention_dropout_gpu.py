@@ -17,22 +17,32 @@ def _tm(t):  # (b,h,n,d) -> token-major (b,n,h*d)
     return t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], -1).contiguous()
 
 
-@pytest.mark.parametrize("nq", [40, 32, 20])   # <= 32 queries: the register-resident backward path
-def test_attention_dropout_matches_torch_with_recovered_mask(nq):
+@pytest.mark.parametrize("nq,nk", [(40, 64), (32, 64), (20, 64),     # <= 64 x 64: the small-problem backward's 2 x 2 form
+                                   (32, 256), (20, 200),              # 32 x <= 1024: its one-query-block form
+                                   (40, 200)])                        # neither: the generic backward
+def test_attention_dropout_matches_torch_with_recovered_mask(nq, nk):
     from situation3d_amd.qformer import fused_attention
-    b, h, nk, p = 2, 3, 64, 0.25
+    b, h, p = 2, 3, 0.25
     g = torch.Generator().manual_seed(0)
     q = torch.randn(b, h, nq, 64, generator=g).to(DEV)
     k = torch.randn(b, h, nk, 64, generator=g).to(DEV)
-    eye = torch.eye(64, device=DEV).expand(b, h, nk, 64).contiguous()
-    probe = fused_attention(_tm(q), _tm(k), _tm(eye), None, h, p, call_id=11)  # (b,nq,h*64)
-    keep = (probe.view(b, nq, h, 64).permute(0, 2, 1, 3) > 0)                # (b,h,nq,nk)
+
+    def probe_mask(call_id):      # V = 64 keys' worth of identity at a time: out[q][j] = keep * P / (1 - p) of key 64 c + j
+        cols = []
+        for c in range((nk + 63) // 64):
+            sel = torch.zeros(nk, 64, device=DEV)
+            n_here = min(64, nk - 64 * c)
+            sel[64 * c + torch.arange(n_here, device=DEV), torch.arange(n_here, device=DEV)] = 1.0
+            o = fused_attention(_tm(q), _tm(k), _tm(sel.expand(b, h, nk, 64).contiguous()), None, h, p, call_id=call_id)
+            cols.append(o.view(b, nq, h, 64).permute(0, 2, 1, 3)[..., :n_here])
+        return torch.cat(cols, -1)                                            # (b,h,nq,nk)
+
+    probe = probe_mask(11)
+    keep = probe > 0
     rate = 1.0 - keep.float().mean().item()
     assert abs(rate - p) < 4 * math.sqrt(p * (1 - p) / keep.numel()), rate
-    again = fused_attention(_tm(q), _tm(k), _tm(eye), None, h, p, call_id=11)
-    assert torch.equal(probe, again)                                          # fixed seed: same mask
-    other = fused_attention(_tm(q), _tm(k), _tm(eye), None, h, p, call_id=12)
-    assert not torch.equal(probe > 0, other > 0)                              # per-module streams
+    assert torch.equal(probe, probe_mask(11))                                 # fixed seed: same mask
+    assert not torch.equal(keep, probe_mask(12) > 0)                          # per-module streams
 
     v = torch.randn(b, h, nk, 64, generator=g).to(DEV)
     go = torch.randn(b, nq, h * 64, generator=g).to(DEV)

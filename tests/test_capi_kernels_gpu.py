@@ -87,9 +87,14 @@ def _attn_ref(q, k, v, mask, scale):
                                                 (2, 2, 256, 256, True), (1, 2, 300, 48, False), (1, 1, 129, 129, True),
                                                 (1, 2, 20, 700, True), (3, 1, 32, 1000, True), (1, 1, 7, 97, False)])
 @pytest.mark.parametrize("D", [64, 96])
-def test_attention_fwd_bwd(b, h, nq, nk, use_mask, D):
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_attention_fwd_bwd(b, h, nq, nk, use_mask, D, small, monkeypatch):
     """Head sizes 64 (Q-Former) and 96 (MCAN blocks); more than 128 query rows run the backward in query
-    chunks with atomic dK / dV."""
+    chunks with atomic dK / dV.  small: the small-problem backward (eight waves per (batch, head), everything in LDS:
+    <= 64 x 64 and 32 x <= 1024, head size 64) or the generic backward for every shape."""
+    if small == "0" and (D != 64 or (nq > 64 and nk > 64)):
+        pytest.skip("no small-problem kernel for this shape: same launches as small=1")
+    monkeypatch.setenv("SIG3D_ATTN_BWD_SMALL", small)
     L = _lib()
     g = torch.Generator().manual_seed(nq * 131 + nk + D)
     q = torch.randn(b, h, nq, D, generator=g)
@@ -192,9 +197,11 @@ def _to_segments(t, seg, base2=None, rows=None, fill=0.0):
 
 @pytest.mark.parametrize("b,h,n,seg,pad", [(8, 12, 52, 32, 0), (3, 2, 40, 1, 0), (2, 4, 33, 32, 0), (2, 1, 7, 7, 0),
                                            (8, 12, 52, 32, 96), (2, 3, 40, 10, 5)])
-def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad):
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_attention_two_segment_layout_matches_plain(b, h, n, seg, pad, small, monkeypatch):
     """q_seg / k_seg only re-map token -> storage row: results must equal the plain-layout call
-    bit for bit after un-permuting the rows (same arithmetic, same order)."""
+    bit for bit after un-permuting the rows (same arithmetic, same order); small-problem and generic backward."""
+    monkeypatch.setenv("SIG3D_ATTN_BWD_SMALL", small)
     L = _lib()
     g = torch.Generator().manual_seed(n * 7 + seg)
     ld = h * 64

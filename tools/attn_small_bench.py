@@ -1,6 +1,9 @@
-"""sig3d_attention_bwd at the two small shapes of the SQA3D step (B = 8, 12 heads of 64): the 52 x 52 self-attention in
+"""sig3d_attention_fwd / sig3d_attention_bwd at the two small shapes of the SQA3D step (B = 8, 12 heads of 64): the 52 x 52 self-attention in
 the two-segment layout over a fused q / k / v projection, and the 32 x 256 cross-attention.  hipGraph-timed.
-SIG3D_ATTN_BWD_SMALL=0 python tools/attn_small_bench.py   -> the generic kernel;  =1 (default) the small-problem kernel."""
+SIG3D_ATTN_BWD_SMALL=0 python tools/attn_small_bench.py   -> the generic backward;  =1 (default) the small-problem kernel.
+(Forward, streaming kernel: 6.3 / 10.4 us.  A small-problem forward of the same build as the backward -- Q and K in LDS, the
+blocks of S on eight waves, whole-row softmax in LDS, P V over key slices -- was written and measured in round 5: 6.7 / 10.2 us,
+nothing gained, not kept.)"""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -60,7 +63,13 @@ def case(name, nq, nk, seg, self_attn, p_drop):
                base2 if self_attn else b * nq, base2 if self_attn else b * nk, live, live, ldq, ldk, ldv,
                ctypes.c_float(0.125), P(qp), P(kp), P(vp), P(0), L.ptr(out), L.ptr(lse), L.ptr(go), P(dqp), P(dkp), P(dvp),
                ctypes.c_float(p_drop), ctypes.c_uint(7), L.ptr(ctr), L.stream_ptr(dev))
-    print("%-44s %6.1f us" % (name + " p_drop %.1f" % p_drop, graph_time(bwd)))
+    def fwd():
+        L.call("sig3d_attention_fwd", b, h, nq, nk, d, seg, kseg, base2 if self_attn else b * nq,
+               base2 if self_attn else b * nk, live, live, ldq, ldk, ldv, ctypes.c_float(0.125), P(qp), P(kp), P(vp), P(0),
+               L.ptr(out), L.ptr(lse), ctypes.c_float(p_drop), ctypes.c_uint(7), L.ptr(ctr), 1, P(0), L.stream_ptr(dev))
+    t_f = graph_time(fwd)
+    lse.copy_(torch.randn(b, h, nq, device=dev) + 4)
+    print("%-44s forward %6.1f us   backward %6.1f us" % (name + " p_drop %.1f" % p_drop, t_f, graph_time(bwd)))
 
 
 for p in (0.0, 0.1):
