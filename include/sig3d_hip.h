@@ -332,6 +332,16 @@ int sig3d_pos_embed_add(int b, int n, int c, int tw, int trows, float scale, con
  * row-major, out (parts, cols); parts > 1 serves a batched (strided) pair of layers in one launch.
  * Deterministic (no atomics). */
 int sig3d_column_sum(int parts, int rows, int cols, const float *x, float *out, void *stream);
+/* Up to SIG3D_COLUMN_SUM_MAX_JOBS such sums in ONE launch (the weight-gradient flush of the Q-Former: the bias gradients
+ * torch takes as `grad.sum(0)` per nn.Linear, Qformer.py:116-118, :238, :305, :320, and the folds of the LayerNorm
+ * tails' partial rows): job j sums x (parts, rows, cols) over its rows into out (parts, cols). */
+#define SIG3D_COLUMN_SUM_MAX_JOBS 8
+typedef struct sig3d_column_sum_job {
+  const float *x;
+  float *out;
+  int parts, rows, cols, pad;
+} sig3d_column_sum_job;
+int sig3d_column_sum_multi(int njobs, const sig3d_column_sum_job *jobs, void *stream);
 
 /* BertIntermediate's bias + erf-GELU (Qformer.py:311-313) on the GEMM output WITHOUT bias:
  *   gy == NULL: out = gelu(x + bias)            gy != NULL: out = gy * gelu'(x + bias)

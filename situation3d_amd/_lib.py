@@ -120,6 +120,27 @@ SIGNATURES = {
 }
 
 
+class ColumnSumJob(ctypes.Structure):
+    """struct sig3d_column_sum_job of include/sig3d_hip.h."""
+    _fields_ = [("x", _P), ("out", _P), ("parts", _I), ("rows", _I), ("cols", _I), ("pad", _I)]
+
+
+COLUMN_SUM_MAX_JOBS = 8
+SIGNATURES["sig3d_column_sum_multi"] = [_I, ctypes.POINTER(ColumnSumJob), _P]
+
+
+def column_sum_multi(device, jobs):
+    """jobs: (x2, parts, out) triples -- column sums of contiguous (parts * rows, cols) matrices into (parts, cols) / (cols,)
+    outputs, COLUMN_SUM_MAX_JOBS per launch."""
+    for i in range(0, len(jobs), COLUMN_SUM_MAX_JOBS):
+        chunk = jobs[i:i + COLUMN_SUM_MAX_JOBS]
+        arr = (ColumnSumJob * len(chunk))()
+        for a, (x2, parts, out) in zip(arr, chunk):
+            a.x, a.out, a.parts, a.rows, a.cols = x2.data_ptr(), out.data_ptr(), parts, x2.shape[0] // parts, x2.shape[1]
+        with torch.cuda.device(device):
+            call("sig3d_column_sum_multi", len(chunk), arr, stream_ptr(device))
+
+
 class Gemm16Problem(ctypes.Structure):
     """struct sig3d_gemm16_problem of include/sig3d_hip.h (field order and types must match)."""
     _fields_ = [("A", _P), ("lda", _I), ("stride_a", ctypes.c_long),

@@ -468,6 +468,70 @@ extern "C" int sig3d_bias_gelu(int rows, int cols, int part_rows, const float *x
   return 0;
 }
 
+// several column sums in ONE launch: the weight-gradient flush of the Q-Former folds seven kinds of partial rows
+// (bias gradients of the projections and the feed-forward pair, the LayerNorm tails' [d gamma | d beta | d bias])
+// whose launches were 4-14 us each for 0.1-5 MB.  Same arithmetic and order per job as column_sum_kernel.
+struct ColumnSumJobs {
+  sig3d_column_sum_job job[SIG3D_COLUMN_SUM_MAX_JOBS];
+  int first_block[SIG3D_COLUMN_SUM_MAX_JOBS + 1];     // job j owns workgroups [first_block[j], first_block[j + 1])
+  int njobs;
+};
+
+__global__ __launch_bounds__(CS_WAVES * 64) void column_sum_multi_kernel(ColumnSumJobs js) {
+  __shared__ float part[CS_WAVES][64];
+  int j = 0;
+  while (j + 1 < js.njobs && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
+  const sig3d_column_sum_job q = js.job[j];
+  const int local = (int)blockIdx.x - js.first_block[j], cblocks = (q.cols + 63) / 64;
+  const int pi = local / cblocks, cb = local - pi * cblocks;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int c = cb * 64 + lane;
+  const float *x = q.x + (size_t)pi * q.rows * q.cols;
+  float *out = q.out + (size_t)pi * q.cols;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  if (c < q.cols) {
+    int r = wave;
+    for (; r + 7 * CS_WAVES < q.rows; r += 8 * CS_WAVES) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += x[(size_t)(r + i * CS_WAVES) * q.cols + c];
+    }
+    for (; r < q.rows; r += CS_WAVES) acc[0] += x[(size_t)r * q.cols + c];
+  }
+  part[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && c < q.cols) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < CS_WAVES; ++w) s2 += part[w][lane];
+    out[c] = s2;
+  }
+}
+
+extern "C" int sig3d_column_sum_multi(int njobs, const sig3d_column_sum_job *jobs, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(njobs >= 0 && njobs <= SIG3D_COLUMN_SUM_MAX_JOBS, "at most SIG3D_COLUMN_SUM_MAX_JOBS jobs per launch");
+  SIG3D_REQUIRE(njobs == 0 || jobs != nullptr, "null job list");
+  ColumnSumJobs js = {};
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const sig3d_column_sum_job &q = jobs[j];
+    SIG3D_REQUIRE(q.parts >= 1 && q.rows >= 0 && q.cols >= 0, "negative size");
+    if (q.cols == 0) continue;
+    SIG3D_REQUIRE(q.out != nullptr && (q.rows == 0 || q.x != nullptr), "null operand");
+    js.job[js.njobs] = q;
+    js.first_block[js.njobs] = blocks;
+    blocks += sig3d_ceil_div(q.cols, 64) * q.parts;
+    ++js.njobs;
+  }
+  js.first_block[js.njobs] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(column_sum_multi_kernel, dim3(blocks), dim3(CS_WAVES * 64), 0, stream, js);
+  SIG3D_LAUNCH_CHECK("column_sum_multi_kernel");
+  return 0;
+}
+
 extern "C" int sig3d_column_sum(int parts, int rows, int cols, const float *x, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(parts >= 1 && rows >= 0 && cols >= 0, "negative size");

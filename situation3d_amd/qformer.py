@@ -135,6 +135,10 @@ OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
 OWN_CONFIG = int(os.environ.get("SIG3D_QF_GEMM_CONFIG", "0"))
 
 
+# the flush's column sums (bias gradients, LayerNorm-tail folds) as one launch (sig3d_column_sum_multi) or one per kind
+COLSUM_MULTI = os.environ.get("SIG3D_QF_COLSUM_MULTI", "1") != "0"
+
+
 # SIG3D_QF_DW: the layer-batched weight-gradient products dW = dY^T X of _WeightGradArena.flush() on sig3d_gemmp
 # (csrc/gemmp_core.h: the f32 product as six bf16 products over operands split ONCE into chunked bf16 planes, both
 # operands read through the LDS transposing read, 128 x 128 tiles) instead of torch.bmm (rocBLAS / hipBLASLt).
@@ -877,16 +881,17 @@ class _WeightGradArena:
                       out=self.gw2[lo:hi].view(2 * n, H, I))
             torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
                       out=self.gw1[lo:hi].view(2 * n, I, H))
-        _colsum(self.gpre[lo:hi].view(2 * n * P, I), parts=2 * n, out=self.gb1[lo:hi])
         # self-attention
         if not own:
             torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
             torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
-        _colsum(self.dproj[lo:hi].view(n * L, 3 * H), parts=n, out=self.gbqkv[lo:hi])
-        # LayerNorm tails: (layer, part) x blocks-per-part partial rows -> [d gamma | d beta | d bias]
+        # bias gradients, and the LayerNorm tails' (layer, part) x blocks-per-part partial rows -> [d gamma | d beta |
+        # d bias]: ONE launch for all kinds (sig3d_column_sum_multi; seven launches of 4-14 us before)
         bf, ba = self.ln_blocks_ffn, self.ln_blocks_attn
-        _colsum(self.ln_work_ffn[lo:hi].view(n * bf, 3 * H), parts=2 * n, out=self.ln_ffn[lo:hi].view(2 * n, 3 * H))
-        _colsum(self.ln_work_attn[lo:hi].view(n * ba, 3 * H), parts=n, out=self.ln_attn[lo:hi].view(n, 3 * H))
+        sums = [(self.gpre[lo:hi].view(2 * n * P, I), 2 * n, self.gb1[lo:hi]),
+                (self.dproj[lo:hi].view(n * L, 3 * H), n, self.gbqkv[lo:hi]),
+                (self.ln_work_ffn[lo:hi].view(n * bf, 3 * H), 2 * n, self.ln_ffn[lo:hi].view(2 * n, 3 * H)),
+                (self.ln_work_attn[lo:hi].view(n * ba, 3 * H), n, self.ln_attn[lo:hi].view(n, 3 * H))]
         # cross-attention layers inside the range
         if js:
             j0, j1 = js[0], js[-1] + 1
@@ -894,15 +899,20 @@ class _WeightGradArena:
             if not own:
                 torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
                 torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
-            _colsum(self.dq_x[j0:j1].view(m * rq, H), parts=m, out=self.gbq_x[j0:j1])
-            _colsum(self.ln_work_x[j0:j1].view(m * ba, 3 * H), parts=m, out=self.ln_x[j0:j1].view(m, 3 * H))
+            sums.append((self.dq_x[j0:j1].view(m * rq, H), m, self.gbq_x[j0:j1]))
+            sums.append((self.ln_work_x[j0:j1].view(m * ba, 3 * H), m, self.ln_x[j0:j1].view(m, 3 * H)))
             cols = slice(j0 * 2 * H, j1 * 2 * H)
             if not own:
                 torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
             if m == len(self.cross):
-                _colsum(self.dkv, out=self.gbkv)
+                sums.append((self.dkv, 1, self.gbkv))
             else:
                 torch.sum(self.dkv[:, cols], dim=0, out=self.gbkv[cols])
+        if COLSUM_MULTI:
+            _lib.column_sum_multi(self.gb1.device, sums)
+        else:
+            for x2, parts, out in sums:
+                _colsum(x2, parts=parts, out=out)
 
 
 class _AttentionBlockFn(torch.autograd.Function):

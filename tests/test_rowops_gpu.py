@@ -174,3 +174,26 @@ def test_tails_add_the_slabs_of_a_split_dense_layer(p_drop, rows, live, part_row
     torch.testing.assert_close(dx_b, dx_a, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(dres_b, dres_a, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(dp_b, dp_a, rtol=2e-5, atol=2e-4)
+
+
+def test_column_sum_multi_matches_the_single_launches():
+    """sig3d_column_sum_multi: the Q-Former flush's seven kinds of column sums in one launch -- bit for bit what
+    sig3d_column_sum gives job by job (same order of additions), ragged column counts and more jobs than one launch holds."""
+    import ctypes
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    shapes = [(24, 256, 3072), (12, 416, 2304), (24, 4, 2304), (12, 7, 2304), (6, 256, 768), (6, 7, 2304), (1, 2048, 9216),
+              (3, 5, 70), (1, 1, 1), (2, 33, 65), (1, 0, 17)]
+    jobs, ref = [], []
+    for parts, rows, cols in shapes:
+        x = torch.randn(parts * rows, cols, generator=g).to(DEV)
+        out = torch.full((parts, cols), float("nan"), device=DEV)
+        one = torch.empty(parts, cols, device=DEV)
+        L.call("sig3d_column_sum", parts, rows, cols, L.ptr(x), L.ptr(one), L.stream_ptr(torch.device(DEV)))
+        jobs.append((x, parts, out))
+        ref.append(one)
+    L.column_sum_multi(torch.device(DEV), [j for j in jobs if j[0].shape[0] > 0 or True])
+    for (x, parts, out), one, shp in zip(jobs, ref, shapes):
+        assert torch.equal(out, one), shp
+        if shp[1] > 0:
+            torch.testing.assert_close(out.double(), x.view(parts, shp[1], shp[2]).double().sum(1), rtol=1e-5, atol=1e-4)
