@@ -667,6 +667,20 @@ int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY,
                               const float *pscale, const float *pshift, const int *n_act, float *dW,
                               float *work, void *stream);
 long sig3d_mlp_layer_dw_stream_work_floats(int b, int cin, int cout, long e);
+/* The same product without its fold -- dW holds the first slab, `work` the others (work_floats / roundup4(cout * cin) of
+ * them, roundup4(cout * cin) floats apart) -- and the fold of several such results in ONE launch: dst[0 .. n) += the sum
+ * of nslabs slabs, slab_stride floats apart, added in the order sig3d_mlp_layer_dw_stream adds them. */
+int sig3d_mlp_layer_dw_stream_nofold(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                     const float *pscale, const float *pshift, const int *n_act, float *dW,
+                                     float *work, void *stream);
+#define SIG3D_SUM_SLABS_MAX_JOBS 8
+typedef struct sig3d_sum_slabs_job {
+  float *dst;
+  const float *slabs;
+  long n, slab_stride;
+  int nslabs, pad;
+} sig3d_sum_slabs_job;
+int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, void *stream);
 
 /* ---- the two MLP heads on the pooled Q-Former output (csrc/heads.hip) ----------------------------------------
  * situation3d/models/sqa_module.py: the fused query tokens are averaged per sample and feed

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sig3d_mlp_layer0_scatter_dx_w": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_dx": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_dw_stream": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer_dw_stream_nofold": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
     "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],
@@ -139,6 +140,27 @@ def column_sum_multi(device, jobs):
             a.x, a.out, a.parts, a.rows, a.cols = x2.data_ptr(), out.data_ptr(), parts, x2.shape[0] // parts, x2.shape[1]
         with torch.cuda.device(device):
             call("sig3d_column_sum_multi", len(chunk), arr, stream_ptr(device))
+
+
+class SumSlabsJob(ctypes.Structure):
+    """struct sig3d_sum_slabs_job of include/sig3d_hip.h."""
+    _fields_ = [("dst", _P), ("slabs", _P), ("n", ctypes.c_long), ("slab_stride", ctypes.c_long), ("nslabs", _I), ("pad", _I)]
+
+
+SUM_SLABS_MAX_JOBS = 8
+SIGNATURES["sig3d_sum_slabs_multi"] = [_I, ctypes.POINTER(SumSlabsJob), _P]
+
+
+def sum_slabs_multi(device, jobs):
+    """jobs: (dst, work, n, slab_stride, nslabs): dst[:n] += the nslabs slabs of `work`; SUM_SLABS_MAX_JOBS per launch."""
+    jobs = [j for j in jobs if j[4] > 0]
+    for i in range(0, len(jobs), SUM_SLABS_MAX_JOBS):
+        chunk = jobs[i:i + SUM_SLABS_MAX_JOBS]
+        arr = (SumSlabsJob * len(chunk))()
+        for a, (dst, work, n, stride, nslabs) in zip(arr, chunk):
+            a.dst, a.slabs, a.n, a.slab_stride, a.nslabs = dst.data_ptr(), work.data_ptr(), n, stride, nslabs
+        with torch.cuda.device(device):
+            call("sig3d_sum_slabs_multi", len(chunk), arr, stream_ptr(device))
 
 
 class Gemm16Problem(ctypes.Structure):

@@ -108,9 +108,8 @@ extern "C" long sig3d_mlp_layer_dw_stream_work_floats(int b, int cin, int cout, 
   return (pairs > 1 ? pairs - 1 : 0) * (((long)cout * cin + 3) / 4 * 4);
 }
 
-extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY, const float *x,
-                                         const float *pscale, const float *pshift, const int *n_act, float *dW,
-                                         float *work, void *stream_) {
+static int dw_stream_impl(int b, int cin, int cout, long e, const float *dY, const float *x, const float *pscale,
+                          const float *pshift, const int *n_act, float *dW, float *work, bool fold, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0 && e % 4 == 0, "bad size (rows of 16-byte multiples)");
   SIG3D_REQUIRE((pscale == nullptr) == (pshift == nullptr), "pscale/pshift must come together");
@@ -137,13 +136,90 @@ extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const
   hipError_t err = dw_narrow_tiles(cin) ? gemm16::launch<1, 3, 4, 1, 4, 3, true>(p, gemm16::B_KC, stream)
                                         : gemm16::launch<1, 2, 4, 2, 4, 2, true>(p, gemm16::B_KC, stream);
   if (err != hipSuccess) { sig3d_set_error("gemm16_kernel (weight gradient)", err); return (int)err; }
-  if (pairs > 1) {
+  if (pairs > 1 && fold) {
     SIG3D_REQUIRE(((size_t)dW & 15) == 0 && ((long)cout * cin) % 4 == 0, "dW: 16-byte aligned, cout * cin a multiple of 4");
     const int n4 = (int)((long)cout * cin / 4);
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(sig3d_ceil_div(n4, 64)), dim3(256), 0, stream, n4, (int)(pairs - 1),
                        (size_t)(slab / 4), reinterpret_cast<float4 *>(dW), reinterpret_cast<const float4 *>(work));
     SIG3D_LAUNCH_CHECK("sum_slabs_kernel");
   }
+  return 0;
+}
+
+extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                         const float *pscale, const float *pshift, const int *n_act, float *dW,
+                                         float *work, void *stream_) {
+  return dw_stream_impl(b, cin, cout, e, dY, x, pscale, pshift, n_act, dW, work, true, stream_);
+}
+
+// The same product WITHOUT the fold: dW holds slab 0, `work` the others; the caller folds the layers of a level with one
+// sig3d_sum_slabs_multi launch (a fold per layer was 11 launches of ~5 us per training step).
+extern "C" int sig3d_mlp_layer_dw_stream_nofold(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                                const float *pscale, const float *pshift, const int *n_act,
+                                                float *dW, float *work, void *stream_) {
+  return dw_stream_impl(b, cin, cout, e, dY, x, pscale, pshift, n_act, dW, work, false, stream_);
+}
+
+namespace {
+struct SumSlabsJobs {
+  sig3d_sum_slabs_job job[SIG3D_SUM_SLABS_MAX_JOBS];
+  int first_block[SIG3D_SUM_SLABS_MAX_JOBS + 1];
+  int njobs;
+};
+
+// sum_slabs_kernel for several (dst, slabs) pairs: same columns per workgroup, same order of additions per job
+__global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SumSlabsJobs js) {
+  __shared__ float4 s_part[4][64];
+  int j = 0;
+  while (j + 1 < js.njobs && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
+  const sig3d_sum_slabs_job q = js.job[j];
+  const int n4 = (int)(q.n / 4), nslabs = q.nslabs;
+  const size_t slab4 = (size_t)(q.slab_stride / 4);
+  float4 *dst = reinterpret_cast<float4 *>(q.dst);
+  const float4 *slabs = reinterpret_cast<const float4 *>(q.slabs);
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int blk = (int)blockIdx.x - js.first_block[j];
+  const int i = min(blk * 64 + c, n4 - 1);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = g; s0 < nslabs; s0 += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)min(s0 + 4 * u, nslabs - 1) * slab4 + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + 4 * u < nslabs) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  }
+  s_part[g][c] = a;
+  __syncthreads();
+  if (g == 0 && blk * 64 + c < n4) {
+    const float4 d = dst[i], p0 = s_part[0][c], p1 = s_part[1][c], p2 = s_part[2][c], p3 = s_part[3][c];
+    dst[i] = make_float4(d.x + ((p0.x + p1.x) + (p2.x + p3.x)), d.y + ((p0.y + p1.y) + (p2.y + p3.y)),
+                         d.z + ((p0.z + p1.z) + (p2.z + p3.z)), d.w + ((p0.w + p1.w) + (p2.w + p3.w)));
+  }
+}
+}  // namespace
+
+extern "C" int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(njobs >= 0 && njobs <= SIG3D_SUM_SLABS_MAX_JOBS, "at most SIG3D_SUM_SLABS_MAX_JOBS jobs per launch");
+  SIG3D_REQUIRE(njobs == 0 || jobs != nullptr, "null job list");
+  SumSlabsJobs js = {};
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const sig3d_sum_slabs_job &q = jobs[j];
+    SIG3D_REQUIRE(q.n >= 0 && q.nslabs >= 0 && q.n % 4 == 0 && q.slab_stride % 4 == 0 && q.slab_stride >= q.n,
+                  "n and the slab stride in multiples of 4 floats");
+    if (q.n == 0 || q.nslabs == 0) continue;
+    SIG3D_REQUIRE(q.dst && q.slabs && ((size_t)q.dst & 15) == 0 && ((size_t)q.slabs & 15) == 0, "16-byte aligned operands");
+    js.job[js.njobs] = q;
+    js.first_block[js.njobs] = blocks;
+    blocks += sig3d_ceil_div(q.n / 4, 64);
+    ++js.njobs;
+  }
+  js.first_block[js.njobs] = blocks;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, stream, js);
+  SIG3D_LAUNCH_CHECK("sum_slabs_multi_kernel");
   return 0;
 }
 

@@ -141,16 +141,16 @@ __global__ __launch_bounds__(256) void pos_mlp_fwd_kernel(int rows, int cin, int
 
 // backward, input side: dpre[m][j] = gelu'(pre[m][j]) * sum_c dy[m][c] w2[c][j];  dw1[j][:] += dpre[:, j]^T x,
 // db1[j] += sum_m dpre[m][j] (float atomics: dw1 / db1 zero on entry).  grid (row tiles, hid tiles)
-__global__ __launch_bounds__(256) void pos_mlp_bwd_in_kernel(int rows, int cin, int hid, int cout,
-                                                             const float *__restrict__ x, const float *__restrict__ w2,
-                                                             const float *__restrict__ pre, const float *__restrict__ dy,
-                                                             float *__restrict__ dpre, float *__restrict__ dw1,
-                                                             float *__restrict__ db1) {
+__device__ __forceinline__ void pos_mlp_bwd_in_body(int bx, int by, int rows, int cin, int hid, int cout,
+                                                    const float *__restrict__ x, const float *__restrict__ w2,
+                                                    const float *__restrict__ pre, const float *__restrict__ dy,
+                                                    float *__restrict__ dpre, float *__restrict__ dw1,
+                                                    float *__restrict__ db1) {
   extern __shared__ __attribute__((aligned(16))) float sg_smem[];
   float(*As)[SG_LD] = reinterpret_cast<float(*)[SG_LD]>(sg_smem);
   float(*Bs)[SG_LD] = As + SG_K;
   __shared__ float s_x[SG_T][PE_MAXCIN], s_p[16][SG_T][PE_MAXCIN + 1];
-  const int m0 = blockIdx.x * SG_T, n0 = blockIdx.y * SG_T, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int m0 = bx * SG_T, n0 = by * SG_T, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   for (int i = tid; i < SG_T * PE_MAXCIN; i += 256) {
     const int r = i / PE_MAXCIN, c = i % PE_MAXCIN;
     s_x[r][c] = (m0 + r < rows && c < cin) ? x[(size_t)(m0 + r) * cin + c] : 0.f;
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256) void pos_mlp_bwd_in_kernel(int rows, int cin, 
 
 // backward, weight side: dw2[c][j] += sum_m dy[m][c] gelu(pre[m][j]) over this workgroup's 128 rows, db2[c] += sum_m
 // dy[m][c] (float atomics: zero on entry).  grid (cout tiles, hid tiles, chunks of 128 rows)
-__global__ __launch_bounds__(256) void pos_mlp_bwd_w_kernel(int rows, int hid, int cout,
-                                                            const float *__restrict__ pre, const float *__restrict__ dy,
-                                                            float *__restrict__ dw2, float *__restrict__ db2) {
+__device__ __forceinline__ void pos_mlp_bwd_w_body(int bx, int by, int bz, int rows, int hid, int cout,
+                                                   const float *__restrict__ pre, const float *__restrict__ dy,
+                                                   float *__restrict__ dw2, float *__restrict__ db2) {
   extern __shared__ __attribute__((aligned(16))) float sg_smem[];
   float(*As)[SG_LD] = reinterpret_cast<float(*)[SG_LD]>(sg_smem);
   float(*Bs)[SG_LD] = As + SG_K;
-  const int m0 = blockIdx.x * SG_T, n0 = blockIdx.y * SG_T, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int r0 = blockIdx.z * SG_K;
+  const int m0 = bx * SG_T, n0 = by * SG_T, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int r0 = bz * SG_K;
   const int k = tid >> 1, q = (tid & 1) * 32;   // row r0 + k, 32 consecutive columns
   const bool live = r0 + k < rows;
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void pos_mlp_bwd_w_kernel(int rows, int hid, i
       if (n < hid) unsafeAtomicAdd(dw2 + (size_t)c * hid + n, acc.v[i][j]);
     }
   }
-  if (blockIdx.y == 0 && tid < SG_T && m0 + tid < cout) {   // bias gradient once per (cout tile, row chunk)
+  if (by == 0 && tid < SG_T && m0 + tid < cout) {   // bias gradient once per (cout tile, row chunk)
     float t = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SG_K; ++r) t += As[r][tid];
@@ -298,6 +298,24 @@ extern "C" int sig3d_pos_mlp_fwd_posed(int b, int tokens, int hid, int cout, int
                           pre, out, stream_);
 }
 
+// Both sides of the backward pass in ONE launch: they read dy and pre and share nothing they write, and each is a few
+// dozen workgroups of ~20 us -- in a row they cost the step two such waits.  Workgroups [0, n_in) are the input side's
+// (row tile, hid tile) grid, the rest the weight side's (cout tile, hid tile, row chunk) grid.
+__global__ __launch_bounds__(256) void pos_mlp_bwd_kernel(int rows, int cin, int hid, int cout, int in_x, int n_in, int w_x,
+                                                          int w_y, const float *__restrict__ x,
+                                                          const float *__restrict__ w2, const float *__restrict__ pre,
+                                                          const float *__restrict__ dy, float *__restrict__ dpre,
+                                                          float *__restrict__ dw1, float *__restrict__ db1,
+                                                          float *__restrict__ dw2, float *__restrict__ db2) {
+  const int blk = (int)blockIdx.x;       // (uniform branch: a workgroup runs one body)
+  if (blk < n_in) {
+    pos_mlp_bwd_in_body(blk % in_x, blk / in_x, rows, cin, hid, cout, x, w2, pre, dy, dpre, dw1, db1);
+  } else {
+    const int t = blk - n_in;
+    pos_mlp_bwd_w_body(t % w_x, (t / w_x) % w_y, t / (w_x * w_y), rows, hid, cout, pre, dy, dw2, db2);
+  }
+}
+
 static int pos_mlp_bwd_impl(int rows, int cin, int hid, int cout, const float *x, const float *w2, const float *pre,
                             const float *dy, float *dpre, float *grads, bool grads_zeroed, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -310,12 +328,11 @@ static int pos_mlp_bwd_impl(int rows, int cin, int hid, int cout, const float *x
     SIG3D_HIP_TRY(hipMemsetAsync(grads, 0, sizeof(float) * ((size_t)hid * cin + hid + (size_t)cout * hid + cout), stream));
   if (rows == 0) return 0;
   const size_t lds = sizeof(float) * 2 * SG_K * SG_LD;
-  SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)pos_mlp_bwd_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)pos_mlp_bwd_w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(pos_mlp_bwd_in_kernel, dim3(sig3d_ceil_div(rows, SG_T), sig3d_ceil_div(hid, SG_T)), dim3(256), lds,
-                     stream, rows, cin, hid, cout, x, w2, pre, dy, dpre, dw1, db1);
-  hipLaunchKernelGGL(pos_mlp_bwd_w_kernel, dim3(sig3d_ceil_div(cout, SG_T), sig3d_ceil_div(hid, SG_T), sig3d_ceil_div(rows, SG_K)),
-                     dim3(256), lds, stream, rows, hid, cout, pre, dy, dw2, db2);
+  SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)pos_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int in_x = sig3d_ceil_div(rows, SG_T), n_in = in_x * sig3d_ceil_div(hid, SG_T);
+  const int w_x = sig3d_ceil_div(cout, SG_T), w_y = sig3d_ceil_div(hid, SG_T), w_z = sig3d_ceil_div(rows, SG_K);
+  hipLaunchKernelGGL(pos_mlp_bwd_kernel, dim3(n_in + w_x * w_y * w_z), dim3(256), lds, stream, rows, cin, hid, cout, in_x,
+                     n_in, w_x, w_y, x, w2, pre, dy, dpre, dw1, db1, dw2, db2);
   SIG3D_LAUNCH_CHECK("pos_mlp_bwd kernels");
   return 0;
 }

@@ -97,6 +97,9 @@ def compact_lists(idx):
 # SIG3D_DW_STREAM=0: the layers' weight gradients through mlp_dw_kernel (one 64-byte run per lane and row, f32 atomics)
 # instead of the k-streaming split product of sig3d_mlp_layer_dw_stream
 DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 3: every level, whatever its size
+# SIG3D_DW_FOLD_ONCE=0: every streaming weight gradient folds its own slabs (a launch per layer: 11 per step) instead of one
+# fold per SharedMLP stack (sig3d_sum_slabs_multi: 4 per step)
+DW_FOLD_ONCE = os.environ.get("SIG3D_DW_FOLD_ONCE", "1") != "0"
 # SIG3D_DW_REGROUP=0: the gathered first layer of a compact level keeps its gathering weight-gradient kernel
 DW_REGROUP = os.environ.get("SIG3D_DW_REGROUP", "1") != "0"
 # dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
@@ -358,6 +361,8 @@ class _FusedMLPMax(torch.autograd.Function):
                 sums_all = scratch.zeros((nl, 2, cmax), torch.float64, dev)
                 dw_all = torch.zeros(n_dw, dtype=torch.float32, device=dev)
             dw_off = 0
+            folds = []           # (dW, work, n, slab stride, slabs) of the streaming weight gradients: ONE fold per stack
+            dw_entry = "sig3d_mlp_layer_dw_stream_nofold" if DW_FOLD_ONCE else "sig3d_mlp_layer_dw_stream"
             for k in range(nl - 1, -1, -1):
                 cout, cin = ws[k].shape
                 scale, shift, mean, invstd = _aff_rows(affs[k])
@@ -409,8 +414,11 @@ class _FusedMLPMax(torch.autograd.Function):
                               _lib.ptr(c_cidx), _lib.ptr(c_cent), _lib.ptr(c_nact), _lib.ptr(rg), stream)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
                     work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
-                    _lib.call("sig3d_mlp_layer_dw_stream", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(rg), _lib.ptr(None),
+                    _lib.call(dw_entry, b, cin, cout, e, _lib.ptr(dY), _lib.ptr(rg), _lib.ptr(None),
                               _lib.ptr(None), _lib.ptr(c_nact), _lib.ptr(dW), _lib.ptr(work), stream)
+                    if DW_FOLD_ONCE:
+                        slab = (cout * cin + 3) // 4 * 4
+                        folds.append((dW, work, cout * cin, slab, n_work // slab))
                 elif gather is not None and k == 0 and regroup is None:
                     _lib.call("sig3d_mlp_layer0_gather_dw", b, n_src, p, s, c_src, cout, int(g_norm),
                               ctypes.c_float(g_radius), _lib.ptr(g_xyz), _lib.ptr(g_new_xyz), _lib.ptr(x),
@@ -423,9 +431,12 @@ class _FusedMLPMax(torch.autograd.Function):
                     # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
                     work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
-                    _lib.call("sig3d_mlp_layer_dw_stream", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
+                    _lib.call(dw_entry, b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
                               _lib.ptr(ppb), _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dW),
                               _lib.ptr(work), stream)
+                    if DW_FOLD_ONCE:
+                        slab = (cout * cin + 3) // 4 * 4
+                        folds.append((dW, work, cout * cin, slab, n_work // slab))
                 elif compact is not None:
                     _lib.call("sig3d_mlp_layer_dw_compact", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev),
                               _lib.ptr(pps), _lib.ptr(ppb), _lib.ptr(dW), 1, _lib.ptr(c_nact), stream)
@@ -470,6 +481,8 @@ class _FusedMLPMax(torch.autograd.Function):
                                   _lib.ptr(c_nact if compact is not None else None), stream)
                     if k == 0:
                         grad_x = dA
+            if folds:
+                _lib.sum_slabs_multi(dev, folds)
             sums32 = sums_all.to(torch.float32)                # one conversion launch for the whole stack
             for k in range(nl):
                 cout = ws[k].shape[0]

@@ -334,7 +334,7 @@ def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monke
             max(i for i, nm in enumerate(calls) if nm.startswith("sig3d_bn_relu_maxpool"))
         assert not any(nm.startswith("sig3d_query_group") for nm in calls[:fwd_end + 1])
         assert "sig3d_mlp_layer0_gather_dw" in calls or \
-            calls.index("sig3d_query_group_compact") < calls.index("sig3d_mlp_layer_dw_stream", calls.index("sig3d_query_group_compact"))
+            calls.index("sig3d_query_group_compact") < calls.index("sig3d_mlp_layer_dw_stream_nofold", calls.index("sig3d_query_group_compact"))
         assert "sig3d_mlp_layer0_scatter_dx_w" in calls
     elif mode == "dense":   # forward without it; the backward re-materialises it (faster than gathering twice more)
         assert calls.index("sig3d_query_group_fused_pm") > calls.index("sig3d_bn_relu_maxpool")
@@ -668,6 +668,20 @@ def test_streaming_weight_gradient_matches_the_row_per_lane_kernel_and_float64(b
         else:
             L.call("sig3d_mlp_layer_dw", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(old), 0, st)
     assert torch.equal(outs[0], outs[1])
+    # the same product without its fold + the fold of several results in one launch (what a SharedMLP stack's backward
+    # pass does): bit for bit the folded product, whatever else shares the launch
+    with torch.cuda.device(DEV):
+        dW2 = torch.full((cout, cin), float("nan"), device=DEV)
+        work2 = torch.empty_like(work)
+        L.call("sig3d_mlp_layer_dw_stream_nofold", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(n_act),
+               L.ptr(dW2), L.ptr(work2), st)
+        n_work = int(L.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
+        slab = (cout * cin + 3) // 4 * 4
+        other = torch.ones(40, device=DEV)
+        other_slabs = torch.arange(3 * 40, dtype=torch.float32, device=DEV)
+        L.sum_slabs_multi(torch.device(DEV), [(other, other_slabs, 40, 40, 3), (dW2, work2, cout * cin, slab, n_work // slab)])
+    assert torch.equal(dW2, outs[0])
+    assert torch.equal(other, 1 + other_slabs.view(3, 40).sum(0))
     a = x.double()
     if prologue:
         a = torch.relu(a * ps.double()[None, :, None] + pb.double()[None, :, None])

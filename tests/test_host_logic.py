@@ -199,13 +199,14 @@ def test_qformer_state_dict_keys_match_reference():
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
-    """The ctypes mirrors of the C-ABI structs (sig3d_bq_level, sig3d_column_sum_job, sig3d_gemm16_problem,
+    """The ctypes mirrors of the C-ABI structs (sig3d_bq_level, sig3d_column_sum_job, sig3d_sum_slabs_job, sig3d_gemm16_problem,
     sig3d_gemmp_problem) must agree with what a C compiler makes of include/sig3d_hip.h: size and every field offset,
     checked by compiling a probe with gcc."""
     import ctypes
     import subprocess
     from situation3d_amd import _lib
     structs = {"sig3d_bq_level": _lib.BqLevel, "sig3d_column_sum_job": _lib.ColumnSumJob,
+               "sig3d_sum_slabs_job": _lib.SumSlabsJob,
                "sig3d_gemm16_problem": _lib.Gemm16Problem, "sig3d_gemmp_problem": _lib.GemmpProblem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sig3d_hip.h"', 'int main(void) {']
     for cname, cls in structs.items():
