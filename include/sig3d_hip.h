@@ -680,7 +680,10 @@ typedef struct sig3d_sum_slabs_job {
   long n, slab_stride;
   int nslabs, pad;
 } sig3d_sum_slabs_job;
-int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, void *stream);
+/* cvt_n > 0: the same launch also converts cvt_n doubles to floats (cvt_dst[i] = (float)cvt_src[i]: the stack's f64
+ * BatchNorm-gradient sums -> its f32 d gamma / d beta). */
+int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, const double *cvt_src, float *cvt_dst, int cvt_n,
+                          void *stream);
 
 /* ---- the two MLP heads on the pooled Q-Former output (csrc/heads.hip) ----------------------------------------
  * situation3d/models/sqa_module.py: the fused query tokens are averaged per sample and feed

@@ -148,19 +148,22 @@ class SumSlabsJob(ctypes.Structure):
 
 
 SUM_SLABS_MAX_JOBS = 8
-SIGNATURES["sig3d_sum_slabs_multi"] = [_I, ctypes.POINTER(SumSlabsJob), _P]
+SIGNATURES["sig3d_sum_slabs_multi"] = [_I, ctypes.POINTER(SumSlabsJob), _P, _P, _I, _P]
 
 
-def sum_slabs_multi(device, jobs):
-    """jobs: (dst, work, n, slab_stride, nslabs): dst[:n] += the nslabs slabs of `work`; SUM_SLABS_MAX_JOBS per launch."""
+def sum_slabs_multi(device, jobs, convert=None):
+    """jobs: (dst, work, n, slab_stride, nslabs): dst[:n] += the nslabs slabs of `work`; SUM_SLABS_MAX_JOBS per launch.
+    convert: (float64 source, float32 destination) of equal size, contiguous: converted by the (first) launch as well."""
     jobs = [j for j in jobs if j[4] > 0]
-    for i in range(0, len(jobs), SUM_SLABS_MAX_JOBS):
+    for i in range(0, max(len(jobs), 1), SUM_SLABS_MAX_JOBS):
         chunk = jobs[i:i + SUM_SLABS_MAX_JOBS]
-        arr = (SumSlabsJob * len(chunk))()
+        arr = (SumSlabsJob * max(len(chunk), 1))()
         for a, (dst, work, n, stride, nslabs) in zip(arr, chunk):
             a.dst, a.slabs, a.n, a.slab_stride, a.nslabs = dst.data_ptr(), work.data_ptr(), n, stride, nslabs
+        cv = convert if i == 0 else None
         with torch.cuda.device(device):
-            call("sig3d_sum_slabs_multi", len(chunk), arr, stream_ptr(device))
+            call("sig3d_sum_slabs_multi", len(chunk), arr, ptr(cv[0]) if cv else None, ptr(cv[1]) if cv else None,
+                 cv[0].numel() if cv else 0, stream_ptr(device))
 
 
 class Gemm16Problem(ctypes.Structure):

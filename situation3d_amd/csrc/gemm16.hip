@@ -165,11 +165,21 @@ struct SumSlabsJobs {
   sig3d_sum_slabs_job job[SIG3D_SUM_SLABS_MAX_JOBS];
   int first_block[SIG3D_SUM_SLABS_MAX_JOBS + 1];
   int njobs;
+  // riding along: cvt_dst[i] = (float)cvt_src[i], i < cvt_n, by the workgroups from first_block[njobs] on (the f64
+  // BatchNorm-gradient sums of the same stack become its f32 d gamma / d beta: a conversion launch per stack before)
+  const double *cvt_src;
+  float *cvt_dst;
+  int cvt_n;
 };
 
 // sum_slabs_kernel for several (dst, slabs) pairs: same columns per workgroup, same order of additions per job
 __global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SumSlabsJobs js) {
   __shared__ float4 s_part[4][64];
+  if ((int)blockIdx.x >= js.first_block[js.njobs]) {      // (uniform) the conversion's workgroups
+    const int i = ((int)blockIdx.x - js.first_block[js.njobs]) * 256 + (int)threadIdx.x;
+    if (i < js.cvt_n) js.cvt_dst[i] = (float)js.cvt_src[i];
+    return;
+  }
   int j = 0;
   while (j + 1 < js.njobs && (int)blockIdx.x >= js.first_block[j + 1]) ++j;
   const sig3d_sum_slabs_job q = js.job[j];
@@ -199,8 +209,10 @@ __global__ __launch_bounds__(256) void sum_slabs_multi_kernel(SumSlabsJobs js) {
 }
 }  // namespace
 
-extern "C" int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, void *stream_) {
+extern "C" int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs, const double *cvt_src, float *cvt_dst,
+                                     int cvt_n, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(cvt_n >= 0 && (cvt_n == 0 || (cvt_src && cvt_dst)), "conversion: null operand");
   SIG3D_REQUIRE(njobs >= 0 && njobs <= SIG3D_SUM_SLABS_MAX_JOBS, "at most SIG3D_SUM_SLABS_MAX_JOBS jobs per launch");
   SIG3D_REQUIRE(njobs == 0 || jobs != nullptr, "null job list");
   SumSlabsJobs js = {};
@@ -217,6 +229,8 @@ extern "C" int sig3d_sum_slabs_multi(int njobs, const sig3d_sum_slabs_job *jobs,
     ++js.njobs;
   }
   js.first_block[js.njobs] = blocks;
+  js.cvt_src = cvt_src; js.cvt_dst = cvt_dst; js.cvt_n = cvt_n;
+  blocks += sig3d_ceil_div(cvt_n, 256);
   if (blocks == 0) return 0;
   hipLaunchKernelGGL(sum_slabs_multi_kernel, dim3(blocks), dim3(256), 0, stream, js);
   SIG3D_LAUNCH_CHECK("sum_slabs_multi_kernel");

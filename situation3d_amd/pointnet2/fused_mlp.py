@@ -481,9 +481,11 @@ class _FusedMLPMax(torch.autograd.Function):
                                   _lib.ptr(c_nact if compact is not None else None), stream)
                     if k == 0:
                         grad_x = dA
-            if folds:
-                _lib.sum_slabs_multi(dev, folds)
-            sums32 = sums_all.to(torch.float32)                # one conversion launch for the whole stack
+            if folds:            # the folds of the stack and the f64 -> f32 conversion of its BatchNorm-gradient sums: one launch
+                sums32 = torch.empty(sums_all.shape, dtype=torch.float32, device=dev)
+                _lib.sum_slabs_multi(dev, folds, convert=(sums_all, sums32))
+            else:
+                sums32 = sums_all.to(torch.float32)            # one conversion launch for the whole stack
             for k in range(nl):
                 cout = ws[k].shape[0]
                 grads[3 * k + 1] = sums32[k, 1, :cout]         # d gamma

@@ -679,9 +679,13 @@ def test_streaming_weight_gradient_matches_the_row_per_lane_kernel_and_float64(b
         slab = (cout * cin + 3) // 4 * 4
         other = torch.ones(40, device=DEV)
         other_slabs = torch.arange(3 * 40, dtype=torch.float32, device=DEV)
-        L.sum_slabs_multi(torch.device(DEV), [(other, other_slabs, 40, 40, 3), (dW2, work2, cout * cin, slab, n_work // slab)])
+        src64 = torch.randn(700, dtype=torch.float64, device=DEV)
+        dst32 = torch.full((700,), float("nan"), device=DEV)
+        L.sum_slabs_multi(torch.device(DEV), [(other, other_slabs, 40, 40, 3), (dW2, work2, cout * cin, slab, n_work // slab)],
+                          convert=(src64, dst32))
     assert torch.equal(dW2, outs[0])
     assert torch.equal(other, 1 + other_slabs.view(3, 40).sum(0))
+    assert torch.equal(dst32, src64.float())            # the conversion riding along
     a = x.double()
     if prologue:
         a = torch.relu(a * ps.double()[None, :, None] + pb.double()[None, :, None])
