@@ -673,6 +673,12 @@ long sig3d_mlp_layer_dw_stream_work_floats(int b, int cin, int cout, long e);
 int sig3d_mlp_layer_dw_stream_nofold(int b, int cin, int cout, long e, const float *dY, const float *x,
                                      const float *pscale, const float *pshift, const int *n_act, float *dW,
                                      float *work, void *stream);
+/* A compact level's layer in the backward pass, both products that read its dY in ONE launch (two workgroup ranges): the
+ * weight gradient as sig3d_mlp_layer_dw_stream_nofold and the input gradient dA (b, cin, e) = W^T dY as sig3d_mlp_layer_dx
+ * (w (cout, cin) as stored).  Same results bit for bit; shapes that take other kernel instances run the two launches. */
+int sig3d_mlp_layer_dw_dx(int b, int cin, int cout, long e, const float *dY, const float *x, const float *pscale,
+                          const float *pshift, const int *n_act, const float *w, float *dW, float *work, float *dA,
+                          void *stream);
 #define SIG3D_SUM_SLABS_MAX_JOBS 8
 typedef struct sig3d_sum_slabs_job {
   float *dst;

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sig3d_mlp_layer_dx": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_dw_stream": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_dw_stream_nofold": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sig3d_mlp_layer_dw_dx": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_mlp_layer_fwd_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "sig3d_mlp_layer_dw_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _I, _P, _P],
     "sig3d_bn_relu_maxpool_compact": [_I, _I, _I, ctypes.c_long, _P, _P, _P, _P, _P, _P, _P],

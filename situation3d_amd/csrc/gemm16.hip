@@ -146,6 +146,32 @@ static int dw_stream_impl(int b, int cin, int cout, long e, const float *dY, con
   return 0;
 }
 
+// For shared_mlp.hip's launch of a layer's weight gradient and input gradient as two workgroup ranges: the weight
+// gradient's problem as dw_stream_impl sets it up (no launch).  *usable = 0 when the product would take another tiling
+// than <1, 2, 4, 2> (48-wide column tiles) or is empty; grid = workgroups of the product.
+extern "C" int sig3d_internal_dw_stream_problem(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                                const float *pscale, const float *pshift, const int *n_act, float *dW,
+                                                float *work, void *problem_out, int *grid, int *usable) {
+  *usable = 0; *grid = 0;
+  if (b <= 0 || e <= 0 || e % 4 != 0 || dw_narrow_tiles(cin) || !dY || !x || !dW) return 0;
+  auto al = [](const void *q) { return ((size_t)q & 15) == 0; };
+  if (!al(dY) || !al(x) || (size_t)cout * e * 4 >= (1ull << 31) || (size_t)cin * e * 4 >= (1ull << 31)) return 0;
+  const int splits = dw_stream_splits(b, cin, cout, e);
+  if ((long)b * splits > 1 && work == nullptr) return 0;
+  gemm16::Problem p = {};
+  p.A = dY; p.B = x; p.C = dW; p.Cs = work;
+  p.M = cout; p.N = cin; p.K = (int)e;
+  p.lda = (int)e; p.ldb = (int)e; p.ldc = cin;
+  p.sA = (long)cout * e; p.sB = (long)cin * e; p.sC = 0; p.slab = ((long)cout * cin + 3) / 4 * 4;
+  p.batch = b; p.splits = splits; p.act = 0;
+  p.k_dev = n_act; p.b_scale = pscale; p.b_shift = pshift;
+  p.ntm = (p.M + 63) / 64; p.ntn = (p.N + 63) / 64;
+  *reinterpret_cast<gemm16::Problem *>(problem_out) = p;
+  *grid = p.ntm * p.ntn * p.splits * p.batch;
+  *usable = 1;
+  return 0;
+}
+
 extern "C" int sig3d_mlp_layer_dw_stream(int b, int cin, int cout, long e, const float *dY, const float *x,
                                          const float *pscale, const float *pshift, const int *n_act, float *dW,
                                          float *work, void *stream_) {

@@ -78,8 +78,11 @@ __device__ __forceinline__ int slot_off(int row, int q) { return row * BK + ((q 
 
 // AB x BB blocks of 16 x 16 per wave, WGM x WGN waves per workgroup, PF >= 3 chunks in flight (register ring,
 // statically indexed: the loop is unrolled PF times), OCC workgroups per CU the register budget is sized for.
-template <int AB, int BB, int WGM, int WGN, int PF, int OCC, int BMODE, bool KEDGE, bool DW = false>
-__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Problem p) {
+// The kernel's body as a device function of (problem, this workgroup's number, workgroups of the product): a launch may
+// carry another kernel's workgroups behind these (shared_mlp.hip: a layer's weight gradient and its input gradient as
+// two workgroup ranges of one launch).
+template <int AB, int BB, int WGM, int WGN, int PF, int BMODE, bool KEDGE, bool DW>
+__device__ __forceinline__ void gemm16_body(const Problem &p, const int block_id, const int T) {
   static_assert(!DW || BMODE == B_KC, "the weight-gradient form streams two k-contiguous operands");
   static_assert(PF >= 3, "chunk c + 2 is stored while chunk c + PF is requested into chunk c's slot");
   constexpr int NW = WGM * WGN, NT = 64 * NW;
@@ -93,11 +96,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
 
   // ---- which tile.  Workgroups of one XCD (blockIdx % 8) take a contiguous run of work ids; ids are ordered
   // (batch, n tile, split, m tile) with the m tile fastest: neighbours share their weight tile in the XCD's L2.
-  const int T = gridDim.x;
-  const int xcd = blockIdx.x & 7;
+  const int xcd = block_id & 7;
   int base = 0;
   for (int y = 0; y < xcd; ++y) base += (T - y + 7) >> 3;
-  int w = base + (blockIdx.x >> 3);
+  int w = base + (block_id >> 3);
   const int tm = w % p.ntm; w /= p.ntm;
   const int z = w % p.splits; w /= p.splits;
   const int tn = w % p.ntn;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
   // ---- prologue: PF chunks requested, chunks 0 and 1 staged, half 0 of chunk 0 in registers
 #ifdef GEMM16_TIMING
   int stamp_n = 0;
-#define GEMM16_STAMP() do { if (blockIdx.x == 0 && tid == 0 && stamp_n < 60) p.dbg[stamp_n] = __builtin_readcyclecounter(); ++stamp_n; } while (0)
+#define GEMM16_STAMP() do { if (block_id == 0 && tid == 0 && stamp_n < 60) p.dbg[stamp_n] = __builtin_readcyclecounter(); ++stamp_n; } while (0)
 #else
 #define GEMM16_STAMP() do { } while (0)
 #endif
@@ -397,6 +399,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Probl
   }
   GEMM16_STAMP();
 #undef GEMM16_STAMP
+}
+
+template <int AB, int BB, int WGM, int WGN, int PF, int OCC, int BMODE, bool KEDGE, bool DW = false>
+__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm16_kernel(const Problem p) {
+  gemm16_body<AB, BB, WGM, WGN, PF, BMODE, KEDGE, DW>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <int AB, int BB, int WGM, int WGN>

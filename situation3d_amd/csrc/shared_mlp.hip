@@ -24,7 +24,15 @@
 // per lane&31), K = input channels; C/D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 #include <cstdlib>
 
+#include "gemm16_core.h"
 #include "sig3d_common.h"
+
+extern "C" int sig3d_internal_dw_stream_problem(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                                const float *pscale, const float *pshift, const int *n_act, float *dW,
+                                                float *work, void *problem_out, int *grid, int *usable);   // gemm16.hip
+extern "C" int sig3d_mlp_layer_dw_stream_nofold(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                                const float *pscale, const float *pshift, const int *n_act,
+                                                float *dW, float *work, void *stream);
 
 namespace {
 
@@ -90,12 +98,15 @@ struct MlpGather {
   float *scatter;               // input-gradient use: add the tile into this point-major (B, N, C) gradient
 };
 
+// (the body takes its workgroup's coordinates and the grid's y extent as arguments: mlp_dw_dx_kernel below runs it as a
+// workgroup range of a launch that also carries the layer's weight-gradient product)
 template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER>
-__global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
+__device__ __forceinline__ void mlp_layer_fwd_body(
+    const int blk_x, const int blk_y, const int blk_z, const int grid_y,
     int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
     const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
     float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq,
-    const int *__restrict__ n_act, const float *__restrict__ mult, MlpGather ga, int w_t) {
+    const int *__restrict__ n_act, const float *__restrict__ mult, const MlpGather &ga, int w_t) {
   // Compact mode (n_act given, compact.hip): only the first n_act[b] positions of every row exist -- the
   // distinct neighbours -- and position u stands for mult[b][u] equal columns: the statistics are weighted.
   // E stays the row stride; En is the number of positions.
@@ -110,13 +121,13 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
 
   const int lane = lane_id(), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int co0 = blockIdx.x * CT;
-  const int bi = blockIdx.z;
+  const int co0 = blk_x * CT;
+  const int bi = blk_z;
   const int nt_act = min(NT, (cout - co0 + 31) / 32);  // 32-channel tiles of this block that hold channels
   float *s_tr = s_red + ML_WAVES * 2 * CT + wave * (16 * ML_TRLD);  // [ML_WAVES][16][ML_TRLD], wave-private
 
   // compact mode: the grid is sized for the dense row; workgroups without a tile leave before staging weights
-  if (n_act != nullptr && (long)blockIdx.y * ML_WAVES * 32 >= (long)n_act[bi]) return;
+  if (n_act != nullptr && (long)blk_y * ML_WAVES * 32 >= (long)n_act[bi]) return;
   ML_MARK(0);
   // weight tile -> LDS: a wave takes 8 rows at a time and issues their (clamped, unconditional)
   // loads together; one load -> wait -> ds_write per element took 20 us per workgroup at 128x128
@@ -168,8 +179,8 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
   // The launcher sizes gridDim.y so that the grid is ONE full round of resident workgroups
   // (weights staged once per workgroup, no tail round, neighbouring waves stream neighbouring tiles).
   const long n_tiles = (En + 31) / 32;
-  const long tile0 = (long)blockIdx.y * ML_WAVES + wave;
-  const long tile_stride = (long)gridDim.y * ML_WAVES;
+  const long tile0 = (long)blk_y * ML_WAVES + wave;
+  const long tile_stride = (long)grid_y * ML_WAVES;
   int my_tiles = 0;
   for (int t = 0; t < tiles_per_wave; ++t)
     if (tile0 + (long)t * tile_stride < n_tiles) my_tiles = t + 1;
@@ -417,6 +428,17 @@ __global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
       unsafeAtomicAdd((which ? stat_sq : stat_sum) + co0 + co, tot);
     }
   }
+}
+
+template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER>
+__global__ __launch_bounds__(ML_WAVES * 64, 2) void mlp_layer_fwd_kernel(
+    int cin, int cout, long E, int tiles_per_wave, const float *__restrict__ x,
+    const float *__restrict__ w, const float *__restrict__ pscale, const float *__restrict__ pshift,
+    float *__restrict__ y, double *__restrict__ stat_sum, double *__restrict__ stat_sq,
+    const int *__restrict__ n_act, const float *__restrict__ mult, MlpGather ga, int w_t) {
+  mlp_layer_fwd_body<NT, PROLOGUE, VEC, RAGGED, GATHER, SCATTER>((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                                                                 (int)gridDim.y, cin, cout, E, tiles_per_wave, x, w, pscale,
+                                                                 pshift, y, stat_sum, stat_sq, n_act, mult, ga, w_t);
 }
 
 // ---- BatchNorm statistics -> affine (scale, shift), saved stats, running stats ---------------
@@ -1679,6 +1701,71 @@ extern "C" int sig3d_mlp_layer_dx(int b, int cin, int cout, long e, const float 
   tl_w_t = 0;
   tl_n_act = nullptr;
   return rc;
+}
+
+// A compact level's layer in the backward pass: its weight gradient (the k-streaming product of gemm16_core.h, without its
+// fold) and its input gradient (the layer kernel above with the stored weight read transposed) share only dY, and each is
+// 15-40 us of mostly latency for one or two tiles per wave -- in a row they cost the step both waits.  ONE launch: workgroups
+// [0, n_dw) are the product's, the rest (their first four waves) the layer kernel's (xi, yi, zi) grid.
+__global__ __launch_bounds__(512, 2) void mlp_dw_dx_kernel(const gemm16::Problem p, int n_dw, int gx, int gy, int cin_k,
+                                                           int cout_k, long E, int tpw, const float *__restrict__ dY,
+                                                           const float *__restrict__ w, float *__restrict__ dA,
+                                                           const int *__restrict__ n_act) {
+  if ((int)blockIdx.x < n_dw) {
+    gemm16::gemm16_body<1, 2, 4, 2, 4, gemm16::B_KC, true, true>(p, (int)blockIdx.x, n_dw);
+    return;
+  }
+  if (threadIdx.x >= ML_WAVES * 64) return;        // (the layer kernel is four waves; a barrier counts live waves only)
+  const int t = (int)blockIdx.x - n_dw;
+  mlp_layer_fwd_body<2, false, true, false, false, false>(t % gx, (t / gx) % gy, t / (gx * gy), gy, cin_k, cout_k, E, tpw, dY, w,
+                                                         nullptr, nullptr, dA, nullptr, nullptr, n_act, nullptr, MlpGather{}, 1);
+}
+
+// dW (cout, cin) = sum dY a^T (a = x or relu(x * pscale + pshift), slabs NOT folded: sig3d_sum_slabs_multi) and
+// dA (b, cin, e) = W^T dY, compact lists (n_act).  Falls back to the two launches when the shapes take other instances.
+extern "C" int sig3d_mlp_layer_dw_dx(int b, int cin, int cout, long e, const float *dY, const float *x,
+                                     const float *pscale, const float *pshift, const int *n_act, const float *w,
+                                     float *dW, float *work, float *dA, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && cin >= 1 && cout >= 1 && e >= 0 && dY && x && w && dW && dA && n_act, "bad arguments");
+  gemm16::Problem p;
+  int n_dw = 0, usable = 0;
+  if (int rc = sig3d_internal_dw_stream_problem(b, cin, cout, e, dY, x, pscale, pshift, n_act, dW, work, &p, &n_dw, &usable))
+    return rc;
+  // the input gradient runs the layer kernel with (reduction, rows) = (cout, cin): the <2, .., VEC, !RAGGED> instance only
+  const int cin_k = cout, cout_k = cin;
+  const int kpad = ml_kpad(cin_k), ldw = kpad | 1;
+  const size_t lds_mlp = sizeof(float) * ((size_t)64 * ldw + 2 * kpad + ML_WAVES * 2 * 64 + ML_WAVES * 16 * ML_TRLD);
+  const bool ragged = (cin_k % (2 * ML_KC) != 0 && kpad - cin_k >= 2) || (cout_k % 64 != 0 && cout_k % 64 <= 32);
+  static const bool off = [] { const char *v = getenv("SIG3D_DW_DX_ONE_LAUNCH"); return v && atoi(v) == 0; }();
+  if (off || !usable || ragged || cout_k <= 32 || lds_mlp > 80 * 1024 || e % 4 != 0 || getenv("SIG3D_MLP_NT") ||
+      (long)cin_k * e >= (1L << 31) || (long)cout_k * e >= (1L << 31)) {
+    if (int rc = sig3d_mlp_layer_dw_stream_nofold(b, cin, cout, e, dY, x, pscale, pshift, n_act, dW, work, stream_)) return rc;
+    return sig3d_mlp_layer_dx(b, cin, cout, e, dY, w, dA, n_act, stream_);
+  }
+  // the layer kernel's grid as launch_mlp_fwd_g sizes it (one round of resident workgroups)
+  const long wave_tiles = (e + 31) / 32;
+  const int cblocks = sig3d_ceil_div(cout_k, 64);
+  int occ = (int)((160 * 1024) / lds_mlp);
+  if (occ > 3) occ = 3;
+  if (occ < 1) occ = 1;
+  long gy = (256L * occ + (long)b * cblocks - 1) / ((long)b * cblocks);
+  const long gy_max = (wave_tiles + ML_WAVES - 1) / ML_WAVES;
+  if (gy > gy_max) gy = gy_max;
+  if (gy < 1) gy = 1;
+  const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
+  const size_t lds_dw = gemm16::lds_bytes<1, 2, 4, 2>();
+  const size_t lds = lds_mlp > lds_dw ? lds_mlp : lds_dw;
+  static bool attr_done = false;
+  if (!attr_done) {
+    SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done = true;
+  }
+  const long blocks = (long)n_dw + (long)cblocks * gy * b;
+  hipLaunchKernelGGL(mlp_dw_dx_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, p, n_dw, cblocks, (int)gy, cin_k, cout_k,
+                     e, tpw, dY, w, dA, n_act);
+  SIG3D_LAUNCH_CHECK("mlp_dw_dx_kernel");
+  return 0;
 }
 
 // sig3d_mlp_layer0_scatter_dx with the weight as stored, w (cout, 3 + c)

@@ -100,6 +100,8 @@ DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 3: every level, w
 # SIG3D_DW_FOLD_ONCE=0: every streaming weight gradient folds its own slabs (a launch per layer: 11 per step) instead of one
 # fold per SharedMLP stack (sig3d_sum_slabs_multi: 4 per step)
 DW_FOLD_ONCE = os.environ.get("SIG3D_DW_FOLD_ONCE", "1") != "0"
+# SIG3D_DW_DX_ONE=0: a compact level's layer launches its weight gradient and its input gradient separately
+DW_DX_ONE = os.environ.get("SIG3D_DW_DX_ONE", "1") != "0"
 # SIG3D_DW_REGROUP=0: the gathered first layer of a compact level keeps its gathering weight-gradient kernel
 DW_REGROUP = os.environ.get("SIG3D_DW_REGROUP", "1") != "0"
 # dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
@@ -397,6 +399,7 @@ class _FusedMLPMax(torch.autograd.Function):
                 ppb = affs[k - 1][1] if k > 0 else None
                 dW = dw_all[dw_off:dw_off + cout * cin].view(cout, cin)
                 dw_off += cout * cin
+                dA_next = None       # set by a launch that computes the input gradient along with the weight gradient
                 if ctx.first is not None and k == 0:
                     f_new_xyz, f_idx, _, f_radius, f_norm, f_cin = ctx.first
                     _lib.call("sig3d_sa_first_layer_dw", b, x.shape[1], p, s, x.shape[2], f_cin, cout, int(f_norm),
@@ -431,9 +434,16 @@ class _FusedMLPMax(torch.autograd.Function):
                     # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
                     work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
-                    _lib.call(dw_entry, b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
-                              _lib.ptr(ppb), _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dW),
-                              _lib.ptr(work), stream)
+                    if DW_DX_ONE and DW_FOLD_ONCE and compact is not None and k > 0 and not ctx.library_gemm:
+                        # the layer's two products over dY as workgroup ranges of one launch (they share only what they read)
+                        dA_next = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
+                        _lib.call("sig3d_mlp_layer_dw_dx", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
+                                  _lib.ptr(ppb), _lib.ptr(c_nact), _lib.ptr(ws[k]), _lib.ptr(dW), _lib.ptr(work),
+                                  _lib.ptr(dA_next), stream)
+                    else:
+                        _lib.call(dw_entry, b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),
+                                  _lib.ptr(ppb), _lib.ptr(c_nact if compact is not None else None), _lib.ptr(dW),
+                                  _lib.ptr(work), stream)
                     if DW_FOLD_ONCE:
                         slab = (cout * cin + 3) // 4 * 4
                         folds.append((dW, work, cout * cin, slab, n_work // slab))
@@ -471,6 +481,8 @@ class _FusedMLPMax(torch.autograd.Function):
                         else:
                             grad_x = torch.empty((b, c_src, n_src), dtype=torch.float32, device=dev)
                             _lib.call("sig3d_transpose_cn", b, n_src, c_src, _lib.ptr(grad_pm), _lib.ptr(grad_x), stream)
+                elif dA_next is not None:
+                    dA = dA_next
                 elif k > 0 or ctx.needs_input_grad[0]:
                     if ctx.library_gemm:
                         dA = torch.bmm(ws[k].t().unsqueeze(0).expand(b, cin, cout), dY.view(b, cout, e)).view(b, cin, p, s)

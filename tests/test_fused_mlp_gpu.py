@@ -697,3 +697,43 @@ def test_streaming_weight_gradient_matches_the_row_per_lane_kernel_and_float64(b
     scale = max(1.0, float(ref.abs().max()))
     assert float((outs[0].double() - ref).abs().max()) < 2e-5 * scale
     assert float((old.double() - ref).abs().max()) < 1e-4 * scale
+
+
+@pytest.mark.parametrize("b,cin,cout,e,live,prologue", [(8, 64, 128, 131072, 14400, True), (8, 64, 64, 131072, 47000, True),
+                                                        (8, 128, 256, 32768, 1300, True), (8, 128, 128, 32768, 5400, True),
+                                                        (3, 96, 128, 4096, 700, False), (2, 35, 64, 132, 100, True),
+                                                        (2, 64, 40, 1024, 300, True)])
+def test_weight_and_input_gradient_in_one_launch_match_the_two_launches(b, cin, cout, e, live, prologue):
+    """sig3d_mlp_layer_dw_dx (a compact layer's weight gradient and input gradient as two workgroup ranges of one
+    launch) against sig3d_mlp_layer_dw_stream_nofold + sig3d_mlp_layer_dx: bit for bit, ragged live counts, shapes that
+    fall back to the two launches included (odd channel counts)."""
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(cin + cout + e)
+    dY = torch.randn(b, cout, e, generator=g).to(DEV)
+    x = torch.randn(b, cin, e, generator=g).to(DEV)
+    w = torch.randn(cout, cin, generator=g).to(DEV)
+    ps = (torch.rand(cin, generator=g) + 0.5).to(DEV) if prologue else None
+    pb = torch.randn(cin, generator=g).to(DEV) if prologue else None
+    lives = [live, max(live // 3, 1), 5, 0, live - 1, live // 2, 33, live][:b]
+    n_act = torch.tensor(lives, dtype=torch.int32, device=DEV)
+    st = L.stream_ptr(DEV)
+    n_work = int(L.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
+    res = []
+    with torch.cuda.device(DEV):
+        for one in (False, True):
+            dW = torch.full((cout, cin), float("nan"), device=DEV)
+            dA = torch.zeros(b, cin, e, device=DEV)          # (columns past a sample's live count are not written)
+            work = torch.full((max(n_work, 4),), float("nan"), device=DEV)
+            if one:
+                L.call("sig3d_mlp_layer_dw_dx", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb), L.ptr(n_act),
+                       L.ptr(w), L.ptr(dW), L.ptr(work), L.ptr(dA), st)
+            else:
+                L.call("sig3d_mlp_layer_dw_stream_nofold", b, cin, cout, e, L.ptr(dY), L.ptr(x), L.ptr(ps), L.ptr(pb),
+                       L.ptr(n_act), L.ptr(dW), L.ptr(work), st)
+                L.call("sig3d_mlp_layer_dx", b, cin, cout, e, L.ptr(dY), L.ptr(w), L.ptr(dA), L.ptr(n_act), st)
+            res.append((dW, work[:n_work].clone(), dA))
+    for a, c, name in zip(res[0], res[1], ("dW", "slabs", "dA")):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(c, nan=-7.0)), name
+    ref = torch.einsum("oc,boe->bce", w.double(), dY.double())
+    for i, n in enumerate(lives):
+        assert float((res[1][2][i, :, :n].double() - ref[i, :, :n]).abs().max() if n else 0.0) < 1e-3
