@@ -53,6 +53,10 @@ def parse_args(argv=None):
     # round 5: THREE chains in flight.  Since the main chain lost another ~0.5 ms in round 4 the step waited for its
     # geometry in every step (tools/probes/chain_slack.py: +0.05 ... +0.18 ms); with the chain two more steps ahead it
     # does not: -0.065 ms at depth 2, -0.094 at depth 3, +0.01 from 2 to 4 (tools/ab_step.py env:SIG3D_GEO_DEPTH)
+    ap.add_argument("--qf-cut", type=int, default=int(os.environ.get("SIG3D_QF_CUT", "0")),
+                    help="data-parallel forms only: cut the backward pass after this Q-Former layer as well (three graphs, three "
+                         "bucket sets; the optimizer stores the layers below / above it as two arenas) so that the upper "
+                         "layers' gradients are on the wire while the lower layers compute; 0 = one cut, at the scene tokens")
     ap.add_argument("--geo-depth", type=int, default=int(os.environ.get("SIG3D_GEO_DEPTH", "3")),
                     help="geometry chains in flight beside the step (geometry.GeometryPipeline; 1 = round 2's one-ahead)")
     return ap.parse_args(argv)
@@ -216,7 +220,7 @@ def to_device(d, device):
     return out
 
 
-CPU_SCENES = 4   # scenes in the bounded cpu_baseline sample
+CPU_SCENES = 8   # the whole B = 8 batch (BatchNorm statistics are batch-wide: the metric's own configuration)
 
 
 def group_algorithmic_bytes(b, n, m, ns, c):
@@ -319,7 +323,7 @@ def cpu_baseline(model, seed):
 TIMED_ENTRY_POINTS = ["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
                       "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query",
                       "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_ball_query_levels_ex",
-                      "sig3d_furthest_point_sampling",
+                      "sig3d_furthest_point_sampling", "sig3d_furthest_point_sampling_blocks",
                       "sig3d_sa_first_layer_fwd", "sig3d_sa_first_layer_dw"]
 KSTEPS = 3   # eager steps bracketed with HIP events after the timed region
 
@@ -336,9 +340,11 @@ def measure(args, rank, world, device, steps, warmup, surface=False, compact=Tru
         model = SIG3DQFormer(num_answers=NUM_ANSWERS).to(device).train()
         # clip_grad_value_(1.0) + AdamW (lr 2e-5, wd 0.05: scripts/train.sh:7) + zero_grad fused over
         # flat storage; under data parallelism the same flat gradient buffers are all-reduced in place
-        optimizer = build_optimizer(model, name="adamw" if args.torch_adamw else "flat_adamw")
+        data_parallel = world > 1 or args.force_reducer
+        optimizer = build_optimizer(model, name="adamw" if args.torch_adamw else "flat_adamw",
+                                    qf_cut=args.qf_cut if data_parallel and not args.torch_adamw else None)
         reducer = None
-        if world > 1 or args.force_reducer:
+        if data_parallel:
             reducer = (GradBucketReducer(model.parameters()) if args.torch_adamw
                        else GradBucketReducer.from_flat(optimizer.flat_grad_buffers()))
         n_batches = min(4, steps + warmup)
@@ -641,36 +647,59 @@ def config5_variant(device, bsz=4, reps=5):
             "ms": round(dt * 1e3, 3), "value": round(bsz / dt, 2), "unit": "samples/s", "batch": bsz,
             "library_projections_ms": round(dt_lib * 1e3, 3),
             "roofline_kv_projection": {
+                # the kernel issues bf16 MFMAs -- six per f32-equivalent product -- so its roofline is the dense bf16
+                # matrix peak over the ISSUED work; the f32-equivalent rate is reported beside it, without a fraction
                 "bound": "mfma", "launches": len(proj_ms), "ms": round(sum(proj_ms), 3), "flops": flops,
-                "achieved": round(ach, 1), "unit": "TFLOP/s (f32-equivalent)", "peak": MFMA_F32_PEAK_TFLOPS,
-                "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                "issued_bf16": {"achieved": round(6 * ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(6 * ach / MFMA_BF16_PEAK_TFLOPS, 4)},
-                "dtype": "f32 results from six bf16 products per f32 product (three-term split, f32 accumulation)"}}
+                "issued_flops": 6 * flops,
+                "achieved": round(6 * ach, 1), "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS,
+                "frac": round(6 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                "f32_equivalent_tflops": round(ach, 1),
+                "dtype": "bf16 MFMA: f32 results from six bf16 products per f32 product (three-term split, f32 accumulation)"}}
     qf.BIG_ROWS = big_rows
     del model
     torch.cuda.empty_cache()
     return out
 
 
-def comm_model(world, bytes_per_step, single_gpu_ms=7.5):
+def comm_model(world, bytes_per_step, single_gpu_ms=7.5, qf_cut=0):
     """DESIGN.md section 6, stated so that a measured line falsifies or confirms it: the gradient exchange of one step
     over xGMI (point-to-point links, 76.8 GB/s per direction each; every GPU has a direct link to each of its N - 1
-    peers), a ring / mesh all-reduce moving 2 (N - 1) / N x S bytes per rank over those links, on the wire from the end
-    of the Q-Former's backward pass (70 % of a single-GPU step) on and hidden under the encoder's backward pass and the
-    bucket-by-bucket update; + 0.3 ms of RCCL kernels sharing the CUs.  N = 8 also with RCCL's measured ~180 GB/s of
-    algorithm bandwidth on this class of node instead of the 7-link ideal."""
-    if world <= 1:
-        return {"wire_ms": 0.0, "predicted_ms_per_step": None, "note": "no wire at world size 1"}
+    peers), a ring / mesh all-reduce moving 2 (N - 1) / N x S bytes per rank over those links; + 0.3 ms of RCCL kernels
+    sharing the CUs.  Two forms of the step (graph_step.GraphedTrainStep):
+      uncut: every Q-Former gradient is ready when the Q-Former's backward pass and its layer-batched weight gradients
+             are done (70 % of a single-GPU step); the wire runs under the encoder's backward pass and the bucket-by-bucket update;
+      cut k: the layers from k on (half the bytes at k = 6) are ready at ~52 % of the step, the rest at 70 %.
+    `forms` holds both at N = 2 / 4 / 8 (predicted ms per step and the part of the exchange that is NOT hidden), so that
+    one SCALE run says which form to keep; N = 8 also with RCCL's measured ~180 GB/s of algorithm bandwidth on this
+    class of node instead of the 7-link ideal."""
     link = 76.8e9
-    wire = 2.0 * (world - 1) / world * bytes_per_step / ((world - 1) * link) * 1e3
-    out = {"links_per_gpu": world - 1, "link_gbs_per_direction": 76.8, "wire_ms": round(wire, 3),
-           "assumed_single_gpu_ms": single_gpu_ms,
-           "predicted_ms_per_step": round(max(single_gpu_ms + 0.3, 0.7 * single_gpu_ms + wire + 0.1), 3)}
+
+    def one(n, cut, rccl_180=False):
+        wire = bytes_per_step / 180e9 * 1e3 if rccl_180 else 2.0 * (n - 1) / n * bytes_per_step / ((n - 1) * link) * 1e3
+        floor = single_gpu_ms + 0.3                        # compute chain + RCCL's kernels on the CUs
+        if cut:
+            upper_done = max(0.52 * single_gpu_ms + wire / 2, 0.7 * single_gpu_ms)
+            end = upper_done + wire / 2 + 0.1
+        else:
+            end = 0.7 * single_gpu_ms + wire + 0.1
+        return {"wire_ms": round(wire, 3), "predicted_ms_per_step": round(max(floor, end), 3),
+                "exposed_ms": round(max(0.0, end - floor), 3)}
+
+    forms = {}
+    for n in (2, 4, 8):
+        forms["N=%d" % n] = {"uncut": one(n, False), "cut": one(n, True)}
+    forms["N=8 at rccl 180 GB/s"] = {"uncut": one(8, False, True), "cut": one(8, True, True)}
+    if world <= 1:
+        return {"wire_ms": 0.0, "predicted_ms_per_step": None, "note": "no wire at world size 1", "forms": forms}
+    mine = one(world, bool(qf_cut))
+    out = {"links_per_gpu": world - 1, "link_gbs_per_direction": 76.8, "wire_ms": mine["wire_ms"],
+           "assumed_single_gpu_ms": single_gpu_ms, "form": "cut %d" % qf_cut if qf_cut else "uncut",
+           "predicted_ms_per_step": mine["predicted_ms_per_step"], "predicted_exposed_ms": mine["exposed_ms"],
+           "forms": forms}
     if world == 8:
-        wire_rccl = bytes_per_step / 180e9 * 1e3
-        out["wire_ms_at_rccl_180_gbs"] = round(wire_rccl, 3)
-        out["predicted_ms_per_step_at_rccl_180_gbs"] = round(max(single_gpu_ms + 0.3, 0.7 * single_gpu_ms + wire_rccl + 0.1), 3)
+        r = one(8, bool(qf_cut), True)
+        out["wire_ms_at_rccl_180_gbs"] = r["wire_ms"]
+        out["predicted_ms_per_step_at_rccl_180_gbs"] = r["predicted_ms_per_step"]
     return out
 
 
@@ -731,7 +760,7 @@ def main():
         achieved = grp_bytes / (sum(grp) * 1e-3) / 1e9 if grp else 0.0
         bq = kernel_ms("sig3d_ball_query") + kernel_ms("sig3d_ball_query_grid") + kernel_ms("sig3d_ball_query_levels") \
             + kernel_ms("sig3d_ball_query_levels_ex")
-        fps = kernel_ms("sig3d_furthest_point_sampling")
+        fps = kernel_ms("sig3d_furthest_point_sampling") + kernel_ms("sig3d_furthest_point_sampling_blocks")
         # HBM traffic cannot be read from inside this process: it comes from the rocprofv3 --pmc passes of the
         # commit named in the file (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE; tools/pmc_traffic.py)
         traffic, traffic_commit, traffic_stale = None, None, None
@@ -827,7 +856,8 @@ def main():
         if head["comm"] is not None:
             # data-parallel form (N > 1, or --force-reducer): what the gradient exchange costs the step (ddp.CommStats)
             out["comm"] = dict(head["comm"])
-            out["comm"]["model"] = comm_model(world, head["comm"]["bytes_per_step"])
+            out["comm"]["model"] = comm_model(world, head["comm"]["bytes_per_step"], qf_cut=args.qf_cut)
+            out["comm"]["qf_cut"] = args.qf_cut
     # ---- beside the headline (N = 1): the same step with every level dense, and on surface-shaped scenes
     if world == 1 and not args.no_variants:
         vsteps, vwarm = min(args.steps, 10), min(args.warmup, 3)

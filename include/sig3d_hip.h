@@ -55,6 +55,16 @@ int sig3d_queue_hold(int hold_us, void *stream);
 int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                   int *idxs, void *stream);
 
+/* The same wrapper with a caller-provided workspace instead of `temp` (the reference's wrapper has no way to ask
+ * for more than its (b,n) floats: sampling.cpp:74-76): `work` = sig3d_fps_blocks_workspace_bytes(b, n) bytes,
+ * 16-byte aligned, contents irrelevant.  Scenes of 8193 .. 196 608 points then run as ONE workgroup per scene over
+ * a Morton-ordered copy held in L2 -- only the blocks a new sample can reach are swept -- instead of eight
+ * register-resident workgroups exchanging candidates through memory.  Same indices for any input
+ * (sampling_gpu.cu:69-173: same distance arithmetic, skip rule and tie order). */
+long sig3d_fps_blocks_workspace_bytes(int b, int n);
+int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const float *dataset, void *work, long work_bytes,
+                                         int *idxs, void *stream);
+
 /* Same wrapper, same results for ANY input, for the call sites whose `dataset` is itself the
  * output of an earlier FPS stored in pick order (SA level l+1 sampling the centres of level l,
  * pointnet2_modules.py:233-240 stacked four times in models/.../pointnet2 backbone).  FPS over
@@ -516,10 +526,7 @@ int sig3d_gather_table(int nchunks, const void *table, void *stream);
  *          writes C_slabs + (z-1)*slab_stride (+ i*stride_c, row stride ldc) and the CONSUMER adds the slabs while
  *          it loads them (sig3d_dropout_add_ln_fwd_slabs / _bwd_slabs): no atomics, no zero fill, no fold launch.
  *          act != 0 requires splits == 1.  sig3d_gemm16_splits proposes the count measured best on MI355X.
- * config : 0 = choose; 1 = 64x64 workgroup tiles (8 waves), 2 = 32x64 (4 waves), 3 = 64x128 (8 waves);
- *          11 / 12 = the same product on the bf16 matrix cores (csrc/gemmx6_core.h: every f32 operand split into
- *          three bf16 terms, six products, f32 accumulation -- f32-equivalent results, not a reduced precision):
- *          64x128 tiles of 8 waves / of 4 waves.  Never chosen by 0.
+ * config : 0 = choose; 1 = 64x64 workgroup tiles (8 waves), 2 = 32x64 (4 waves), 3 = 64x128 (8 waves).
  * k % 4 == 0, 16-byte aligned operand rows (n % 4 == 0 for bmode 1); every operand below 2 GB per batch element. */
 typedef struct sig3d_gemm16_problem {
   const float *A; int lda; long stride_a;

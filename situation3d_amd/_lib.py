@@ -19,6 +19,7 @@ _F = ctypes.c_float
 # name -> argtypes (restype is int status everywhere); order == include/sig3d_hip.h
 SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "sig3d_furthest_point_sampling_blocks": [_I, _I, _I, _P, _P, ctypes.c_long, _P, _P],
     "sig3d_furthest_point_sampling_nested": [_I, _I, _I, _P, _P, _P, _P, _P],
     "sig3d_fps_nested_chain": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_fps_timeout_count": [_P, _I],
@@ -275,7 +276,7 @@ def bq_levels_workspace_bytes(batch, arr):
     return int(load().sig3d_ball_query_levels_workspace_bytes(batch, len(arr), arr))
 
 
-INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes",
+INFO_SYMBOLS = ("sig3d_version", "sig3d_last_error", "sig3d_voxelize_workspace_bytes", "sig3d_fps_blocks_workspace_bytes",
                 "sig3d_ball_query_levels_workspace_bytes", "sig3d_pooled_heads_work_floats",
                 "sig3d_mlp_layer_dw_stream_work_floats", "sig3d_gemmp_work_floats")
 
@@ -303,6 +304,8 @@ def load():
         fn.restype = ctypes.c_int
     lib.sig3d_version.restype = ctypes.c_char_p
     lib.sig3d_last_error.restype = ctypes.c_char_p
+    lib.sig3d_fps_blocks_workspace_bytes.argtypes = [_I, _I]
+    lib.sig3d_fps_blocks_workspace_bytes.restype = ctypes.c_long
     lib.sig3d_voxelize_workspace_bytes.argtypes = [_I, ctypes.c_long, _I]
     lib.sig3d_voxelize_workspace_bytes.restype = ctypes.c_long
     lib.sig3d_ball_query_levels_workspace_bytes.argtypes = [_I, _I, ctypes.POINTER(BqLevel)]
@@ -354,6 +357,13 @@ def call(name, *args):
         rec.append((start, end, tuple(a for a in args if isinstance(a, int))))
     if status != 0:
         raise Sig3dError("%s failed: %s" % (name, lib.sig3d_last_error().decode()))
+
+
+def fps_workspace(b, n, device):
+    """Scratch of sig3d_furthest_point_sampling_blocks for (b, n): an uninitialised byte tensor (16-byte aligned by
+    the allocator)."""
+    need = int(load().sig3d_fps_blocks_workspace_bytes(int(b), int(n)))
+    return torch.empty(max(need, 16), dtype=torch.uint8, device=device)
 
 
 def fps_timeouts(reset=False):

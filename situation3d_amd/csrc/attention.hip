@@ -1269,13 +1269,13 @@ static int attention_bwd_impl(int b, int h, int nq, int nk, int d, int q_seg, in
                                      (size_t)(q_rows > q_extent ? q_rows : q_extent), stream));
     }
     constexpr size_t lds22 = attention_bwd_small_lds<2, 2>(), lds14 = attention_bwd_small_lds<1, 4>();
-    static bool small_attr = false;
-    if (!small_attr) {
+    static sig3d_once_per_device small_attr;
+    if (small_attr.pending()) {
       SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_small_kernel<2, 2>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds22));
       SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_small_kernel<1, 4>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds14));
-      small_attr = true;
+      small_attr.done();
     }
     if (self_like)
       hipLaunchKernelGGL((attention_bwd_small_kernel<2, 2>), dim3(h, 1, b), dim3(512), lds22, stream,
@@ -1325,15 +1325,15 @@ static int attention_bwd_impl(int b, int h, int nq, int nk, int d, int q_seg, in
   const int qsplit_max = (qchunk <= 64 && img + red_bytes <= 136 * 1024) ? 2 : 1;
   const size_t lds = img + (qsplit_max == 2 ? red_bytes : 0);
   SIG3D_REQUIRE(lds <= 136 * 1024, "attention backward: LDS budget exceeded");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static sig3d_once_per_device attr_done;
+  if (attr_done.pending()) {
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<64, true>,   // + 36 KB of static LDS
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)attention_bwd_kernel<96, false>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    attr_done = true;
+    attr_done.done();
   }
   // one query tile and whole key tiles per wave: the register-resident path (see the kernel)
   const bool oneqt = d == 64 && nq <= 32;

@@ -13,7 +13,6 @@
 // workgroups exist.
 #include <cstdlib>
 #include "gemm16_core.h"
-#include "gemmx6_core.h"
 #include "sig3d_common.h"
 
 namespace {
@@ -33,13 +32,6 @@ int choose_config(const sig3d_gemm16_problem &q) {
 }
 
 int choose_splits(const sig3d_gemm16_problem &q, int config) {
-  if (q.act == 0 && config >= 11) {    // 64 x 128 tiles: ~256 workgroups, at least 4 chunks each
-    const int t = tiles_of(q, 64, 128), chunks = sig3d_ceil_div(q.k, gemm16::BK);
-    int s = (256 + t / 2) / (t > 0 ? t : 1);
-    if (s > chunks / 4) s = chunks / 4;
-    if (s > 8) s = 8;
-    return s < 1 ? 1 : s;
-  }
   if (q.act != 0 || config != 1) return 1;
   const int t64 = tiles_of(q, 64, 64);
   const int chunks = sig3d_ceil_div(q.k, gemm16::BK);
@@ -279,8 +271,7 @@ extern "C" int sig3d_gemm16(const sig3d_gemm16_problem *qp, void *stream_) {
   SIG3D_REQUIRE(q.act != 2 || q.aux != nullptr, "act 2 needs the pre-activation matrix");
   SIG3D_REQUIRE(q.splits >= 1 && q.splits <= 64, "splits must be 1 .. 64 (sig3d_gemm16_splits proposes a count)");
   SIG3D_REQUIRE(q.splits == 1 || (q.act == 0 && q.C_slabs != nullptr), "a split product has no activation and needs slabs");
-  SIG3D_REQUIRE((q.config >= 0 && q.config <= 3) || q.config == 11 || q.config == 12,
-                "config must be 0 (choose) .. 3, or 11 / 12 (the bf16 x 6 core, gemmx6_core.h)");
+  SIG3D_REQUIRE(q.config >= 0 && q.config <= 3, "config must be 0 (choose) .. 3");
   if (q.batch == 0 || q.m == 0 || q.n == 0) return 0;
   // 16-byte requests: the k-contiguous operands need k % 4 == 0 and aligned rows, an n-contiguous B needs n % 4 == 0
   auto al = [](const void *p) { return ((size_t)p & 15) == 0; };
@@ -307,8 +298,6 @@ extern "C" int sig3d_gemm16(const sig3d_gemm16_problem *qp, void *stream_) {
   switch (choose_config(q)) {
     case 1: e = gemm16::launch<1, 2, 4, 2, 4, 2>(p, q.bmode, stream); break;
     case 2: e = gemm16::launch<1, 2, 2, 2, 4, 3>(p, q.bmode, stream); break;
-    case 11: e = gemmx6::launch<1, 1, 2, 4, 4>(p, q.bmode, stream); break;   // 64 x 128, 8 waves of 32 x 32
-    case 12: e = gemmx6::launch<1, 2, 2, 2, 4>(p, q.bmode, stream); break;   // 64 x 128, 4 waves of 32 x 64
     default: e = gemm16::launch<2, 2, 2, 4, 4, 1>(p, q.bmode, stream); break;
   }
   if (e != hipSuccess) {

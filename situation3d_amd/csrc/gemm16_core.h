@@ -23,9 +23,22 @@
 // Arithmetic: every product and sum in f32 (bitwise an fmaf chain per k slice, guide section 3).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <type_traits>
 
 namespace gemm16 {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is set per kernel AND per device: one of these per launch site
+struct OncePerDevice {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long current() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return 1ull << (d & 63);
+  }
+  bool pending() const { return !(mask.load(std::memory_order_acquire) & current()); }
+  void done() { mask.fetch_or(current(), std::memory_order_release); }
+};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -424,12 +437,12 @@ hipError_t launch(Problem p, int bmode, hipStream_t stream) {
 #define GEMM16_GO(BM, KE)                                                                                   \
   do {                                                                                                      \
     auto kern = gemm16_kernel<AB, BB, WGM, WGN, PF, OCC, BM, KE, DW>;                                       \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done && lds > 64 * 1024) {                                                                    \
+    static gemm16::OncePerDevice attr_done;                                                                 \
+    if (lds > 64 * 1024 && attr_done.pending()) {                                                           \
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                          (int)lds);                                                         \
       if (e != hipSuccess) return e;                                                                        \
-      attr_done = true;                                                                                     \
+      attr_done.done();                                                                                     \
     }                                                                                                       \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WGM * WGN), lds, stream, p);                             \
   } while (0)

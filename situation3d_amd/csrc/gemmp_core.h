@@ -506,12 +506,12 @@ hipError_t launch_modes(Problem p, hipStream_t stream) {
 #define GEMMP_GO(KE)                                                                                        \
   do {                                                                                                      \
     auto kern = gemmp_kernel<MB, NB, WGM, WGN, PF, OCC, AMODE, BMODE, KE>;                                  \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done && lds > 64 * 1024) {                                                                    \
+    static gemm16::OncePerDevice attr_done;                                                                 \
+    if (lds > 64 * 1024 && attr_done.pending()) {                                                           \
       hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                          (int)lds);                                                         \
       if (e != hipSuccess) return e;                                                                        \
-      attr_done = true;                                                                                     \
+      attr_done.done();                                                                                     \
     }                                                                                                       \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WGM * WGN), lds, stream, p);                             \
   } while (0)

@@ -563,8 +563,10 @@ extern "C" int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, 
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused: n must be >= 1 when idx is non-empty");
   const bool vec = (nsample % 4 == 0);
-  dim3 grid((unsigned)((long)sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS) *
-                       ((use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB)) * b));   // 1-D: xcd_local_scene
+  const long blocks = (long)sig3d_ceil_div(vec ? total / 4 : total, GP_THREADS) *
+                      ((use_xyz ? 1 : 0) + sig3d_ceil_div(c, GP_CSLAB)) * b;
+  SIG3D_REQUIRE(blocks < (1L << 31), "query_group_fused: more than 2^31 - 1 workgroups in the 1-D grid");
+  dim3 grid((unsigned)blocks);   // 1-D: xcd_local_scene
   // the vector path streams the grouped tensor out with nontemporal stores (+4 % on this kernel)
   if (vec)
     hipLaunchKernelGGL((query_group_fused_kernel<true, true>), grid, dim3(GP_THREADS), 0, stream, b, n, m, c,
@@ -596,7 +598,9 @@ static int launch_group_pm(int b, int n, int m, int c, int ld, int nsample, int 
   SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
   if (b == 0 || total == 0) return 0;
   SIG3D_REQUIRE(n >= 1, "query_group_fused_pm: n must be >= 1 when idx is non-empty");
-  dim3 grid((unsigned)(sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b));   // 1-D: xcd_local_scene
+  const long blocks = (long)sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b;
+  SIG3D_REQUIRE(blocks < (1L << 31), "query_group_fused_pm: more than 2^31 - 1 workgroups in the 1-D grid");
+  dim3 grid((unsigned)blocks);   // 1-D: xcd_local_scene
   if (n_act != nullptr)
     hipLaunchKernelGGL(query_group_fused_pm_kernel<true>, grid, dim3(GP_THREADS), 0, stream, b, n, m, c, ld, nsample,
                        use_xyz, normalize_xyz, radius, xyz, new_xyz, features_pm, idx, out, centre_of, n_act);
@@ -646,7 +650,9 @@ static int launch_group_grad_pm(int b, int n, int m, int c, int ld, int nsample,
   if (b == 0 || n == 0) return 0;
   if (!zeroed) SIG3D_HIP_TRY(hipMemsetAsync(grad_features_pm, 0, sizeof(float) * (size_t)b * n * ld, stream));
   if (total == 0) return 0;
-  dim3 grid((unsigned)(sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b));   // 1-D: xcd_local_scene
+  const long blocks = (long)sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(c, GPM_C) * b;
+  SIG3D_REQUIRE(blocks < (1L << 31), "group_points_grad_pm: more than 2^31 - 1 workgroups in the 1-D grid");
+  dim3 grid((unsigned)blocks);   // 1-D: xcd_local_scene
   hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, b, n, c, ld, (int)total, c_total,
                      c_off, grad_out, idx, grad_features_pm, n_act);
   SIG3D_LAUNCH_CHECK("group_points_grad_pm_kernel");

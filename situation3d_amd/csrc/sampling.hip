@@ -22,6 +22,8 @@
 // case return index 0 as the reference does (best = -1, besti = 0).
 #include "sig3d_common.h"
 
+#include <type_traits>
+
 #ifndef SIG3D_FPS_PROBE
 #define SIG3D_FPS_PROBE 0   // measurement builds only: 1 = the cooperative kernel sweeps half of a thread's points per round (wrong results); 2 = it claims 256 VGPRs a lane (same results); 3 = a round's sample coordinates are made up instead of loaded (wrong results; 3.49 -> 3.34 ms alone: the dependent load is 0.08 of a 1.72 us round)
 #endif
@@ -658,6 +660,8 @@ int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *tem
   unsigned short *order = nullptr;
   if (BLOCKED) {
     SIG3D_REQUIRE(n >= 512 && n <= 65535, "the blocked cooperative FPS numbers a scene's points in 16 bits (512 <= n <= 65535)");
+    SIG3D_REQUIRE((n + W * (NT / 64) - 1) / (W * (NT / 64)) <= PPT * 64,
+                  "the blocked cooperative FPS: a wave's block must fit its PPT x 64 register slots");
     order = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(temp) + sizeof(u64) * (size_t)b * FPS_SLOT_U64);
     hipLaunchKernelGGL(fps_morton_order_kernel, dim3(b), dim3(1024), 0, stream, n, dataset, order);
     SIG3D_LAUNCH_CHECK("fps_morton_order_kernel");
@@ -670,6 +674,306 @@ int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *tem
                        dataset, (u64 *)temp, idxs, order);
   SIG3D_LAUNCH_CHECK("fps_coop_kernel");
   return 0;
+}
+
+// ---- block-list FPS: ONE workgroup per scene, the scene in L2, only the blocks a sample can reach are swept --------
+// The cooperative kernel above keeps a scene in the registers of 8 workgroups: 64 CUs hold ~120 VGPRs a lane for
+// 3.4 ms of every step and every round pays a global-memory hop between them.  Its blocked form already showed that a
+// sample changes a small part of the scene after the first few dozen rounds.  Here that is the whole design:
+//   * a pre-pass (fps_blocks_sort_kernel) stores the scene along a Morton curve as {x, y, z, tie key} rows; a block is
+//     64 * PPL consecutive rows (625 blocks of 64 at n = 40 000); the running distances live beside them in global
+//     memory -- 800 KB per scene, resident in the XCD's L2 (workgroup i lands on XCD i mod 8);
+//   * lane l of wave w MANAGES block l * NW + w: its box, its largest running distance, the tie key and the coordinates
+//     of the point that holds it -- all in that lane's registers (11 VGPRs), nothing of it in LDS;
+//   * a round: every lane tests the new sample against its block's box (the blocked kernel's test, same margin); a
+//     wave sweeps the blocks of its own lanes that can change (ballot -> scalar loop; one point per lane and row, the
+//     loads of up to four blocks in flight), reduces each (max distance, then min key: the reference's total order)
+//     and hands the result to the managing lane; the wave's candidate {value, key, x, y, z} goes to LDS, ONE barrier,
+//     every wave reduces the NW candidates itself.  The next sample's coordinates come with the candidate: no
+//     dependent global load, no exchange between CUs.
+// Waves only touch the running distances of their own blocks, so no memory ordering between waves is needed, and the
+// barrier waits for the LDS write only (the distance stores drain behind it).  Same indices as every other kernel of
+// this file: the same individually rounded distance, min, skip rule and (value, key) order; a block that sits a round
+// out holds exactly what a sweep would have left.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wave_allreduce_fmin(float v) {
+  v = fminf(v, dpp_f32<0xB1>(v)); v = fminf(v, dpp_f32<0x4E>(v)); v = fminf(v, dpp_f32<0x141>(v)); v = fminf(v, dpp_f32<0x140>(v));
+  return fminf(fminf(readlane_f32(v, 0), readlane_f32(v, 16)), fminf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+__device__ __forceinline__ float wave_allreduce_fmax(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0x141>(v)); v = fmaxf(v, dpp_f32<0x140>(v));
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+
+constexpr unsigned FPSB_NOKEY = 0xFFFFFFFFu;
+
+// Morton order of the scene (the grid of fps_morton_order_kernel) written out as rows {x, y, z, key}; rows [n, n_pad)
+// are padding (key = FPSB_NOKEY: never take part).  Which of a cell's points comes first is left to the atomics.
+__global__ __launch_bounds__(1024) void fps_blocks_sort_kernel(int n, int n_pad, int L,
+                                                               const float *__restrict__ dataset_all,
+                                                               float4 *__restrict__ rows_all) {
+  __shared__ int s_bin[FPS_CELLS];
+  __shared__ float s_box[6][16];
+  __shared__ int s_scan[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *dataset = dataset_all + (size_t)blockIdx.x * n * 3;
+  float4 *rows = rows_all + (size_t)blockIdx.x * n_pad;
+  const unsigned bsmask = (1u << L) - 1u;
+  float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+  for (int k = tid; k < n; k += 1024) {
+    const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+    ax = fminf(ax, x); ay = fminf(ay, y); az = fminf(az, z);
+    bx = fmaxf(bx, x); by = fmaxf(by, y); bz = fmaxf(bz, z);
+  }
+  ax = wave_allreduce_fmin(ax); ay = wave_allreduce_fmin(ay); az = wave_allreduce_fmin(az);
+  bx = wave_allreduce_fmax(bx); by = wave_allreduce_fmax(by); bz = wave_allreduce_fmax(bz);
+  if (lane == 0) {
+    s_box[0][wave] = ax; s_box[1][wave] = ay; s_box[2][wave] = az;
+    s_box[3][wave] = bx; s_box[4][wave] = by; s_box[5][wave] = bz;
+  }
+  for (int i = tid; i < FPS_CELLS; i += 1024) s_bin[i] = 0;
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    ax = fminf(ax, s_box[0][i]); ay = fminf(ay, s_box[1][i]); az = fminf(az, s_box[2][i]);
+    bx = fmaxf(bx, s_box[3][i]); by = fmaxf(by, s_box[4][i]); bz = fmaxf(bz, s_box[5][i]);
+  }
+  const float sx = 32.f / (bx - ax), sy = 32.f / (by - ay), sz = 8.f / (bz - az);
+  auto cell_of = [&](float x, float y, float z) {   // NaN, infinities and a flat box land in a valid cell
+    const unsigned ix = (unsigned)fminf(fmaxf((x - ax) * sx, 0.f), 31.f);
+    const unsigned iy = (unsigned)fminf(fmaxf((y - ay) * sy, 0.f), 31.f);
+    const unsigned iz = (unsigned)fminf(fmaxf((z - az) * sz, 0.f), 7.f);
+    const unsigned hx = ix >> 3, hy = iy >> 3;
+    const unsigned hi = (hx & 1u) | ((hy & 1u) << 1) | ((hx & 2u) << 1) | ((hy & 2u) << 2);
+    return (int)(fps_spread3(ix & 7u) | (fps_spread3(iy & 7u) << 1) | (fps_spread3(iz) << 2) | (hi << 9));
+  };
+  for (int k = tid; k < n; k += 1024)
+    atomicAdd(&s_bin[cell_of(dataset[3 * k + 0], dataset[3 * k + 1], dataset[3 * k + 2])], 1);
+  __syncthreads();
+  constexpr int CPT = FPS_CELLS / 1024;
+  int c[CPT], sum = 0;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) { c[i] = s_bin[tid * CPT + i]; sum += c[i]; }
+  int inc = sum;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  int base = inc - sum;
+  for (int i = 0; i < wave; ++i) base += s_scan[i];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) { s_bin[tid * CPT + i] = base; base += c[i]; }
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) {
+    const float x = dataset[3 * k + 0], y = dataset[3 * k + 1], z = dataset[3 * k + 2];
+    const int pos = atomicAdd(&s_bin[cell_of(x, y, z)], 1);
+    if (pos >= 0 && pos < n)
+      rows[pos] = make_float4(x, y, z, __builtin_bit_cast(float, fps_key((unsigned)k, L, bsmask)));
+  }
+  for (int k = n + tid; k < n_pad; k += 1024) rows[k] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, FPSB_NOKEY));
+}
+
+template <int NW, int MB, int PPL>
+__global__ __launch_bounds__(NW * 64) void fps_blocks_kernel(int n, int n_pad, int m, int L,
+                                                             const float *__restrict__ dataset_all,
+                                                             const float4 *__restrict__ rows_all,
+                                                             float *__restrict__ dist_all,
+                                                             int *__restrict__ idxs_all) {
+  constexpr int BP = 64 * PPL;
+  static_assert(NW == 4 || NW == 8 || NW == 16, "the candidates of all waves are reduced inside a 16-lane row");
+  __shared__ int s_part[2][NW][8];   // a wave's candidate: value bits, key, x, y, z
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *dataset = dataset_all + (size_t)blockIdx.x * n * 3;
+  const float4 *rows = rows_all + (size_t)blockIdx.x * n_pad;
+  float *dist = dist_all + (size_t)blockIdx.x * n_pad;
+  int *idxs = idxs_all + (size_t)blockIdx.x * m;
+  const int nb = n_pad / BP;
+  // wave w owns blocks w, w + NW, ...: its i-th block is MANAGED by slot i / 64 of lane i % 64 (i < mine <= 64 MB)
+  const int mine = (nb - wave + NW - 1) / NW;
+
+  // the reduction of one block's rows: largest running distance, lowest key among its holders, that point's coordinates
+  struct Cand { int v; unsigned k; float x, y, z; };
+  auto reduce_block = [&](const float4 (&p)[PPL], const float (&t)[PPL]) {
+    float best = t[0];
+    unsigned bk = __builtin_bit_cast(unsigned, p[0].w);
+    float x = p[0].x, y = p[0].y, z = p[0].z;
+#pragma unroll
+    for (int q = 1; q < PPL; ++q) {
+      const unsigned kq = __builtin_bit_cast(unsigned, p[q].w);
+      const bool gt = t[q] > best || (t[q] == best && kq < bk);
+      best = gt ? t[q] : best; bk = gt ? kq : bk;
+      x = gt ? p[q].x : x; y = gt ? p[q].y : y; z = gt ? p[q].z : z;
+    }
+    const int myv = __builtin_bit_cast(int, best);   // >= 0 or -1: ordered as signed integers
+    Cand c;
+    c.v = wave_allreduce_max_i32(myv);
+    c.k = wave_allreduce_min_u32(myv == c.v ? bk : FPSB_NOKEY);
+    const unsigned long long holders = __builtin_amdgcn_ballot_w64(myv == c.v && bk == c.k);
+    const int wl = (int)__builtin_ctzll(holders | (1ull << 63));
+    c.x = readlane_f32(x, wl); c.y = readlane_f32(y, wl); c.z = readlane_f32(z, wl);
+    return c;
+  };
+
+  // ---- prologue: running distances (1e10, or -1 for the points that never take part), boxes, first candidates
+  int bval[MB];
+  unsigned bkey[MB];
+  float cx[MB], cy[MB], cz[MB], lo_x[MB], lo_y[MB], lo_z[MB], hi_x[MB], hi_y[MB], hi_z[MB];
+#pragma unroll
+  for (int s = 0; s < MB; ++s) {
+    bval[s] = (int)0x80000000; bkey[s] = FPSB_NOKEY;
+    cx[s] = cy[s] = cz[s] = lo_x[s] = lo_y[s] = lo_z[s] = hi_x[s] = hi_y[s] = hi_z[s] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < MB; ++s) {
+    for (int i = s * 64; i < min(mine, (s + 1) * 64); ++i) {
+      const size_t base = (size_t)(i * NW + wave) * BP;
+      float4 p[PPL];
+      float t[PPL];
+      float ax = 3.0e38f, ay = 3.0e38f, az = 3.0e38f, bx = -3.0e38f, by = -3.0e38f, bz = -3.0e38f;
+#pragma unroll
+      for (int q = 0; q < PPL; ++q) {
+        p[q] = rows[base + q * 64 + lane];
+        const float mag = __fadd_rn(__fadd_rn(__fmul_rn(p[q].x, p[q].x), __fmul_rn(p[q].y, p[q].y)), __fmul_rn(p[q].z, p[q].z));
+        const bool pad = __builtin_bit_cast(unsigned, p[q].w) == FPSB_NOKEY;
+        t[q] = (pad || (double)mag <= 1e-3) ? -1.f : 1e10f;  // sampling_gpu.cu:100-101, sampling.cpp:74-76
+        dist[base + q * 64 + lane] = t[q];
+        if (t[q] >= 0.f) {
+          ax = fminf(ax, p[q].x); ay = fminf(ay, p[q].y); az = fminf(az, p[q].z);
+          bx = fmaxf(bx, p[q].x); by = fmaxf(by, p[q].y); bz = fmaxf(bz, p[q].z);
+        }
+      }
+      ax = wave_allreduce_fmin(ax); ay = wave_allreduce_fmin(ay); az = wave_allreduce_fmin(az);
+      bx = wave_allreduce_fmax(bx); by = wave_allreduce_fmax(by); bz = wave_allreduce_fmax(bz);
+      const Cand c = reduce_block(p, t);
+      if (lane == i - s * 64) {
+        bval[s] = c.v; bkey[s] = c.k; cx[s] = c.x; cy[s] = c.y; cz[s] = c.z;
+        lo_x[s] = ax; lo_y[s] = ay; lo_z[s] = az; hi_x[s] = bx; hi_y[s] = by; hi_z[s] = bz;
+      }
+    }
+  }
+
+  // the wave's candidate over its managed blocks, with its coordinates, in every lane (wave-uniform)
+  int pub_v = (int)0x80000000;
+  unsigned pub_k = FPSB_NOKEY;
+  float pub_x = 0.f, pub_y = 0.f, pub_z = 0.f;
+  auto refresh_candidate = [&]() {
+    int v = bval[0];
+    unsigned k = bkey[0];
+    float x = cx[0], y = cy[0], z = cz[0];
+#pragma unroll
+    for (int s = 1; s < MB; ++s) {
+      const bool gt = bval[s] > v || (bval[s] == v && bkey[s] < k);
+      v = gt ? bval[s] : v; k = gt ? bkey[s] : k;
+      x = gt ? cx[s] : x; y = gt ? cy[s] : y; z = gt ? cz[s] : z;
+    }
+    pub_v = wave_allreduce_max_i32(v);
+    pub_k = wave_allreduce_min_u32(v == pub_v ? k : FPSB_NOKEY);
+    const int wl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(v == pub_v && k == pub_k) | (1ull << 63));
+    pub_x = readlane_f32(x, wl); pub_y = readlane_f32(y, wl); pub_z = readlane_f32(z, wl);
+  };
+  refresh_candidate();
+
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  if (tid == 0) idxs[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    bool swept = false;
+#pragma unroll
+    for (int s = 0; s < MB; ++s) {
+      // which of my blocks can this sample change?  (the blocked cooperative kernel's test: squared distance to the
+      // box, shrunk by more than any rounding of either side; NaN compares false and sweeps)
+      const float ex = fmaxf(fmaxf(lo_x[s] - x1, x1 - hi_x[s]), 0.f), ey = fmaxf(fmaxf(lo_y[s] - y1, y1 - hi_y[s]), 0.f);
+      const float ez = fmaxf(fmaxf(lo_z[s] - z1, z1 - hi_z[s]), 0.f);
+      const float d_box = (ex * ex + ey * ey + ez * ez) * 0.99998f;
+      const bool sit_out = bval[s] < 0 || d_box > __builtin_bit_cast(float, bval[s]);
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(!sit_out && s * 64 + lane < mine);
+      swept |= todo != 0;
+
+      auto sweep = [&](auto ucount) {
+        constexpr int U = decltype(ucount)::value;
+        int bi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          bi[u] = (int)__builtin_ctzll(todo);
+          todo &= todo - 1;
+        }
+        float4 p[U][PPL];
+        float t[U][PPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const size_t base = (size_t)((s * 64 + bi[u]) * NW + wave) * BP;
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) {
+            p[u][q] = rows[base + q * 64 + lane];
+            t[u][q] = dist[base + q * 64 + lane];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const size_t base = (size_t)((s * 64 + bi[u]) * NW + wave) * BP;
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) {
+            const float d = sq_dist3(p[u][q].x, p[u][q].y, p[u][q].z, x1, y1, z1);
+            const float tn = fminf(d, t[u][q]);
+            if (tn != t[u][q]) dist[base + q * 64 + lane] = tn;
+            t[u][q] = tn;
+          }
+          const Cand c = reduce_block(p[u], t[u]);
+          if (lane == bi[u]) { bval[s] = c.v; bkey[s] = c.k; cx[s] = c.x; cy[s] = c.y; cz[s] = c.z; }
+        }
+      };
+      while (__builtin_popcountll(todo) >= 4) sweep(std::integral_constant<int, 4>{});
+      if (__builtin_popcountll(todo) >= 2) sweep(std::integral_constant<int, 2>{});
+      while (todo) sweep(std::integral_constant<int, 1>{});
+    }
+    if (swept) refresh_candidate();
+
+    const int par = j & 1;
+    if (lane == 0) {
+      s_part[par][wave][0] = pub_v;
+      s_part[par][wave][1] = (int)pub_k;
+      s_part[par][wave][2] = __builtin_bit_cast(int, pub_x);
+      s_part[par][wave][3] = __builtin_bit_cast(int, pub_y);
+      s_part[par][wave][4] = __builtin_bit_cast(int, pub_z);
+    }
+    // the barrier orders the LDS candidates only: running distances are private to their wave, and their stores
+    // may still be in flight behind it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+
+    const int *sp = s_part[par][lane & (NW - 1)];
+    const int ov = sp[0];
+    const unsigned ok = (unsigned)sp[1];
+    const float ox = __builtin_bit_cast(float, sp[2]), oy = __builtin_bit_cast(float, sp[3]), oz = __builtin_bit_cast(float, sp[4]);
+    const int gv = row_allreduce_max_i32(ov);
+    const unsigned gk = row_allreduce_min_u32(ov == gv ? ok : FPSB_NOKEY);
+    const int gvu = __builtin_amdgcn_readfirstlane(gv);
+    const unsigned gku = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
+    if (gvu < 0) {
+      // nothing takes part (every point within the skip rule): the reference returns index 0 for every round
+      for (int jj = j + tid; jj < m; jj += NW * 64) idxs[jj] = 0;
+      return;
+    }
+    const int gl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(ov == gvu && ok == gku) | (1ull << 63));
+    x1 = readlane_f32(ox, gl); y1 = readlane_f32(oy, gl); z1 = readlane_f32(oz, gl);
+    if (tid == 0) idxs[j] = (int)fps_unkey(gku, L);
+  }
+}
+
+// rows of a scene in the block-list workspace: whole blocks, at most 64 * FPSB_NW of them
+static int fpsb_points_per_lane(int n) { return n <= 65536 ? 1 : n <= 131072 ? 2 : 3; }
+static long fpsb_padded(int n) {
+  const long bp = 64L * fpsb_points_per_lane(n);
+  return (n + bp - 1) / bp * bp;
 }
 
 // ---- gather_points: out[b,c,j] = points[b,c,idx[b,j]] ---------------------------------------
@@ -791,6 +1095,53 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
     return 0;
   }
   return launch_fps<1024, 24>(b, n, m, L, dataset, temp, idxs, stream);  // global-memory tail
+}
+
+// FPS with a caller-provided workspace (sig3d_fps_blocks_workspace_bytes): scenes of 8193 .. 196 608 points run the
+// block-list kernel -- one workgroup per scene instead of the cooperative kernel's eight -- every other size the kernels
+// of sig3d_furthest_point_sampling with the workspace as their `temp`.  Same indices for any input.
+extern "C" long sig3d_fps_blocks_workspace_bytes(int b, int n) {
+  if (b < 0 || n < 0) return -1;
+  return (long)b * fpsb_padded(n) * (long)(sizeof(float4) + sizeof(float));
+}
+
+extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const float *dataset, void *work,
+                                                    long work_bytes, int *idxs, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+  if (b == 0 || m <= 0) return 0;  // sampling_gpu.cu:73
+  SIG3D_REQUIRE(n >= 1, "furthest_point_sampling needs n >= 1");
+  SIG3D_REQUIRE(work != nullptr && work_bytes >= sig3d_fps_blocks_workspace_bytes(b, n),
+                "workspace smaller than sig3d_fps_blocks_workspace_bytes(b, n)");
+  SIG3D_REQUIRE(((uintptr_t)work & 15u) == 0, "workspace must be 16-byte aligned");
+  if (n <= 8192 || n > 196608)
+    return sig3d_furthest_point_sampling(b, n, m, dataset, (float *)work, idxs, stream_);
+  const int L = ref_opt_n_threads_log2(n);
+  const int ppl = fpsb_points_per_lane(n);
+  const long n_pad = fpsb_padded(n);
+  const long nblocks = n_pad / (64 * ppl);
+  float4 *rows = (float4 *)work;
+  float *dist = (float *)(rows + (size_t)b * n_pad);
+  hipLaunchKernelGGL(fps_blocks_sort_kernel, dim3(b), dim3(1024), 0, stream, n, (int)n_pad, L, dataset, rows);
+  SIG3D_LAUNCH_CHECK("fps_blocks_sort_kernel");
+  // waves per scene x managed blocks per lane (SIG3D_FPS_BLOCKS_SHAPE: 0 = 16 x 1, 1 = 8 x 2, 2 = 4 x 4): what the
+  // workgroup holds of its CU is what the training step's kernels cannot use there
+  const char *shape = getenv("SIG3D_FPS_BLOCKS_SHAPE");
+  const int sh = shape ? atoi(shape) : 0;
+#define SIG3D_FPSB(NWV, MBV, PPLV)                                                                                  \
+  do {                                                                                                              \
+    SIG3D_REQUIRE(nblocks <= 64L * NWV * MBV, "block-list FPS: more blocks than managing lanes");                    \
+    hipLaunchKernelGGL((fps_blocks_kernel<NWV, MBV, PPLV>), dim3(b), dim3(NWV * 64), 0, stream, n, (int)n_pad, m, L,  \
+                       dataset, rows, dist, idxs);                                                                  \
+  } while (0)
+  if (ppl == 1 && sh == 1) SIG3D_FPSB(8, 2, 1);
+  else if (ppl == 1 && sh == 2) SIG3D_FPSB(4, 4, 1);
+  else if (ppl == 1) SIG3D_FPSB(16, 1, 1);
+  else if (ppl == 2) SIG3D_FPSB(16, 1, 2);
+  else SIG3D_FPSB(16, 1, 3);
+#undef SIG3D_FPSB
+  SIG3D_LAUNCH_CHECK("fps_blocks_kernel");
+  return 0;
 }
 
 // the segmented check from 256 rounds (8 threads per point); below, the plain one (SIG3D_FPS_CHECK_SEG=0: always)

@@ -1357,11 +1357,11 @@ static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, co
   constexpr int CT = 32 * NT;
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
   const size_t lds = sizeof(float) * ((size_t)CT * ldw + 2 * kpad + ML_WAVES * 2 * CT + ML_WAVES * 16 * ML_TRLD);
-  static bool attr_done = false;  // per template instance
-  if (!attr_done) {
+  static sig3d_once_per_device attr_done;  // per template instance
+  if (attr_done.pending()) {
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_layer_fwd_kernel<NT, PROLOGUE, VEC, RAGGED, GATHER, SCATTER>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.done();
   }
   // one full round of resident workgroups: occupancy per CU from LDS and registers (168 / 134 /
   // 120 VGPRs for NT = 4 / 2 / 1 -> 3 / 3 / 4 waves per SIMD), 256 CUs
@@ -1756,10 +1756,10 @@ extern "C" int sig3d_mlp_layer_dw_dx(int b, int cin, int cout, long e, const flo
   const int tpw = (int)((wave_tiles + gy * ML_WAVES - 1) / (gy * ML_WAVES));
   const size_t lds_dw = gemm16::lds_bytes<1, 2, 4, 2>();
   const size_t lds = lds_mlp > lds_dw ? lds_mlp : lds_dw;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static sig3d_once_per_device attr_done;
+  if (attr_done.pending()) {
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)mlp_dw_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done = true;
+    attr_done.done();
   }
   const long blocks = (long)n_dw + (long)cblocks * gy * b;
   hipLaunchKernelGGL(mlp_dw_dx_kernel, dim3((unsigned)blocks), dim3(512), lds, stream, p, n_dw, cblocks, (int)gy, cin_k, cout_k,

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/sig3d_hip.h"
 #include "../../include/sig3d_debug.h"
 
@@ -38,6 +40,20 @@ void sig3d_set_error_msg(const char *where, const char *msg);
   } while (0)
 
 static inline int sig3d_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON ONE DEVICE: a process that drives a second GPU
+// must set it there too.  One of these per call site: `pending()` is true until `done()` was called for the CURRENT device
+// (a bit per device id; two threads racing set the attribute twice, which is harmless).
+struct sig3d_once_per_device {
+  std::atomic<uint64_t> mask{0};
+  static uint64_t current() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return 1ull << (d & 63);
+  }
+  bool pending() const { return !(mask.load(std::memory_order_acquire) & current()); }
+  void done() { mask.fetch_or(current(), std::memory_order_release); }
+};
 
 // ---- exact f32 arithmetic ----------------------------------------------------------------
 // The parity contract (oracle/pointnet2_oracle.c header) is "every * and +/- individually

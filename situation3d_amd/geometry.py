@@ -61,6 +61,7 @@ class GeometryPlan:
         self.batch, self.n_points = batch, n_points
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
+        self._fps_work = None   # scratch of the block-list FPS (level 0, scenes above 8192 points)
         self._bq_work = None    # scratch of the multi-level ball query (allocated once: static under hipGraph)
         self._bq_clean = False  # True once the workspace has been through a call (counters zero again)
         self._bq_levels = None  # its level table (ctypes array of sig3d_bq_level: raw pointers of the plan's buffers)
@@ -98,7 +99,12 @@ class GeometryPlan:
                     srcs.append(cur)
                     cur, n = self.new_xyz[lvl], npoint
                     continue
-                if lvl == 0 or not NESTED_FPS:
+                if (lvl == 0 or not NESTED_FPS) and _ext.FPS_BLOCKS and n > 8192:
+                    if self._fps_work is None:
+                        self._fps_work = _lib.fps_workspace(b, n, dev)
+                    _lib.call("sig3d_furthest_point_sampling_blocks", b, n, npoint, _lib.ptr(cur),
+                              _lib.ptr(self._fps_work), self._fps_work.numel(), _lib.ptr(self.inds[lvl]), s)
+                elif lvl == 0 or not NESTED_FPS:
                     _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
                               _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
                 else:

@@ -15,8 +15,8 @@ a latency-bound chain that keeps a handful of CUs busy for milliseconds.  With
 batch i (reading the plan computed during the previous call) runs: the chain is a hipGraph of its
 own on a stream of its own (geometry.GeometryPipeline) beside the step's graph, which stays ONE
 linear chain, and the fresh plan is handed over at the start of the next call.  (Rounds 1-2 forked
-the chain inside the step's graph and joined it at the end: SIG3D_GEO_FORK=inline, slower, see
-DESIGN.md section 4e.)  Every step still performs the full work of one batch (one geometry chain +
+the chain inside the step's graph and joined it at the end: slower; removed
+in round 6.)  Every step still performs the full work of one batch (one geometry chain +
 one training pass); only the order is pipelined, like a data loader running one batch ahead.  The
 plan is bit-identical to computing it inline.
 
@@ -97,7 +97,7 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, example_batch, max_grad_value=1.0, warmup=3,
                  prefetch_geometry=False, geometry_levels=None, reducer=None, split_backward=True,
-                 prefetch_depth=None, update_beside=None):
+                 prefetch_depth=None, qf_cut=None):
         """`reducer` (ddp.GradBucketReducer, data parallel): the step becomes graph A (forward +
         backward, gradients accumulated into the reducer's flat buckets) -> eager bucketed RCCL
         all-reduce -> graph B (value clip + AdamW).  No collective is ever captured."""
@@ -117,36 +117,25 @@ class GraphedTrainStep:
             if getattr(optimizer, "process_group", None) is None:
                 optimizer.process_group = reducer.group   # liveness agreed on the reducer's group from the first gather on
         self.prefetch = bool(prefetch_geometry)
-        # Where the geometry chains run.  Default: geometry.GeometryPipeline -- the chains of the next
-        # `prefetch_depth` batches (default 1; bench.py runs 3) as graphs of their own on streams of their own, beside
-        # the step's graph, which stays ONE linear chain.  SIG3D_GEO_FORK=inline (single GPU only): rounds 1-2's
-        # branch forked inside the step's graph and joined at its end -- every kernel node enqueued while another
-        # queue holds a blocked barrier costs ~1.7 us extra on this runtime (tools/probes/fork_penalty.py).
-        self._geo_inline = bool(self.prefetch and reducer is None and os.environ.get("SIG3D_GEO_FORK", "graph") == "inline")
-        self.prefetch_depth = 1 if self._geo_inline or not self.prefetch else max(1, int(prefetch_depth or 1))
+        # The geometry chains of the next `prefetch_depth` batches (default 1; bench.py runs 3) are graphs of their own
+        # on streams of their own (geometry.GeometryPipeline) beside the step's graph, which stays ONE linear chain:
+        # every kernel node enqueued while another queue holds a blocked barrier costs ~1.7 us extra on this runtime
+        # (tools/probes/fork_penalty.py), which is what a branch forked inside the step's graph paid.
+        self.prefetch_depth = 1 if not self.prefetch else max(1, int(prefetch_depth or 1))
         self._pipe = None
-        self._primed = False
-        self._announced = Announced()
         params =[p for p in model.parameters() if p.requires_grad]
 
         if self.prefetch:
             pc = self.static_batch["point_clouds"]
             b, n = pc.shape[0], pc.shape[1]
             levels = geometry_levels or model.encoder.LEVELS
-            if self._geo_inline:
-                self.plan_cur = GeometryPlan(b, n, levels, pc.device)
-                self.plan_next = GeometryPlan(b, n, levels, pc.device)
-                self.static_next_xyz = pc[..., :3].contiguous()
-                self.side = torch.cuda.Stream(pc.device)
-                self.plan_cur.copy_from(self.plan_next)      # builds the hand-over's copy table OUTSIDE any capture
-            else:
-                self._pipe = GeometryPipeline(b, n, levels, pc.device, stream, depth=self.prefetch_depth,
-                                              handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0",
-                                              example_xyz=pc[..., :3])
-                self.plan_cur = self._pipe.plan_cur
-                if reducer is not None:
-                    from . import ddp
-                    ddp._OWN_BESIDE.extend(sl["stream"] for sl in self._pipe.slots)   # own-stream collectives: other queues
+            self._pipe = GeometryPipeline(b, n, levels, pc.device, stream, depth=self.prefetch_depth,
+                                          handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0",
+                                          example_xyz=pc[..., :3])
+            self.plan_cur = self._pipe.plan_cur
+            if reducer is not None:
+                from . import ddp
+                ddp._OWN_BESIDE.extend(sl["stream"] for sl in self._pipe.slots)   # own-stream collectives: other queues
             self.plan_cur.compute(pc[..., :3].contiguous())  # geometry of the example batch
 
         def fwd_bwd():
@@ -187,7 +176,7 @@ class GraphedTrainStep:
                 leaves = [self._boundary[1]] + ([self._qf_boundary[1]] if self._qf_boundary is not None else [])
                 loss.backward(inputs=self._upper_params + leaves)
                 _flush_deferred(model)   # weight gradients of the layers above the cut (qformer._WeightGradArena)
-                optimizer.gather_grads(slot=0, zero=True)
+                optimizer.gather_grads(zero=True)
             except BaseException:
                 STEP_ZEROS.end_step()    # a step that died must not leave the zero region open for whoever runs next
                 raise
@@ -199,7 +188,7 @@ class GraphedTrainStep:
             hidden, leaf = self._qf_boundary
             hidden.backward(leaf.grad, inputs=self._lower_params + [self._boundary[1]])
             _flush_deferred(model)
-            optimizer.gather_grads(slot=1, zero=False)
+            optimizer.gather_grads(zero=False)
             self._qf_boundary = None
 
         def bwd_encoder():
@@ -207,7 +196,7 @@ class GraphedTrainStep:
             try:
                 tokens, leaf = self._boundary
                 tokens.backward(leaf.grad)
-                optimizer.gather_grads(slot=2, zero=False)
+                optimizer.gather_grads(zero=False)
                 self._boundary = None
             finally:
                 STEP_ZEROS.end_step()
@@ -225,16 +214,17 @@ class GraphedTrainStep:
                 and hasattr(model, "encoder") and hasattr(model, "Qformer")):
             from .ddp import GradBucketReducer
             layers = list(model.Qformer.bert.encoder.layer)
-            # SIG3D_QF_CUT=k (default 0 = off): also cut the backward after Q-Former layer k (third graph / gather /
-            # bucket set), so that the upper layers' gradients travel under the lower layers' backward.  Since the
-            # deferred weight gradients are written straight into the flat gradient buffers (kind-major parameter
-            # order, qformer.parameter_adjacency_groups) the layers above and below a cut INTERLEAVE in storage:
-            # the two bucket sets fall into dozens of small slices, and the cut costs ~1 ms per step at world size
-            # 1 (8.6 -> 9.5 ms) -- more than the 1.4 ms earlier start of the exchange can return even on the
-            # single xGMI link of a 2-GPU run.  Opt-in only.
-            cut = 0
-            if getattr(model.Qformer.bert, "segmented_layout", False) and len(layers) >= 2:
-                cut = max(0, min(int(os.environ.get("SIG3D_QF_CUT", "0")), len(layers) - 1))
+            # qf_cut = k: also cut the backward after Q-Former layer k (third graph / gather / bucket set), so that the
+            # upper layers' gradients travel under the lower layers' backward.  The deferred weight gradients are
+            # written straight into the flat gradient buffers, so the cut is only cheap when the optimizer stores the
+            # layers below and above it as two arenas (trainer.build_optimizer(qf_cut=k) -> encoder.storage_cut, the
+            # default here): over ONE kind-major arena the two pieces interleave kind by kind and fall into dozens of
+            # small collectives and AdamW launches (+0.95 ms per step at world size 1).
+            enc_mod = model.Qformer.bert.encoder
+            cut = qf_cut if qf_cut is not None else (getattr(enc_mod, "storage_cut", None) or 0)
+            if not getattr(model.Qformer.bert, "segmented_layout", False) or len(layers) < 2:
+                cut = 0
+            cut = max(0, min(int(cut), len(layers) - 1))
             up_mods = layers[cut:] + [model.position_head, model.rotation_head, model.aux_reg, model.answer_cls]
             upper = [p for mod in up_mods for p in mod.parameters() if p.requires_grad]
             up_ids = {id(p) for p in upper}
@@ -266,8 +256,6 @@ class GraphedTrainStep:
                 self._red_enc = GradBucketReducer.from_flat(parts[2], process_group=reducer.group)
                 self.graph_low = torch.cuda.CUDAGraph() if lower else None
                 self.graph_enc = torch.cuda.CUDAGraph()
-                optimizer._tables(1)   # later gathers' staging buffers: pinned allocation is illegal in capture
-                optimizer._tables(2)
                 self._split = True
 
         if reducer is not None and fused_opt and hasattr(model, "Qformer"):
@@ -303,74 +291,20 @@ class GraphedTrainStep:
         # they are harmless to this capture, so only police the capturing thread
         import torch.distributed as dist
         cap_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
-        # Single GPU, flat optimizer: the update of everything above the scene tokens (the Q-Former and the heads: 99 % of
-        # the parameters, 0.95 ms of streaming) runs on a stream of its own WHILE the point encoder's backward pass runs --
-        # the first is bound by HBM, the second by latency.  Two graphs (forward + upper backward | encoder backward +
-        # its own small update), one eager AdamW launch between them on the side stream, events at the graph boundaries
-        # (no cross-queue barrier is pending while a graph's kernels are enqueued: tools/probes/fork_penalty.py).
-        if update_beside is None:
-            update_beside = os.environ.get("SIG3D_UPDATE_BESIDE", "0") != "0"
-        self._beside = bool(update_beside and reducer is None and fused_opt and not self._geo_inline
-                            and hasattr(model, "encoder") and hasattr(model, "Qformer"))
-        if self._beside:
-            enc_ids = {id(p) for p in model.encoder.parameters()} | {id(p) for p in model.pos_embed.parameters()}
-            self._upper_params = [p for p in params if id(p) not in enc_ids]
-            self._lower_params = [p for p in params if id(p) in enc_ids]
-            self._side_opt = torch.cuda.Stream(stream.device)
-            self._beside_wgs = int(os.environ.get("SIG3D_UPDATE_BESIDE_WGS", "192"))   # workgroups of the side update
-            self._ev_a, self._ev_u = torch.cuda.Event(), torch.cuda.Event()
-            self.graph_enc = torch.cuda.CUDAGraph()
-            optimizer._tables(1)      # staging buffers of the two parts: pinned allocation is illegal in capture
-            optimizer._tables(2)
-            try:
-                with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
-                    timeline.mark("main:start")
-                    batch = dict(self.static_batch)
-                    batch["_split_backward"] = True
-                    batch["_qf_cut"] = None
-                    if self.prefetch:
-                        batch["geometry_plan"] = self.plan_cur
-                    STEP_ZEROS.begin_step(batch["point_clouds"].device, grads_ok=True)     # closed in the second graph
-                    out = model(batch)
-                    self._boundary = out.pop("_boundary")
-                    out.pop("_qf_boundary", None)
-                    out.pop("_split_backward", None)
-                    out.pop("_qf_cut", None)
-                    loss, out = get_loss(out)
-                    self.static_out = out
-                    loss.backward(inputs=self._upper_params + [self._boundary[1]])
-                    _flush_deferred(model)
-                    optimizer.begin_split_step()
-                    self._table_u = optimizer.upload_part(self._upper_params, slot=1)
-                    self.static_loss = loss
-                    timeline.mark("main:backward done")
-                # the gradients the side stream's update reads stay allocated for good: the second graph (same pool) must not
-                # take their memory while the update may still be reading it
-                self._held_grads = [p.grad for p in self._upper_params if p.grad is not None]
-                with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph_enc, stream=stream, pool=self.graph.pool(),
-                                                               capture_error_mode=cap_mode):
-                    tokens, leaf = self._boundary
-                    tokens.backward(leaf.grad)
-                    self._table_l = optimizer.upload_part(self._lower_params, slot=2)
-                    optimizer.launch_part(self._table_l)
-                    STEP_ZEROS.end_step()
-                    timeline.mark("main:end")
-            except BaseException:
-                STEP_ZEROS.end_step()    # a capture that died must not leave the zero region open
-                raise
-            self._held_grads += [p.grad for p in self._lower_params if p.grad is not None]
-            self._boundary = None
-            for p in params:
-                p.grad = None
-        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode) \
-                if not self._beside else contextlib.nullcontext():
-          if not self._beside:
-            # data parallel: the geometry branch would have to rejoin at the end of THIS graph, i.e. before the
-            # encoder's backward / the exchange / the update -- it gets its own graph on the side stream (below)
-            if self._geo_inline:
-                self.side.wait_stream(stream)                    # fork
-                with torch.cuda.stream(self.side):
-                    self.plan_next.compute(self.static_next_xyz)
+        # the gradient-table uploads of THIS step's captures read pinned staging buffers of their own, dropped with it
+        self._opt_tables = optimizer.new_capture_tables(4) if fused_opt else None
+        scope = optimizer.captured_with(self._opt_tables) if fused_opt else contextlib.nullcontext()
+        with scope:
+            self._capture_all(stream, cap_mode, reducer, fwd_bwd, fwd_bwd_head, bwd_lower, bwd_encoder, update)
+        torch.cuda.synchronize()
+        # hyper-parameters that are baked into captured launches by VALUE: BatchNorm momentum
+        # (sig3d_bn_finalize; the reference's BNMomentumScheduler changes it per epoch, lib/solver.py:248-257)
+        # and, for optimizers other than FlatAdamW with fused kernels, nothing else.  The learning rate is a
+        # device scalar (optim.FlatAdamW.sync_lr) and follows a scheduler across replays.
+        self._captured_bn_momenta = _bn_momenta(model)
+
+    def _capture_all(self, stream, cap_mode, reducer, fwd_bwd, fwd_bwd_head, bwd_lower, bwd_encoder, update):
+        with gemm_tuning.no_tuning(), torch.cuda.graph(self.graph, stream=stream, capture_error_mode=cap_mode):
             if reducer is not None:
                 reducer.zero_grad()
             timeline.mark("main:start")
@@ -379,9 +313,6 @@ class GraphedTrainStep:
             if reducer is None:
                 update()
             timeline.mark("main:update done")
-            if self._geo_inline:
-                stream.wait_stream(self.side)                    # join
-                self.plan_cur.copy_from(self.plan_next)          # hand over for the next replay
             timeline.mark("main:end")
         if self._split:
             if self.graph_low is not None:
@@ -401,23 +332,10 @@ class GraphedTrainStep:
                                                            pool=self.graph.pool(),
                                                            capture_error_mode=cap_mode):
                 update()
-        torch.cuda.synchronize()
-        # hyper-parameters that are baked into captured launches by VALUE: BatchNorm momentum
-        # (sig3d_bn_finalize; the reference's BNMomentumScheduler changes it per epoch, lib/solver.py:248-257)
-        # and, for optimizers other than FlatAdamW with fused kernels, nothing else.  The learning rate is a
-        # device scalar (optim.FlatAdamW.sync_lr) and follows a scheduler across replays.
-        self._captured_bn_momenta = _bn_momenta(model)
 
     def handshake_timed_out(self):
         """True when a geometry chain ever gave up waiting for its ticket (geometry.GeometryPipeline.timed_out)."""
         return self._pipe is not None and self._pipe.timed_out()
-
-    def prime(self, batch):
-        """Inline-fork form: compute the geometry of the FIRST batch (pipeline prologue).  The pipeline form does
-        this by itself (an unannounced batch gets an inline chain)."""
-        if self._geo_inline:
-            self.plan_cur.compute(batch["point_clouds"][..., :3].contiguous())
-        self._primed = True
 
     def __call__(self, batch, next_batch=None, token=None, next_token=None, upcoming=None, upcoming_tokens=None):
         """`upcoming`: the batches of the next `prefetch_depth` calls, in order (the chain of upcoming[-1] starts
@@ -442,23 +360,6 @@ class GraphedTrainStep:
         if self._pipe is not None:
             # hand over the plan of `batch`, start the chain of upcoming[-1] -- under everything below
             self._pipe.advance(batch["point_clouds"], [u["point_clouds"] for u in upcoming], token, upcoming_tokens)
-        elif self.prefetch:
-            next_batch, next_token = upcoming[0], (upcoming_tokens[0] if upcoming_tokens else None)
-            if not self._primed or not self._announced.matches(batch["point_clouds"], token):
-                self.prime(batch)  # pipeline prologue, or the caller broke the announced order
-            self.static_next_xyz.copy_(next_batch["point_clouds"][..., :3], non_blocking=True)
-            self._announced.set(next_batch["point_clouds"], next_token)
-        if self._beside:
-            # forward + upper backward | the upper update on its own stream beside the encoder's backward and update
-            _copy_into(self.static_batch, batch)
-            self.graph.replay()
-            self._ev_a.record(self.stream)
-            self._side_opt.wait_event(self._ev_a)
-            self.optimizer.launch_part(self._table_u, stream=self._side_opt, max_workgroups=self._beside_wgs)
-            self._ev_u.record(self._side_opt)
-            self.graph_enc.replay()
-            self.stream.wait_event(self._ev_u)        # whatever follows on this stream (the next step, a checkpoint) sees
-            return self.static_loss                   # the updated parameters; the encoder's graph above did not wait
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         if self.reducer is not None:

@@ -33,8 +33,7 @@ import torch
 from . import _lib
 
 _CHUNK = 65536
-_CAPTURE_SLOT = 7        # staging buffers: 0 eager, 1-6 the call sites of a captured step in parts, 7 ... a captured whole step
-_MAX_CAPTURES = 8        # ... one per capture (graphs that are alive together must not share a pinned table)
+_SPARE_TABLES = 2        # staging tables kept ready for a capture nobody reserved tables for (see CaptureTables)
 _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"), ("wd", "f4"),
                  ("pad", "f4")])
 
@@ -42,6 +41,59 @@ _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8")
 # workgroups that walk the chunk table of one update launch when the optimizer is not given max_workgroups
 # (0: one workgroup per 64 Ki-element chunk); SIG3D_ADAMW_WORKGROUPS
 DEFAULT_MAX_WORKGROUPS = int(os.environ.get("SIG3D_ADAMW_WORKGROUPS", "0"))
+
+
+def flat_offsets(params):
+    """Element offsets of `params` laid back to back with 16-byte alignment (the flat buffers' rule) -> (offsets, total)."""
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    return offs, total
+
+
+def part_runs(mine, total, parts, exclude=()):
+    """mine: [(parameter, element offset)] of one flat buffer in storage order, `total` its length.  parts: lists of
+    parameters.  -> one list of (lo, hi) element ranges per part -- every maximal run of the part's parameters is a
+    range -- plus a last list for the parameters of no part; parameters in `exclude` belong to no range."""
+    owner = {}
+    for k, ps in enumerate(parts):
+        for p in ps:
+            owner[id(p)] = k
+    for p in exclude:
+        owner[id(p)] = -1
+    out = [[] for _ in range(len(parts) + 1)]
+    i = 0
+    while i < len(mine):
+        k = owner.get(id(mine[i][0]), len(parts))
+        j = i
+        while j < len(mine) and owner.get(id(mine[j][0]), len(parts)) == k:
+            j += 1
+        lo = mine[i][1]
+        hi = mine[j][1] if j < len(mine) else total
+        if k >= 0:
+            out[k].append((lo, hi))
+        i = j
+    return out
+
+
+class CaptureTables:
+    """The pinned staging buffers + device tables of the gradient-table uploads of ONE captured step: a captured upload
+    is a memcpy node that re-reads its pinned staging buffer at every replay, so every upload call site of every live
+    capture needs a buffer of its own -- two graphs over one optimizer (a step rebuilt after a BatchNorm momentum
+    change while the old one is still replayed, the arms of tools/ab_step.py) must never share one.  Built OUTSIDE a
+    capture (pinned memory cannot be allocated inside one) by FlatAdamW.new_capture_tables(), owned by whoever owns
+    the graphs (graph_step.GraphedTrainStep): dropped with them, so there is no cap on the number of captures."""
+
+    def __init__(self, sets):
+        self.sets, self.used = list(sets), 0
+
+    def take(self):
+        if self.used >= len(self.sets):
+            raise RuntimeError("FlatAdamW: this capture uploads more gradient tables than were reserved for it "
+                               "(new_capture_tables(sites)): %d" % len(self.sets))
+        self.used += 1
+        return self.sets[self.used - 1]
 
 
 class FlatAdamW(torch.optim.Optimizer):
@@ -81,10 +133,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._groups.append(None)
                 continue
             dev = ps[0].device
-            offs, total = [], 0
-            for p in ps:  # 16-byte alignment of every parameter inside the flat buffers
-                offs.append(total)
-                total += (p.numel() + 3) // 4 * 4
+            offs, total = flat_offsets(ps)   # 16-byte alignment of every parameter inside the flat buffers
             flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
             m, v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
             for p, off in zip(ps, offs):
@@ -113,28 +162,60 @@ class FlatAdamW(torch.optim.Optimizer):
         self._host = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8).pin_memory()
         self._host_np = self._host.numpy().view(_REC)
         self._table = torch.empty(len(recs) * _REC.itemsize, dtype=torch.uint8, device=dev)
-        self._slots = [(self._host, self._host_np, self._table)]
-        self._tables(_CAPTURE_SLOT + _MAX_CAPTURES - 1)      # pinned memory cannot be allocated during a capture
+        self.capture_tables = None     # CaptureTables of the capture in progress (captured_with)
+        self._spare = [self._new_table_set() for _ in range(_SPARE_TABLES)]
+        self._anonymous = []           # spares that a capture without reserved tables took: alive as long as the optimizer
         self._gathered = False
 
     # ---- chunk table ------------------------------------------------------------------------
-    def _tables(self, slot):
-        """(pinned host staging, its numpy view, device table) of call site `slot`.  Every call site that
-        can sit in a captured hipGraph needs its OWN staging buffer: a captured upload is a memcpy node
-        that re-reads the staging memory at every replay."""
-        while len(self._slots) <= slot:
-            host = torch.empty(len(self._static) * _REC.itemsize, dtype=torch.uint8).pin_memory()
-            self._slots.append((host, host.numpy().view(_REC), torch.empty_like(self._table)))
-        return self._slots[slot]
+    def _new_table_set(self):
+        host = torch.empty(len(self._static) * _REC.itemsize, dtype=torch.uint8).pin_memory()
+        return host, host.numpy().view(_REC), torch.empty_like(self._table)
 
-    def _upload(self, dst_field_from_flat_g=False, slot=0, only=None):
-        """Fill the per-step columns of the table (gradient pointers) and push it to the device.
-        only: a set of id(parameter) -- the records of every other parameter are empty."""
+    def new_capture_tables(self, sites=4):
+        """Staging tables for the uploads of one captured step (`sites` upload call sites: step() or every
+        gather_grads() of the capture).  Call outside any capture, keep the result alive with the graphs, capture
+        inside `with optimizer.captured_with(tables):`."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FlatAdamW.new_capture_tables: pinned memory cannot be allocated during a capture")
+        return CaptureTables([self._new_table_set() for _ in range(sites)])
+
+    def captured_with(self, tables):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, self.capture_tables = self.capture_tables, tables
+            try:
+                yield tables
+            finally:
+                self.capture_tables = prev
+        return scope()
+
+    def _table_set(self):
+        """(pinned host staging, its numpy view, device table) for the upload being issued now.  Eager: the shared set
+        (the copy blocks, the buffer is free again when it returns).  Inside a capture: a set of its own -- from the
+        capture's CaptureTables, else one of the spares (refilled by the next eager upload)."""
+        if not torch.cuda.is_current_stream_capturing():
+            while len(self._spare) < _SPARE_TABLES:
+                self._spare.append(self._new_table_set())
+            return self._host, self._host_np, self._table
+        if self.capture_tables is not None:
+            return self.capture_tables.take()
+        if not self._spare:
+            raise RuntimeError("FlatAdamW: a capture needs gradient tables of its own and the spares are used up -- "
+                               "reserve them before capturing: tables = optimizer.new_capture_tables(sites); "
+                               "with optimizer.captured_with(tables): <capture>")
+        self._anonymous.append(self._spare.pop())
+        return self._anonymous[-1]
+
+    def _upload(self, dst_field_from_flat_g=False):
+        """Fill the per-step columns of the table (gradient pointers) and push it to the device."""
         gptr = np.zeros(len(self._params), dtype=np.uint64)
         live = np.zeros(len(self._params), dtype=bool)
         for i, (p, gi, off) in enumerate(self._params):
             g = p.grad
-            if g is None or (only is not None and id(p) not in only):
+            if g is None:
                 continue
             if not g.is_contiguous():
                 g = g.contiguous()
@@ -144,20 +225,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if dst_field_from_flat_g:
             self._live |= self._agree_on_liveness(live)
             self._live[self._external] = True
-        if slot == 0 and torch.cuda.is_current_stream_capturing():
-            # a captured upload is a memcpy node that re-reads its pinned staging buffer at every replay: it gets a
-            # buffer of its own, which an eager step() between two replays (the short last batch of an epoch) does not
-            # rewrite -- with the shared one the next replay walked a table of freed gradient tensors
-            # ... and every CAPTURE gets its own: two live graphs over one optimizer (a step rebuilt after a BatchNorm
-            # momentum change while the old one is still replayed; tools/ab_step.py's A and B) would otherwise share one
-            # pinned table, and a replay of the first would walk the second's gradient pointers
-            n_cap = self.__dict__.setdefault("_captures", [0])
-            if n_cap[0] >= _MAX_CAPTURES:
-                raise RuntimeError("FlatAdamW: more than %d captured steps over one optimizer (each holds a pinned gradient "
-                                   "table of its own); build a new optimizer object" % _MAX_CAPTURES)
-            slot = _CAPTURE_SLOT + n_cap[0]
-            n_cap[0] += 1
-        host, t, table = self._tables(slot)
+        host, t, table = self._table_set()
         t[:] = self._static
         t["g"] = gptr[self._owners] + self._static["g"]
         t["n"] = np.where(live[self._owners], self._static["n"], 0)  # params without grad: skipped
@@ -205,16 +273,17 @@ class FlatAdamW(torch.optim.Optimizer):
                 g["g"] = torch.zeros(g["total"], dtype=torch.float32, device=self._dev)
         return [g["g"] for g in self._groups if g is not None]
 
-    def gather_grads(self, slot=0, zero=True):
+    def gather_grads(self, zero=True):
         """Scattered .grad tensors -> flat gradient buffers (one launch); the next step() then reads
         the flat (e.g. all-reduced) gradients.  Parameters whose .grad is None are skipped, so a
         backward pass run in two parts gathers in two calls: the first with zero=True (whole buffers
-        cleared), the second with zero=False and its own `slot` (see _tables)."""
+        cleared), the second with zero=False.  Inside a capture every call gets a staging table of its
+        own (_table_set)."""
         self.flat_grad_buffers()
         if zero:
             self._live[:] = False
             self._zero_unaliased()  # parameters without a gradient contribute zeros to the all-reduce
-        table = self._upload(dst_field_from_flat_g=True, slot=slot)
+        table = self._upload(dst_field_from_flat_g=True)
         with torch.cuda.device(self._dev):
             _lib.call("sig3d_gather_table", len(self._static), _lib.ptr(table),
                       _lib.stream_ptr(self._dev))
@@ -306,28 +375,13 @@ class FlatAdamW(torch.optim.Optimizer):
         the part's parameters in storage order is a slice) plus a last list for all other parameters.
         Parameters in `exclude` belong to no list (their slot is exchanged some other way)."""
         self.flat_grad_buffers()
-        owner = {}
-        for k, ps in enumerate(parts):
-            for p in ps:
-                owner[id(p)] = k
-        for p in exclude:
-            owner[id(p)] = -1
         out = [[] for _ in range(len(parts) + 1)]
         for gi, f in enumerate(self._groups):
             if f is None:
                 continue
             mine = [(p, off) for p, g2, off in self._params if g2 == gi]
-            i = 0
-            while i < len(mine):
-                k = owner.get(id(mine[i][0]), len(parts))
-                j = i
-                while j < len(mine) and owner.get(id(mine[j][0]), len(parts)) == k:
-                    j += 1
-                lo = mine[i][1]
-                hi = mine[j][1] if j < len(mine) else f["total"]
-                if k >= 0:
-                    out[k].append(f["g"][lo:hi])
-                i = j
+            for k, runs in enumerate(part_runs(mine, f["total"], parts, exclude)):
+                out[k] += [f["g"][lo:hi] for lo, hi in runs]
         return out
 
     @torch.no_grad()
@@ -412,29 +466,6 @@ class FlatAdamW(torch.optim.Optimizer):
             _lib.call("sig3d_adamw_table", *args, stream)
         else:
             _lib.call("sig3d_adamw_table_bounded", *args, int(bound), stream)
-
-    # ---- the update in two parts (graph_step.GraphedTrainStep, update_beside): the parameters whose gradients are
-    # complete after the first part of the backward pass are updated on ANOTHER stream while the rest of the backward
-    # pass runs; both launches read the step count advanced by begin_split_step()
-    @torch.no_grad()
-    def begin_split_step(self):
-        self.sync_lr()
-        with torch.cuda.device(self._dev):
-            _lib.call("sig3d_step_increment", _lib.ptr(self._step), _lib.stream_ptr(self._dev))
-
-    @torch.no_grad()
-    def upload_part(self, params, slot):
-        """Chunk table (call site `slot` >= 1) of the parameters in `params` that hold a gradient now -> the device table.
-        Inside a capture this is a memcpy node; the gradient tensors must stay alive as long as the table is used."""
-        return self._upload(slot=slot, only={id(p) for p in params})
-
-    @torch.no_grad()
-    def launch_part(self, table, stream=None, max_workgroups=None):
-        """One AdamW launch over a table of upload_part(), on `stream` (a torch stream) or the current one;
-        max_workgroups: a bounded grid that leaves the other stream's kernels their CU slots."""
-        with torch.cuda.device(self._dev):
-            sp = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _lib.stream_ptr(self._dev)
-            self._launch_table(len(self._static), table, sp, max_workgroups=max_workgroups)
 
     @torch.no_grad()
     def update_buckets(self, reducer):

@@ -17,6 +17,9 @@ from .. import _lib
 
 # SIG3D_NESTED_FPS=0: always run the dependent rounds (A/B timing; results are identical)
 NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
+# scenes above 8192 points: one workgroup per scene over a Morton-ordered copy in L2 (sig3d_furthest_point_sampling_blocks);
+# SIG3D_FPS_BLOCKS=0: the cooperative register-resident kernel behind the reference's own argument list (same indices)
+FPS_BLOCKS = os.environ.get("SIG3D_FPS_BLOCKS", "1") != "0"
 
 
 def _check_contiguous(t, name):
@@ -78,6 +81,13 @@ def furthest_point_sampling(points, nsamples):
         flags = torch.empty((b,), dtype=torch.int32, device=dev)
         _run("sig3d_furthest_point_sampling_nested", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
              _lib.ptr(out), _lib.ptr(flags))
+        return out
+    if FPS_BLOCKS and n > 8192:
+        # one workgroup per scene over a Morton-ordered copy in L2 (csrc/sampling.hip: fps_blocks_kernel); the
+        # reference's (B, N) `temp` is too small for it, so it takes a workspace of its own
+        work = _lib.fps_workspace(b, n, dev)
+        _run("sig3d_furthest_point_sampling_blocks", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(work),
+             work.numel(), _lib.ptr(out))
         return out
     _run("sig3d_furthest_point_sampling", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
          _lib.ptr(out))

@@ -23,15 +23,16 @@ once per training forward), a per-module call id and the element index, so forwa
 regenerate the same mask and no (B,H,Nq,Nk) tensor is ever stored.  The random stream differs from
 torch's Philox (same distribution, different bits); eval mode is deterministic.
 """
+import contextlib
 import ctypes
 import math
 import os
+import threading
 import weakref
 from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
-from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib, scratch
 
@@ -130,19 +131,11 @@ def advance_dropout_seed(device):
 # library (rocBLAS / hipBLASLt through torch); this switch is the A/B.
 OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
 OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
-# SIG3D_QF_GEMM_CONFIG: which core / tiling sig3d_gemm16 uses for those products: 0 its own choice among the f32 tilings,
-# 1-3 one of them, 11 / 12 the bf16 x 6 core (gemmx6_core.h: three-term bf16 split, six products, f32-equivalent)
-OWN_CONFIG = int(os.environ.get("SIG3D_QF_GEMM_CONFIG", "0"))
+OWN_CONFIG = 0      # sig3d_gemm16's own choice among its f32 tilings
 
 
 # the flush's column sums (bias gradients, LayerNorm-tail folds) as one launch (sig3d_column_sum_multi) or one per kind
 COLSUM_MULTI = os.environ.get("SIG3D_QF_COLSUM_MULTI", "1") != "0"
-
-
-# SIG3D_QF_DW: the layer-batched weight-gradient products dW = dY^T X of _WeightGradArena.flush() on sig3d_gemmp
-# (csrc/gemmp_core.h: the f32 product as six bf16 products over operands split ONCE into chunked bf16 planes, both
-# operands read through the LDS transposing read, 128 x 128 tiles) instead of torch.bmm (rocBLAS / hipBLASLt).
-OWN_DW = os.environ.get("SIG3D_QF_DW", "0") != "0"
 
 
 # Cross-attention over MANY encoder tokens (the 3D-LLM shape: B x 5000 ... 80 000 point tokens of width 1408,
@@ -160,18 +153,33 @@ def _planes(t2):
 
 
 class _EncoderPlanes:
-    """The planes of the encoder tokens of ONE forward pass, found again by the tensor OBJECT the cross layers are handed
-    (held weakly: the entry dies with the tensor; a tensor written in place since is split again)."""
-    _cache = WeakIdKeyDictionary()      # keyed by identity: a tensor's == is element-wise
+    """The planes of the encoder tokens, shared by the cross layers of ONE BertEncoder.forward: the encoder opens a scope,
+    the layers inside it are handed the same tensor OBJECT and split it once; the scope ends with the forward (the
+    backward pass reads the planes its nodes saved).  Nothing is remembered across forwards -- a reused encoder buffer
+    (a static hipGraph input, a tensor refilled through a raw pointer or a `.data` swap; none of those advance
+    `_version`) is split again -- and a cross-attention module called on its own, outside a scope, splits per call."""
+    _tls = threading.local()
+
+    @classmethod
+    @contextlib.contextmanager
+    def scope(cls):
+        prev, cls._tls.held = getattr(cls._tls, "held", None), []
+        try:
+            yield
+        finally:
+            cls._tls.held = prev
 
     @classmethod
     def of(cls, enc):
-        hit = cls._cache.get(enc)
-        if hit is not None and hit[0] == enc._version:
-            return hit[1]
+        held = getattr(cls._tls, "held", None)
+        if held is not None:
+            for t, pl in held:
+                if t is enc:
+                    return pl
         with torch.no_grad():
             pl = _planes(enc.detach().reshape(-1, enc.shape[-1]).contiguous())
-        cls._cache[enc] = (enc._version, pl)
+        if held is not None:
+            held.append((enc, pl))
         return pl
 
 
@@ -582,6 +590,41 @@ class _ProjAttentionFn(torch.autograd.Function):
                 None, None, None)
 
 
+class _Runs:
+    """A buffer with a leading (layer / cross-layer / row) index that is stored as runs [lo, hi) of that index lying
+    apart in memory: the parameters of the layers above and below a storage cut (parameter_adjacency_groups(cut=k)) are
+    two kind-major arenas, and a layer-batched gradient buffer that IS a slice of the flat gradients has one run in
+    each.  Indexing by a layer, a (layer, ...) tuple or a range inside one run returns plain tensors; a range that
+    straddles the cut is an error (flush() never issues one: it cuts its ranges at the boundary)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)      # [(lo, hi, tensor whose dim 0 is hi - lo)]
+
+    def _run(self, a, b):
+        for lo, hi, t in self.parts:
+            if lo <= a and b <= hi:
+                return lo, t
+        raise IndexError("range [%d, %d) straddles the storage cut" % (a, b))
+
+    def __getitem__(self, key):
+        rest = ()
+        if isinstance(key, tuple):
+            key, rest = key[0], key[1:]
+        if isinstance(key, slice):
+            a = key.start or 0
+            b = key.stop if key.stop is not None else self.parts[-1][1]
+            lo, t = self._run(a, b)
+            return t[(slice(a - lo, b - lo),) + rest]
+        lo, t = self._run(key, key + 1)
+        return t[(key - lo,) + rest]
+
+    def tensors(self):
+        return [t for _, _, t in self.parts]
+
+    def empty_like(self):
+        return _Runs([(lo, hi, torch.empty_like(t)) for lo, hi, t in self.parts])
+
+
 class _WeightGradArena:
     """Per-forward storage that lets the weight-gradient products of ALL Q-Former layers run as a handful of
     strided-batched GEMMs at the end of the backward pass instead of ~90 small ones inside it.
@@ -602,7 +645,8 @@ class _WeightGradArena:
     164-170), so they are ONE GEMM in the forward pass (tokens x [Wk0;Wv0;Wk2;Wv2;...]^T) and their weight /
     input gradients two GEMMs in flush() / the lowest cross-attention block instead of twelve."""
 
-    def __init__(self, layers, batch, tq, tt, part_rows, enc2, num_heads, return_enc_at, grad_store=None):
+    def __init__(self, layers, batch, tq, tt, part_rows, enc2, num_heads, return_enc_at, grad_store=None,
+                 storage_cut=None):
         first = layers[0].attention
         wq = first.self.query.weight
         dev, H, I = wq.device, wq.shape[0], layers[0].intermediate_query.dense.weight.shape[0]
@@ -620,20 +664,32 @@ class _WeightGradArena:
         # optimizer's flat gradient buffers when the parameters they belong to lie there in this very order
         # (parameter_adjacency_groups) -- the batched products then write the gradients where the all-reduce
         # and AdamW read them, and nothing is gathered or zeroed for them
-        def res(params, *shape):
-            v = grad_store(list(params)) if grad_store is not None else None
-            if v is not None and v.numel() == math.prod(shape):
-                return v.view(*shape)
-            return e(*shape)
+        # storage_cut = k: the optimizer keeps the layers below and from k on as two kind-major arenas (trainer.build_optimizer
+        # (qf_cut=k)), so a buffer that IS gradient storage has a run per arena, and the stacked key / value weights too
+        k = storage_cut if storage_cut and 0 < storage_cut < NL else None
+        self.runs = [(0, NL)] if k is None else [(0, k), (k, NL)]
+        jc = sum(1 for i in self.cross if k is not None and i < k)
+        self.cross_runs = [(0, len(self.cross))] if k is None or jc in (0, len(self.cross)) else [(0, jc), (jc, len(self.cross))]
+
+        def res(per_index, runs, unit, *tail):
+            """per_index(i) -> the parameters behind index i; runs over that index; `unit` rows of dim 0 per index"""
+            parts = []
+            for lo, hi in runs:
+                shape = ((hi - lo) * unit,) + tail if unit else (hi - lo,) + tail
+                params = [p for i in range(lo, hi) for p in per_index(i)]
+                v = grad_store(params) if grad_store is not None else None
+                t = v.view(*shape) if v is not None and v.numel() == math.prod(shape) else e(*shape)
+                parts.append((lo * (unit or 1), hi * (unit or 1), t))
+            return parts[0][2] if len(parts) == 1 else _Runs(parts)
 
         sa = [l.attention.self for l in layers]
-        self.gwqkv = res([w for a in sa for w in (a.query.weight, a.key.weight, a.value.weight)], NL, 3 * H, H)
+        self.gwqkv = res(lambda i: (sa[i].query.weight, sa[i].key.weight, sa[i].value.weight), self.runs, 0, 3 * H, H)
         self.gbqkv = e(NL, 3 * H)
-        self.gwo = res([l.attention.output.dense.weight for l in layers], NL, H, H)
-        self.gw1 = res([w for l in layers for w in (l.intermediate_query.dense.weight, l.intermediate.dense.weight)],
-                       NL, 2, I, H)
+        self.gwo = res(lambda i: (layers[i].attention.output.dense.weight,), self.runs, 0, H, H)
+        self.gw1 = res(lambda i: (layers[i].intermediate_query.dense.weight, layers[i].intermediate.dense.weight),
+                       self.runs, 0, 2, I, H)
         self.gb1 = e(NL, 2, I)
-        self.gw2 = res([w for l in layers for w in (l.output_query.dense.weight, l.output.dense.weight)], NL, 2, H, I)
+        self.gw2 = res(lambda i: (layers[i].output_query.dense.weight, layers[i].output.dense.weight), self.runs, 0, 2, H, I)
         # LayerNorm-tail parameter gradients [d gamma | d beta | d bias]: per-workgroup partial rows of every
         # tail's backward kernel, folded over all layers at once
         self.ln_blocks_ffn, self.ln_blocks_attn = _ln_bwd_blocks(rows, P), _ln_bwd_blocks(rows)
@@ -650,20 +706,20 @@ class _WeightGradArena:
             self.dq_x = scratch.zeros((nc, rq, H), torch.float32, dev)
             self.kv, self.dkv = e(nrow_e, nc * 2 * H), e(nrow_e, nc * 2 * H)
             xs = [layers[i].crossattention for i in self.cross]
-            self.gwq_x = res([x.self.query.weight for x in xs], nc, H, H)
+            self.gwq_x = res(lambda j: (xs[j].self.query.weight,), self.cross_runs, 0, H, H)
             self.gbq_x = e(nc, H)
-            self.gwo_x = res([x.output.dense.weight for x in xs], nc, H, H)
-            self.gwkv = res([w for x in xs for w in (x.self.key.weight, x.self.value.weight)], nc * 2 * H, cenc)
+            self.gwo_x = res(lambda j: (xs[j].output.dense.weight,), self.cross_runs, 0, H, H)
+            self.gwkv = res(lambda j: (xs[j].self.key.weight, xs[j].self.value.weight), self.cross_runs, 2 * H, cenc)
             self.gbkv = e(nc * 2 * H)
             self.ln_work_x, self.ln_x = e(nc, self.ln_blocks_attn, 3 * H), e(nc, 3, H)
-            with torch.no_grad():   # [Wk;Wv] of every cross layer stacked: one projection GEMM for all of them
-                ws, bs = [], []
-                for i in self.cross:
-                    sa = layers[i].crossattention.self
-                    ws += [sa.key.weight, sa.value.weight]
-                    bs += [sa.key.bias, sa.value.bias]
-                self.wkv_all = _stacked(ws)
-                torch.addmm(_stacked(bs), enc2, self.wkv_all.t(), out=self.kv)
+            with torch.no_grad():   # [Wk;Wv] of every cross layer stacked: one projection GEMM for all of them (one per arena)
+                self.wkv_runs = []
+                for j0, j1 in self.cross_runs:
+                    ws = [w for j in range(j0, j1) for w in (xs[j].self.key.weight, xs[j].self.value.weight)]
+                    bs = [b_ for j in range(j0, j1) for b_ in (xs[j].self.key.bias, xs[j].self.value.bias)]
+                    w_all = _stacked(ws)
+                    self.wkv_runs.append((j0, j1, w_all))
+                    torch.addmm(_stacked(bs), enc2, w_all.t(), out=self.kv[:, j0 * 2 * H:j1 * 2 * H])
         # cross layers whose backward returns the gradient of the scene tokens, accumulated over the cross layers
         # above them (the lowest one; with a split backward pass also the lowest one of the upper piece)
         self.return_enc_at = sorted(set(return_enc_at) & set(self.cross), reverse=True) if nc else []
@@ -684,7 +740,6 @@ class _WeightGradArena:
         # stack (the consumer is known to look here); whatever is left when the last block is done is an error.
         self.slabs_ok = OWN_GEMM
         self._slabs = {}
-        self._pl = {}                   # chunked bf16 planes of the operand buffers (OWN_DW), made in flush()
 
     def put_slabs(self, grad, slabs, slab_rows):
         self._slabs[grad.data_ptr()] = (slabs, slab_rows)
@@ -719,14 +774,26 @@ class _WeightGradArena:
         j0, j1 = self.cross_ord[layer], self._enc_done_hi
         self._enc_done_hi = j0
         H2 = 2 * self.H
-        return self.dkv[:, j0 * H2:j1 * H2].mm(self.wkv_all[j0 * H2:j1 * H2])
+        out = None
+        for a, b, w in self.wkv_runs:     # the stacked weights of the arenas inside [j0, j1)
+            a2, b2 = max(a, j0), min(b, j1)
+            if a2 >= b2:
+                continue
+            d, wv = self.dkv[:, a2 * H2:b2 * H2], w[(a2 - a) * H2:(b2 - a) * H2]
+            out = d.mm(wv) if out is None else out.addmm_(d, wv)
+        return out
 
     # ---- which parameter gets which view (mirrors what the block functions return) --------------------------
     _RESULTS = ("gwqkv", "gbqkv", "gwo", "gw1", "gb1", "gw2", "ln_ffn", "ln_attn",
                 "gwq_x", "gbq_x", "gwo_x", "gwkv", "gbkv", "ln_x")
 
     def result_buffers(self):
-        return [getattr(self, k) for k in self._RESULTS if hasattr(self, k)]
+        out = []
+        for k in self._RESULTS:
+            t = getattr(self, k, None)
+            if t is not None:
+                out += t.tensors() if isinstance(t, _Runs) else [t]
+        return out
 
     def param_views(self, lo, hi):
         """[(parameter, view of its deferred gradient)] for layers [lo, hi)."""
@@ -778,8 +845,8 @@ class _WeightGradArena:
         views = self.param_views(lo, hi)
         try:
             for k, t in real.items():
-                setattr(self, k, torch.empty_like(t))
-            self._products(lo, hi)
+                setattr(self, k, t.empty_like() if isinstance(t, _Runs) else torch.empty_like(t))
+            self._products_cut(lo, hi)
             temps = self.param_views(lo, hi)
         finally:
             for k, t in real.items():
@@ -812,79 +879,38 @@ class _WeightGradArena:
         self._check_adopted(lo, hi)
         side = self.side_stream
         if side is None:
-            self._products(lo, hi)
+            self._products_cut(lo, hi)
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._products(lo, hi)
+            self._products_cut(lo, hi)
         self._forked = True
+
+    def _products_cut(self, lo, hi):
+        """The products of layers [lo, hi), one batch per storage arena (upper arena first, like the backward pass)."""
+        for a, b in reversed(self.runs):
+            a, b = max(a, lo), min(b, hi)
+            if a < b:
+                self._products(a, b)
 
     def join(self):
         if self._forked:
             torch.cuda.current_stream().wait_stream(self.side_stream)
             self._forked = False
 
-    # ---- the products on sig3d_gemmp ----------------------------------------------------------------------
-    def _planes_of(self, name, lo, hi, live=None):
-        """Chunked bf16 planes of layers [lo, hi) of the operand buffer `name` ((layers, rows, cols) or (rows, cols)),
-        made now (sig3d_planes_split; the first `live` rows): (hi - lo, cols / 32, rows, 96) int16."""
-        t = getattr(self, name)
-        t3 = t if t.dim() == 3 else t.unsqueeze(0)
-        if name not in self._pl:
-            self._pl[name] = torch.empty((t3.shape[0], t3.shape[2] // 32, t3.shape[1], 96), dtype=torch.int16, device=t.device)
-        pl = self._pl[name][lo:hi]
-        _lib.planes_split(t3[lo:hi], pl, rows=live)
-        return pl
-
-    @staticmethod
-    def _dw(pa, pb, out, k, row0=0, col0=0, m=None):
-        """out (batch, M, N) = A^T B over the rows [row0, row0 + k) of the planes pa (batch, Ma / 32, rows, 96) --
-        columns [col0, col0 + m) of A -- and pb (batch, N / 32, rows, 96)."""
-        batch, _, rows_a, _ = pa.shape
-        rows_b = pb.shape[2]
-        m = pa.shape[1] * 32 - col0 if m is None else m
-        n = pb.shape[1] * 32
-        off_a = (col0 // 32) * rows_a * 96 + row0 * 96
-        off_b = row0 * 96
-        _lib.gemmp(out.device, A=pa.data_ptr() + 2 * off_a, chunk_a=rows_a * 96, stride_a=pa[0].numel(),
-                   bytes_a=(pa[0].numel() - off_a) * 2, B=pb.data_ptr() + 2 * off_b, chunk_b=rows_b * 96,
-                   stride_b=pb[0].numel(), bytes_b=(pb[0].numel() - off_b) * 2, C=out, ldc=out.stride(-2),
-                   stride_c=out.stride(0) if out.dim() == 3 else 0, modes=2, batch=batch, m=m, n=n, k=k)
-
-    def _dense_products_own(self, lo, hi, js):
-        P, L, rq, H = self.P, self.L, self.rq, self.H
-        pdy, pact = self._planes_of("dyo_ffn", lo, hi), self._planes_of("act", lo, hi)
-        pg, px = self._planes_of("gpre", lo, hi), self._planes_of("x_ffn", lo, hi)
-        for half in range(2):      # (query branch, text branch): rows [0, P) and [P, 2P) of every layer's matrices
-            self._dw(pdy, pact, self.gw2[lo:hi, half], P, row0=half * P)
-            self._dw(pg, px, self.gw1[lo:hi, half], P, row0=half * P)
-        self._dw(self._planes_of("dyo_attn", lo, hi), self._planes_of("att", lo, hi), self.gwo[lo:hi], L)
-        self._dw(self._planes_of("dproj", lo, hi), self._planes_of("x_attn", lo, hi, live=L), self.gwqkv[lo:hi], L)
-        if js:
-            j0, j1 = js[0], js[-1] + 1
-            self._dw(self._planes_of("dyo_x", j0, j1), self._planes_of("att_x", j0, j1), self.gwo_x[j0:j1], rq)
-            self._dw(self._planes_of("dq_x", j0, j1), self._planes_of("sa_out", j0, j1, live=rq), self.gwq_x[j0:j1], rq)
-            pkv, penc = self._planes_of("dkv", 0, 1), self._planes_of("enc2", 0, 1)
-            self._dw(pkv, penc, self.gwkv[j0 * 2 * H:j1 * 2 * H], self.enc2.shape[0], col0=j0 * 2 * H, m=(j1 - j0) * 2 * H)
-
     @torch.no_grad()
     def _products(self, lo, hi):
         n = hi - lo
         P, H, I, L, rq = self.P, self.H, self.I, self.L, self.rq
-        own = OWN_DW and H % 32 == 0 and I % 32 == 0 and (not self.cross or self.enc2.shape[1] % 32 == 0)
         js = [j for j, l in enumerate(self.cross) if lo <= l < hi]
-        if own:
-            self._dense_products_own(lo, hi, js)
         # feed-forward pair: (query branch, text branch) x n layers
-        if not own:
-            torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
-                      out=self.gw2[lo:hi].view(2 * n, H, I))
-            torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
-                      out=self.gw1[lo:hi].view(2 * n, I, H))
+        torch.bmm(self.dyo_ffn[lo:hi].view(2 * n, P, H).transpose(1, 2), self.act[lo:hi].view(2 * n, P, I),
+                  out=self.gw2[lo:hi].view(2 * n, H, I))
+        torch.bmm(self.gpre[lo:hi].view(2 * n, P, I).transpose(1, 2), self.x_ffn[lo:hi].view(2 * n, P, H),
+                  out=self.gw1[lo:hi].view(2 * n, I, H))
         # self-attention
-        if not own:
-            torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
-            torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
+        torch.bmm(self.dyo_attn[lo:hi].transpose(1, 2), self.att[lo:hi], out=self.gwo[lo:hi])
+        torch.bmm(self.dproj[lo:hi].transpose(1, 2), self.x_attn[lo:hi, :L], out=self.gwqkv[lo:hi])
         # bias gradients, and the LayerNorm tails' (layer, part) x blocks-per-part partial rows -> [d gamma | d beta |
         # d bias]: ONE launch for all kinds (sig3d_column_sum_multi; seven launches of 4-14 us before)
         bf, ba = self.ln_blocks_ffn, self.ln_blocks_attn
@@ -896,14 +922,12 @@ class _WeightGradArena:
         if js:
             j0, j1 = js[0], js[-1] + 1
             m = j1 - j0
-            if not own:
-                torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
-                torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
+            torch.bmm(self.dyo_x[j0:j1].transpose(1, 2), self.att_x[j0:j1], out=self.gwo_x[j0:j1])
+            torch.bmm(self.dq_x[j0:j1].transpose(1, 2), self.sa_out[j0:j1, :rq], out=self.gwq_x[j0:j1])
             sums.append((self.dq_x[j0:j1].view(m * rq, H), m, self.gbq_x[j0:j1]))
             sums.append((self.ln_work_x[j0:j1].view(m * ba, 3 * H), m, self.ln_x[j0:j1].view(m, 3 * H)))
             cols = slice(j0 * 2 * H, j1 * 2 * H)
-            if not own:
-                torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
+            torch.mm(self.dkv[:, cols].t(), self.enc2, out=self.gwkv[cols])
             if m == len(self.cross):
                 sums.append((self.dkv, 1, self.gbkv))
             else:
@@ -1696,7 +1720,8 @@ class BertEncoder(nn.Module):
             enc2 = encoder_hidden_states.reshape(-1, encoder_hidden_states.shape[2])
         arena = _WeightGradArena(self.layer, batch, tq, tt, part_rows, enc2,
                                  self.layer[0].attention.self.num_attention_heads, ret,
-                                 grad_store=getattr(self, "grad_store", None))
+                                 grad_store=getattr(self, "grad_store", None),
+                                 storage_cut=getattr(self, "storage_cut", None))
         if cut is not None:
             arena.slabs_ok = False   # the gradient crosses the cut through a leaf's .grad, not from block to block
         if self.flush_on_side_stream:
@@ -1721,6 +1746,12 @@ class BertEncoder(nn.Module):
                 encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None,
                 use_cache=None, output_attentions=False, output_hidden_states=False,
                 return_dict=True, query_length=0, segments=None):
+        with _EncoderPlanes.scope():
+            return self._forward(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                                 output_attentions, output_hidden_states, return_dict, query_length, segments)
+
+    def _forward(self, hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                 output_attentions, output_hidden_states, return_dict, query_length, segments):
         if segments is not None:
             # hidden_states is the two-segment row matrix (see BertLayer.forward_segmented)
             batch, tq, tt, part_rows = segments
@@ -1860,7 +1891,7 @@ class BertModel(nn.Module):
                                attentions=None, cross_attentions=None)
 
 
-def parameter_adjacency_groups(module):
+def parameter_adjacency_groups(module, cut=None):
     """Tuples of parameters the hot path wants back to back in memory (in this order).  Two users:
       * [Wq;Wk;Wv] of a layer, the (query branch, text branch) pairs of the feed-forward blocks and
         [Wk0;Wv0;Wk2;Wv2;...] of all cross-attention layers are then zero-copy views (_stacked / _pair);
@@ -1868,36 +1899,42 @@ def parameter_adjacency_groups(module):
         the deferred weight gradients (_WeightGradArena: (layers, 3H, H), (layers, 2, I, H), ...) can BE slices of
         a flat gradient buffer with the same layout (optim.FlatAdamW.flat_grad_run): the data-parallel step then
         neither gathers nor zeroes 600 MB of gradients per step.
-    trainer.build_optimizer passes the order on to optim.FlatAdamW; with any other storage the views silently
-    become copies and the arena keeps buffers of its own."""
+    cut = k (data parallel, the backward pass cut after layer k so that the upper layers' gradients travel while the
+    lower layers compute): every kind is TWO groups, layers [0, k) and [k, NL) -- two kind-major arenas instead of
+    one, so that each piece of the backward pass owns one contiguous stretch of the flat gradients (one kind-major
+    arena interleaves the pieces kind by kind: dozens of small collectives and AdamW launches, +0.95 ms per step).
+    trainer.build_optimizer passes the order on to optim.FlatAdamW and notes the cut on the encoder
+    (`storage_cut`); with any other storage the views silently become copies and the arena keeps buffers of its own."""
     layers = [m for m in module.modules() if isinstance(m, BertLayer)]
     if not layers:
         return []
-    cross = [l for l in layers if l.has_cross_attention]
+    k = cut if cut and 0 < cut < len(layers) else None
     flat = lambda rows: tuple(p for row in rows for p in row if p is not None)   # noqa: E731
-    groups = [
-        flat((l.attention.self.query.weight, l.attention.self.key.weight, l.attention.self.value.weight) for l in layers),
-        flat((l.attention.self.query.bias, l.attention.self.key.bias, l.attention.self.value.bias) for l in layers),
-        flat((l.attention.output.dense.weight,) for l in layers),
-    ]
-    if cross:
+    groups = []
+    for part in ([layers] if k is None else [layers[:k], layers[k:]]):
+        cross = [l for l in part if l.has_cross_attention]
         groups += [
-            flat((l.crossattention.self.key.weight, l.crossattention.self.value.weight) for l in cross),
-            flat((l.crossattention.self.key.bias, l.crossattention.self.value.bias) for l in cross),
-            flat((l.crossattention.self.query.weight,) for l in cross),
-            flat((l.crossattention.self.query.bias,) for l in cross),
-            flat((l.crossattention.output.dense.weight,) for l in cross),
+            flat((l.attention.self.query.weight, l.attention.self.key.weight, l.attention.self.value.weight) for l in part),
+            flat((l.attention.self.query.bias, l.attention.self.key.bias, l.attention.self.value.bias) for l in part),
+            flat((l.attention.output.dense.weight,) for l in part),
         ]
-    full = [l for l in layers if l.intermediate is not None and l.output is not None]
-    if len(full) == len(layers):
-        groups += [
-            flat((l.intermediate_query.dense.weight, l.intermediate.dense.weight) for l in layers),
-            flat((l.intermediate_query.dense.bias, l.intermediate.dense.bias) for l in layers),
-            flat((l.output_query.dense.weight, l.output.dense.weight) for l in layers),
-            flat((l.output_query.dense.bias, l.output.dense.bias) for l in layers),
-            flat((l.output_query.LayerNorm.weight, l.output.LayerNorm.weight) for l in layers),
-            flat((l.output_query.LayerNorm.bias, l.output.LayerNorm.bias) for l in layers),
-        ]
+        if cross:
+            groups += [
+                flat((l.crossattention.self.key.weight, l.crossattention.self.value.weight) for l in cross),
+                flat((l.crossattention.self.key.bias, l.crossattention.self.value.bias) for l in cross),
+                flat((l.crossattention.self.query.weight,) for l in cross),
+                flat((l.crossattention.self.query.bias,) for l in cross),
+                flat((l.crossattention.output.dense.weight,) for l in cross),
+            ]
+        if all(l.intermediate is not None and l.output is not None for l in layers):
+            groups += [
+                flat((l.intermediate_query.dense.weight, l.intermediate.dense.weight) for l in part),
+                flat((l.intermediate_query.dense.bias, l.intermediate.dense.bias) for l in part),
+                flat((l.output_query.dense.weight, l.output.dense.weight) for l in part),
+                flat((l.output_query.dense.bias, l.output.dense.bias) for l in part),
+                flat((l.output_query.LayerNorm.weight, l.output.LayerNorm.weight) for l in part),
+                flat((l.output_query.LayerNorm.bias, l.output.LayerNorm.bias) for l in part),
+            ]
     return [g for g in groups if len(g) > 1]
 
 

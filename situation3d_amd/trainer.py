@@ -92,8 +92,44 @@ def get_loss(data_dict, situation_loss_tag="__l2__quat__", use_aux_situation=Tru
     return loss, data_dict
 
 
+def storage_layout(model, param_lists, qf_cut=None):
+    """The order in which FlatAdamW lays `param_lists` (one list per parameter group) out in its flat buffers: the lists'
+    own (named_parameters) order, except that the head of every adjacency group of the Q-Former
+    (qformer.parameter_adjacency_groups) pulls the rest of its group in right behind it -- operands the Q-Former stacks
+    into one GEMM, and the layer-batched weight-gradient buffers, are then views of the flat storage.  qf_cut = k: two
+    kind-major arenas (layers below k, layers from k on), each one contiguous stretch of every list."""
+    from .qformer import parameter_adjacency_groups
+    groups = parameter_adjacency_groups(model, cut=qf_cut)
+    follow = {}
+    for grp in groups:
+        for p in grp[1:]:
+            follow[id(p)] = grp
+    heads = {id(g[0]): g for g in groups}
+
+    def ordered(params):
+        present = {id(p) for p in params}
+        out, done = [], set()
+        for p in params:
+            if id(p) in done or (id(p) in follow and id(follow[id(p)][0]) in present):
+                continue  # emitted together with the head of its group
+            out.append(p)
+            done.add(id(p))
+        final = []
+        for p in out:       # heads pull their followers in right behind them
+            final.append(p)
+            for q in heads.get(id(p), ())[1:]:
+                if id(q) in present:
+                    final.append(q)
+        return final
+
+    return [ordered(ps) for ps in param_lists]
+
+
 def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name="adamw",
-                    clip_value=1.0):
+                    clip_value=1.0, qf_cut=None):
+    """qf_cut (flat_adamw only): store the Q-Former's layers below / from this layer on as two arenas, for a data-parallel
+    step whose backward pass is cut there (graph_step.GraphedTrainStep reads the same number from the encoder's
+    `storage_cut`); None / 0: one arena."""
     no_decay_filter = ("bias", "LayerNorm.weight")
     decay, no_decay = [], []
     for n, p in model.named_parameters():
@@ -101,34 +137,12 @@ def build_optimizer(model, lr=2e-5, wd=0.05, betas=(0.9, 0.999), eps=1e-8, name=
             continue
         (no_decay if any(nd in n for nd in no_decay_filter) else decay).append(p)
     if name == "flat_adamw":
-        # storage order: keep the parameter sets the Q-Former stacks into one GEMM operand adjacent
-        from .qformer import parameter_adjacency_groups
-        follow = {}
-        for grp in parameter_adjacency_groups(model):
-            for p in grp[1:]:
-                follow[id(p)] = grp
-
-        def ordered(params):
-            present = {id(p) for p in params}
-            out, done = [], set()
-            for p in params:
-                if id(p) in done or (id(p) in follow and id(follow[id(p)][0]) in present):
-                    continue  # emitted together with the head of its group
-                out.append(p)
-                done.add(id(p))
-            # heads pull their followers in right behind them
-            final = []
-            heads = {id(g[0]): g for g in parameter_adjacency_groups(model)}
-            for p in out:
-                final.append(p)
-                for q in heads.get(id(p), ())[1:]:
-                    if id(q) in present:
-                        final.append(q)
-            return final
-
         # the groups keep named_parameters() order (what a torch.optim.AdamW / reference checkpoint indexes by:
         # lib/solver.py:657, train.py:262); only the flat buffers follow the adjacency order
-        layout = [ordered(decay), ordered(no_decay)]
+        layout = storage_layout(model, [decay, no_decay], qf_cut=qf_cut)
+        enc = getattr(getattr(getattr(model, "Qformer", None), "bert", None), "encoder", None)
+        if enc is not None:
+            enc.storage_cut = int(qf_cut) if qf_cut else None
     groups = [{"params": decay, "weight_decay": wd}, {"params": no_decay, "weight_decay": 0.0}]
     if name == "flat_adamw":
         # clip_grad_value_(1.0) + AdamW + zero_grad as one streaming kernel per group (optim.py)

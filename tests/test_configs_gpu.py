@@ -271,6 +271,36 @@ def test_config5_blip2_shape_nk80000_forward_backward_matches_oracle():
     assert n >= 6 * 5
 
 
+def test_a_reused_encoder_buffer_is_split_again_every_forward():
+    """Qformer.bert handed the SAME encoder tensor object (>= 8192 rows: the planes path) refilled in ways that do not
+    advance its autograd version -- a `.data` write, as a static hipGraph input or a raw-pointer kernel would do: the
+    second forward must see the new contents (the planes of the encoder tokens live for one encoder forward only;
+    a process-wide cache keyed on identity + `_version` returned the previous batch's planes here)."""
+    from situation3d_amd import qformer
+    from situation3d_amd.blip2 import Blip2PointQFormer
+    torch.manual_seed(61)
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = Blip2PointQFormer(point_width=96, qformer_overrides=small).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    a, b_ = torch.randn(2, 4608, 96, generator=g).to(DEV), torch.randn(2, 4608, 96, generator=g).to(DEV)
+    assert qformer._big_source(a, 2 * 128)
+    q = model.query_tokens.expand(2, -1, -1)
+
+    def run(enc):
+        with torch.no_grad():
+            return model.Qformer.bert(query_embeds=q, encoder_hidden_states=enc,
+                                      encoder_attention_mask=torch.ones(2, enc.shape[1], device=DEV)).last_hidden_state
+    ref_a, ref_b = run(a.clone()), run(b_.clone())
+    assert not torch.allclose(ref_a, ref_b, atol=1e-3)
+    buf = a.clone()
+    version = buf._version
+    assert torch.equal(run(buf), ref_a)
+    buf.data.copy_(b_)                       # refilled behind autograd's back
+    assert buf._version == version
+    assert torch.equal(run(buf), ref_b)
+
+
 @pytest.mark.parametrize("own_gemm,own_dw", [(0, False), (64, False), (127, False), (0, True)])
 def test_full_size_qformer_forward_backward_matches_oracle(own_gemm, own_dw, monkeypatch):
     """768 wide / 12 layers / 12 heads / 6 cross-attention layers, B = 8, 32 queries + 20 question tokens,

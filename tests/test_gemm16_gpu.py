@@ -56,7 +56,7 @@ SHAPES = [(416, 2304, 768), (256, 768, 3072), (64, 64, 32), (100, 36, 72), (37, 
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
-@pytest.mark.parametrize("config", [0, 1, 2, 3, 11, 12])
+@pytest.mark.parametrize("config", [0, 1, 2, 3])
 def test_forward_product_bias_gelu(m, n, k, config):
     """y = x W^T + b; gelu(y) with the pre-activation kept (BertIntermediate, Qformer.py:305-313)."""
     out, _, ref, _ = _run(0, 1, m, n, k, bias=True, config=config)
@@ -67,7 +67,7 @@ def test_forward_product_bias_gelu(m, n, k, config):
 
 
 @pytest.mark.parametrize("m,n,k", [(m, (n + 3) // 4 * 4, k) for m, n, k in SHAPES])   # n-contiguous rows: n % 4 == 0
-@pytest.mark.parametrize("config", [0, 1, 2, 3, 11, 12])
+@pytest.mark.parametrize("config", [0, 1, 2, 3])
 def test_input_gradient_product(m, n, k, config):
     """dx = dy W with the weight read along its rows (bmode 1), plain, times gelu'(pre), plus the residual gradient."""
     out, _, ref, _ = _run(1, 1, m, n, k, config=config)
@@ -85,7 +85,7 @@ def test_input_gradient_product(m, n, k, config):
                                           (100, 36, 200, 2), (37, 132, 96, 3), (64, 64, 64, 2), (50, 52, 2048, 8)])
 def test_split_reduction_writes_slabs_that_sum_to_the_product(bmode, m, n, k, splits):
     """Every split writes its own slab (bias and addend go with split 0): nothing is pre-zeroed, nothing is atomic."""
-    for config in (1, 2, 3, 11, 12):
+    for config in (1, 2, 3):
         out, _, ref, _ = _run(bmode, 1, m, n, k, bias=True, addend=True, splits=splits, config=config)
         _close(out, ref)
         out, _, ref, _ = _run(bmode, 1, m, n, k, addend=True, in_place=True, splits=splits, config=config)
@@ -93,26 +93,13 @@ def test_split_reduction_writes_slabs_that_sum_to_the_product(bmode, m, n, k, sp
 
 
 @pytest.mark.parametrize("bmode", [0, 1])
-@pytest.mark.parametrize("config", [0, 11, 12])
+@pytest.mark.parametrize("config", [0])
 def test_batched_feed_forward_pair(bmode, config):
     """The query branch and the text branch of a layer (different weights, biases) as one launch of batch 2."""
     out, aux, ref, pre = _run(bmode, 2, 256, 3072, 768, act=(1 if bmode == 0 else 2), bias=(bmode == 0), config=config)
     _close(out, ref)
     out, _, ref, _ = _run(bmode, 2, 256, 768, 3072, addend=True, splits=5, bias=(bmode == 0), config=config)
     _close(out, ref)
-
-
-@pytest.mark.parametrize("bmode", [0, 1])
-@pytest.mark.parametrize("config", [11, 12])
-def test_six_bf16_products_are_closer_to_float64_than_an_f32_product(bmode, config):
-    """gemmx6_core.h: a = a1 + a2 + a3 in bf16, six of the nine cross products, f32 accumulation -- not a reduced
-    precision: on the step's shapes the error against float64 is BELOW the f32 core's (and torch's)."""
-    for m, n, k in [(416, 2304, 768), (416, 768, 3072)]:
-        x6, _, ref, _ = _run(bmode, 1, m, n, k, config=config)
-        f32, _, _, _ = _run(bmode, 1, m, n, k, config=1)
-        scale = float(ref.abs().max())
-        e6, e32 = float((x6 - ref).abs().max()) / scale, float((f32 - ref).abs().max()) / scale
-        assert e6 < 2e-6 and e6 <= 1.5 * e32, (e6, e32)
 
 
 def test_heuristic_splits_are_usable():

@@ -293,3 +293,56 @@ def test_ball_query_levels_workspace_is_host_arithmetic():
         2 * 5000 * 4 * 257 + 2 * ((8192 * 4 + 4096 * 16) + (2048 * 4 + 904 * 16))        # two blocks of centres
     assert lib.sig3d_ball_query_levels_workspace_bytes(1, 1, levels([(50000, 17 * 4096, 8, 0.3)])) == -1
     assert lib.sig3d_ball_query_levels_workspace_bytes(0, 1, stack) == 0
+
+
+def test_storage_layout_keeps_two_arenas_when_the_backward_pass_is_cut_inside_the_qformer():
+    """trainer.storage_layout: the order FlatAdamW lays the parameters out in.  One arena: every kind runs over all
+    layers (the layer-batched weight-gradient buffers are slices of the flat gradients).  qf_cut = k: the layers below
+    and from k on are two arenas, each ONE stretch of every parameter group -- a backward pass cut there (graph_step)
+    then owns one stretch per piece instead of a slice per kind -- and inside an arena the kinds still run over its
+    layers, [Wq; Wk; Wv] back to back."""
+    import torch.nn as nn
+    from situation3d_amd.qformer import init_Qformer
+    from situation3d_amd.trainer import storage_layout
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pre = nn.Linear(8, 8)
+            self.Qformer, self.query_tokens = init_Qformer(32, 64, hidden_size=64, num_hidden_layers=6,
+                                                           num_attention_heads=2, intermediate_size=128,
+                                                           max_position_embeddings=64)
+            self.head = nn.Linear(64, 4)
+
+    net = Net()
+    names = {id(p): n for n, p in net.named_parameters()}
+    decay = [p for n, p in net.named_parameters() if "bias" not in n and "LayerNorm.weight" not in n]
+    no_decay = [p for n, p in net.named_parameters() if "bias" in n or "LayerNorm.weight" in n]
+
+    def layer_of(p):
+        n = names[id(p)]
+        return int(n.split("encoder.layer.")[1].split(".")[0]) if "encoder.layer." in n else None
+
+    for cut in (None, 4):
+        for lst, laid in zip((decay, no_decay), storage_layout(net, [decay, no_decay], qf_cut=cut)):
+            assert sorted(map(id, laid)) == sorted(map(id, lst))                  # a permutation
+            side = [None if layer_of(p) is None else int(layer_of(p) >= (cut or 0)) for p in laid]
+            layered = [x for x in side if x is not None]
+            if cut:
+                # lower arena, then upper arena: one switch, and no non-layer parameter in between
+                assert layered == sorted(layered) and 0 < sum(layered) < len(layered)
+                first, last = side.index(0), len(side) - 1 - side[::-1].index(1)
+                assert None not in side[first:last + 1]
+            order = [names[id(p)] for p in laid]
+            for l in range(6):       # [Wq; Wk; Wv] (or their biases) of a layer are adjacent in either layout
+                pre = "Qformer.bert.encoder.layer.%d.attention.self." % l
+                kind = "weight" if lst is decay else "bias"
+                i = order.index(pre + "query." + kind)
+                assert order[i + 1:i + 3] == [pre + "key." + kind, pre + "value." + kind]
+        dec = [names[id(p)] for p in storage_layout(net, [decay, no_decay], qf_cut=cut)[0]]
+        i = dec.index("Qformer.bert.encoder.layer.0.attention.self.value.weight")
+        nxt = "Qformer.bert.encoder.layer.1.attention.self.query.weight"
+        assert dec[i + 1] == nxt                                                   # kind-major inside an arena
+        i = dec.index("Qformer.bert.encoder.layer.3.attention.self.value.weight")
+        after = dec[i + 1]
+        assert (after == "Qformer.bert.encoder.layer.4.attention.self.query.weight") == (cut is None)

@@ -283,19 +283,16 @@ def test_geometry_plan_equals_inline_ops(hip_ext):
             cur = new
 
 
-@pytest.mark.parametrize("prefetch", [False, True, "depth2", "depth3", "depth2-streamwait", "inline-fork", "tokens",
-                                      "broken-order"])
+@pytest.mark.parametrize("prefetch", [False, True, "depth2", "depth3", "depth2-streamwait", "tokens", "broken-order"])
 def test_graphed_step_matches_eager(prefetch, monkeypatch):
     """hipGraph replay (without prefetch; with the geometry chains of the next 1 / 2 / 3 batches in flight as graphs of
-    their own -- geometry.GeometryPipeline, behind the device-side handshake or a stream wait; with rounds 1-2's
-    branch forked inside the step's graph) reproduces the eager training trajectory: same losses for the same
+    their own -- geometry.GeometryPipeline, behind the device-side handshake or a stream wait) reproduces the eager
+    training trajectory: same losses for the same
     batches.  "tokens": the hand-over keyed on the caller's ids; "broken-order": a caller that announces one batch
     and runs another pays inline chains and still gets the right plans."""
     depth = {"depth2": 2, "depth3": 3, "depth2-streamwait": 2, "tokens": 2, "broken-order": 2}.get(prefetch, 1)
     if prefetch == "depth2-streamwait":
         monkeypatch.setenv("SIG3D_GEO_HANDSHAKE", "0")
-    if prefetch == "inline-fork":
-        monkeypatch.setenv("SIG3D_GEO_FORK", "inline")
     mode, prefetch = prefetch, bool(prefetch)
     from situation3d_amd.graph_step import GraphedTrainStep
     from situation3d_amd.model import SIG3DQFormer
@@ -358,30 +355,34 @@ def test_graphed_step_matches_eager(prefetch, monkeypatch):
     torch.testing.assert_close(torch.tensor(graph), torch.tensor(eager), rtol=2e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("split", [False, True, "qf"])
-def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split, monkeypatch):
+@pytest.mark.parametrize("split", [False, True, "qf", "qf-two-arenas", "two-arenas-uncut", "two-arenas-one-graph"])
+def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split):
     """The N > 1 step structure at world size 1: graph (forward + backward + gradient gather) ->
     per-bucket all-reduce -> AdamW bucket by bucket (optim.FlatAdamW.step_after) must follow the
     same loss trajectory as the plain eager FlatAdamW step.  split=True: the backward pass is cut at
     the point encoder's output (two graphs, two bucket sets) so that the Q-Former gradients are on
-    the wire while the encoder's backward runs.  split="qf": a third piece, the cut inside the Q-Former
-    (SIG3D_QF_CUT, opt-in)."""
-    if split == "qf":
-        monkeypatch.setenv("SIG3D_QF_CUT", "1")
+    the wire while the encoder's backward runs.  "qf": a third piece, the cut inside the Q-Former, over ONE kind-major
+    arena of parameters (the pieces interleave in storage: correct, slow); "qf-two-arenas": the same cut over the
+    storage made for it (build_optimizer(qf_cut=k): the layers below and above the cut as two arenas, each piece of
+    the backward pass one stretch of the flat gradients -- the stacked key / value weights, the deferred weight
+    gradients and the scene-token gradient all have a run per arena); "two-arenas-uncut" / "-one-graph": that storage
+    under a step that does not cut there (flushes and the token gradient then span both arenas)."""
+    two_arenas = isinstance(split, str) and "two-arenas" in split
+    step_cut = 2 if split in ("qf", "qf-two-arenas") else (0 if two_arenas else None)
     from situation3d_amd.ddp import GradBucketReducer
     from situation3d_amd.graph_step import GraphedTrainStep
     from situation3d_amd.model import SIG3DQFormer
     from situation3d_amd.trainer import build_optimizer, train_step
-    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+    small = dict(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
                  max_position_embeddings=64, hidden_dropout_prob=0.0)
 
-    def make():
+    def make(qf_cut=None):
         torch.manual_seed(5)
         m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):
                 mod.p = 0.0
-        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
+        return m, build_optimizer(m, lr=1e-3, name="flat_adamw", qf_cut=qf_cut)
 
     g = torch.Generator().manual_seed(1)
     batches = []
@@ -407,13 +408,19 @@ def test_graphed_data_parallel_step_with_bucketed_update_matches_eager(split, mo
         table_grad = m1.Qformer.bert.embeddings.word_embeddings.weight.grad.clone()
         o1.zero_grad()
         eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(5)]
-        m2, o2 = make()
+        m2, o2 = make(qf_cut=2 if two_arenas else None)
+        assert m2.Qformer.bert.encoder.storage_cut == (2 if two_arenas else None)
         reducer = GradBucketReducer.from_flat(o2.flat_grad_buffers(), bucket_bytes=1 << 20)
         assert reducer.num_collectives() > 2
+        split = split != "two-arenas-one-graph" and bool(split)
         gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=True, reducer=reducer,
-                              split_backward=bool(split))
-        assert gs._bucketed_update and gs._split == bool(split)
-        assert (gs._qf_cut == 1) == (split == "qf")
+                              split_backward=split, qf_cut=step_cut)
+        assert gs._bucketed_update and gs._split == split
+        assert gs._qf_cut == (2 if step_cut else None)
+        if step_cut and two_arenas:
+            # each piece of the backward pass owns few, long stretches of the flat gradients (an arena per group + the heads)
+            runs = o2.flat_grad_parts([gs._upper_params, gs._lower_params])
+            assert len(runs[0]) + len(runs[1]) <= 8, [len(r) for r in runs]
         # split form: the word-embedding table's gradient travels as rows (ddp.SparseRowExchange), not in a bucket
         assert (gs._emb_sink is not None) == bool(split)
         graph = []
@@ -800,65 +807,6 @@ def test_fused_bert_embeddings_dropout_and_row_sink():
     torch.testing.assert_close(emb.word_embeddings.weight.grad, dense, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("prefetch", [False, True])
-def test_graphed_step_with_the_upper_update_on_its_own_stream_matches_eager(prefetch):
-    """GraphedTrainStep(update_beside=1): forward + upper backward | FlatAdamW over the Q-Former and the heads on a
-    stream of its own, beside the graph of the point encoder's backward pass and update.  Same trajectory as the eager steps, and the
-    same parameters afterwards as the plain one-graph form (float atomics: tolerance)."""
-    from situation3d_amd.graph_step import GraphedTrainStep
-    from situation3d_amd.model import SIG3DQFormer
-    from situation3d_amd.trainer import build_optimizer, train_step
-    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
-                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-
-    def make():
-        torch.manual_seed(3)
-        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
-        for mod in m.modules():
-            if isinstance(mod, torch.nn.Dropout):
-                mod.p = 0.0
-        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
-
-    g = torch.Generator().manual_seed(0)
-    batches = []
-    for i in range(3):
-        b, n = 2, 5000
-        xyz = torch.rand(b, n, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
-        batches.append({
-            "point_clouds": torch.cat([xyz, torch.rand(b, n, 3, generator=g)], -1).to(DEV),
-            "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * b).to(DEV),
-            "q_feat": {"input_ids": torch.randint(1, 100, (b, 20), generator=g).to(DEV),
-                       "attention_mask": torch.ones(b, 20, dtype=torch.long, device=DEV)},
-            "answer_cat_scores": torch.zeros(b, 16, device=DEV),
-        })
-    work = torch.cuda.Stream()
-    with torch.cuda.stream(work):
-        m1, o1 = make()
-        for _ in range(3):
-            train_step(m1, o1, dict(batches[0]))
-        eager = [float(train_step(m1, o1, dict(batches[i % 3])).item()) for i in range(6)]
-        runs = {}
-        for beside in (0, 1):
-            m2, o2 = make()
-            gs = GraphedTrainStep(m2, o2, batches[0], prefetch_geometry=prefetch, update_beside=beside)
-            assert gs._beside == (beside == 1)
-            losses = [float(gs(batches[i % 3], batches[(i + 1) % 3]).item()) for i in range(6)]
-            work.synchronize()
-            runs[beside] = (losses, {n_: p.detach().clone() for n_, p in m2.named_parameters()})
-    torch.cuda.synchronize()
-    for beside in (0, 1):
-        torch.testing.assert_close(torch.tensor(runs[beside][0]), torch.tensor(eager), rtol=2e-3, atol=1e-4)
-    # parameters: Adam turns a gradient element that is pure rounding noise into a step of +-lr, so single elements may
-    # differ by a few lr; the parameter vectors as wholes must agree
-    def rel(a, b):
-        num = sum(float((a[k].double() - b[k].double()).pow(2).sum()) for k in a)
-        den = sum(float(b[k].double().pow(2).sum()) for k in a)
-        return (num / den) ** 0.5
-    eager_params = {n_: p.detach() for n_, p in m1.named_parameters()}
-    assert rel(runs[1][1], runs[0][1]) < 2e-3
-    assert rel(runs[1][1], eager_params) < 2e-3
-
-
 def test_an_eager_step_between_two_replays_leaves_the_captured_update_intact():
     """The short last batch of an epoch runs as an eager train_step between two replays of the graphed step, on the
     same FlatAdamW.  The captured update uploads its chunk table from a pinned staging buffer at every replay; that
@@ -902,3 +850,56 @@ def test_an_eager_step_between_two_replays_leaves_the_captured_update_intact():
         got.append(float(gs(full0).item()))
     torch.cuda.synchronize()
     torch.testing.assert_close(torch.tensor(got), torch.tensor(eager), rtol=2e-3, atol=1e-4)
+
+
+def test_a_dozen_captured_steps_over_one_optimizer_each_with_tables_of_its_own():
+    """The reference's BatchNorm momentum schedule (lib/solver.py:252-254) takes ten values in a run, and every change
+    needs a new GraphedTrainStep over the SAME optimizer (its Adam moments must survive).  Every capture reads pinned
+    gradient tables of its own (optim.CaptureTables, owned by the step object): twelve rebuilds in a row work, an old
+    and a new object replayed alternately do not walk each other's gradient pointers, and the trajectory is the eager one."""
+    import gc
+    from situation3d_amd.graph_step import GraphedTrainStep
+    from situation3d_amd.model import SIG3DQFormer
+    from situation3d_amd.trainer import build_optimizer, train_step
+    small = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                 max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def make():
+        torch.manual_seed(7)
+        m = SIG3DQFormer(num_answers=16, qformer_overrides=small, vocab_size=100).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m, build_optimizer(m, lr=1e-3, name="flat_adamw")
+
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.rand(2, 5000, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    bt = {"point_clouds": torch.cat([xyz, torch.rand(2, 5000, 3, generator=g)], -1).to(DEV),
+          "auxiliary_task": torch.tensor([[1.0, 2.0, 0.5, 0.0, 0.0, 0.6, 0.8]] * 2).to(DEV),
+          "q_feat": {"input_ids": torch.randint(1, 100, (2, 20), generator=g).to(DEV),
+                     "attention_mask": torch.ones(2, 20, dtype=torch.long, device=DEV)},
+          "answer_cat_scores": torch.zeros(2, 16, device=DEV)}
+    work = torch.cuda.Stream()
+    with torch.cuda.stream(work):
+        m1, o1 = make()
+        n_builds, warm = 12, 1
+        eager = [float(train_step(m1, o1, dict(bt)).item()) for _ in range(n_builds * (warm + 1) + 4)]
+        m2, o2 = make()
+        got, prev = [], None
+        for k in range(n_builds):
+            gs = GraphedTrainStep(m2, o2, bt, warmup=warm)      # `warm` eager steps on the same batch, then the capture
+            got += [None] * warm
+            got.append(float(gs(bt).item()))
+            if k < n_builds - 1:
+                prev = None
+                del gs
+                gc.collect()
+            else:
+                prev = gs
+        other = GraphedTrainStep(m2, o2, bt, warmup=0)          # two live objects, replayed alternately
+        for step in (prev, other, prev, other):
+            got.append(float(step(bt).item()))
+        assert other._opt_tables is not prev._opt_tables and o2.capture_tables is None
+    torch.cuda.synchronize()
+    pairs = [(a, b) for a, b in zip(got, eager) if a is not None]
+    torch.testing.assert_close(torch.tensor([a for a, _ in pairs]), torch.tensor([b for _, b in pairs]), rtol=2e-3, atol=1e-4)

@@ -13,7 +13,6 @@
 #include <string>
 #include <vector>
 #include "../../situation3d_amd/csrc/gemm16_core.h"
-#include "../../situation3d_amd/csrc/gemmx6_core.h"
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -58,10 +57,6 @@ struct Config { const char *name; int id; };
 
 static hipError_t run_config(int id, const gemm16::Problem &p, int bmode, hipStream_t s) {
   switch (id) {
-    case 20: return gemmx6::launch<1, 1, 2, 4, 4>(p, bmode, s);     // bf16 x 6 core: 64 x 128, 8 waves of 32 x 32
-    case 21: return gemmx6::launch<1, 2, 2, 2, 4>(p, bmode, s);     //                64 x 128, 4 waves of 32 x 64
-    case 22: return gemmx6::launch<1, 2, 4, 2, 4>(p, bmode, s);     //                128 x 128, 8 waves of 32 x 64
-    case 23: return gemmx6::launch<1, 2, 2, 4, 4>(p, bmode, s);     //                64 x 256, 8 waves of 32 x 64
 #define X(ID, AB, BB, WGM, WGN, PF, OCC) case ID: return gemm16::launch<AB, BB, WGM, WGN, PF, OCC>(p, bmode, s);
     CONFIGS(X)
 #undef X

@@ -46,7 +46,7 @@ with open(dst, "w") as f:
             return "torch glue (aten elementwise / cat / copy / fill)"
         if "rccl" in name.lower() or "nccl" in name.lower():
             return "RCCL"
-        if "gemm16_kernel" in name or "gemmp_kernel" in name or "gemmx6_kernel" in name:
+        if "gemm16_kernel" in name or "gemmp_kernel" in name:
             return "own GEMM (gemm16 / gemmp kernels)"
         return "own HIP kernels"
     agg = {}
