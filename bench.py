@@ -53,7 +53,9 @@ def parse_args(argv=None):
     # round 5: THREE chains in flight.  Since the main chain lost another ~0.5 ms in round 4 the step waited for its
     # geometry in every step (tools/probes/chain_slack.py: +0.05 ... +0.18 ms); with the chain two more steps ahead it
     # does not: -0.065 ms at depth 2, -0.094 at depth 3, +0.01 from 2 to 4 (tools/ab_step.py env:SIG3D_GEO_DEPTH)
-    ap.add_argument("--qf-cut", type=int, default=int(os.environ.get("SIG3D_QF_CUT", "0")),
+    # round 6: measured at world size 1 behind a real RCCL group of one (tools/cut_ab.sh, three alternating pairs):
+    # 8.93 -> 8.52 ms per step, exposed joins 0.39 -> 0.18 ms -- the second cut pays even before there is a wire
+    ap.add_argument("--qf-cut", type=int, default=int(os.environ.get("SIG3D_QF_CUT", "6")),
                     help="data-parallel forms only: cut the backward pass after this Q-Former layer as well (three graphs, three "
                          "bucket sets; the optimizer stores the layers below / above it as two arenas) so that the upper "
                          "layers' gradients are on the wire while the lower layers compute; 0 = one cut, at the scene tokens")
@@ -518,9 +520,11 @@ def ops_roofline(device, seed=1234):
     work = torch.empty(max(_lib.bq_levels_workspace_bytes(BATCH, arr), 16), dtype=torch.uint8, device=device)
     outs = [torch.empty(BATCH, 3 + c, m, ns, device=device) for n, m, ns, c in SA_LEVELS]
     s = _lib.stream_ptr(device)
-    reps, t_bq, t_gr = 5, [], []
+    garr = _lib.group_levels([(xyz, nxt, radius, idx, feats[li], c >= 32, outs[li])
+                              for li, ((n, m, ns, c), (xyz, nxt, radius, _, idx)) in enumerate(zip(SA_LEVELS, probs))])
+    reps, t_bq, t_gr, t_one = 5, [], [], []
     for it in range(reps + 2):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
         ev[0].record()
         _lib.call("sig3d_ball_query_levels", BATCH, len(arr), arr, _lib.ptr(work), work.numel(), s)
         ev[1].record()
@@ -532,24 +536,32 @@ def ops_roofline(device, seed=1234):
                 _lib.call("sig3d_query_group_fused", BATCH, n, m, c, ns, 1, 1, ctypes.c_float(radius), _lib.ptr(xyz),
                           _lib.ptr(nxt), _lib.ptr(feats[li]), _lib.ptr(idx), _lib.ptr(outs[li]), s)
             ev[2 + li].record()
+        # the same four groupings as ONE launch (sig3d_query_group_levels: every list exists once the ball query has run)
+        _lib.call("sig3d_query_group_levels", BATCH, len(garr), garr, s)
+        ev[6].record()
         torch.cuda.synchronize()
         if it >= 2:
             t_bq.append(ev[0].elapsed_time(ev[1]))
             t_gr.append([ev[1 + li].elapsed_time(ev[2 + li]) for li in range(4)])
+            t_one.append(ev[5].elapsed_time(ev[6]))
     bq_ms = sum(t_bq) / reps
     gr_ms = [sum(t[li] for t in t_gr) / reps for li in range(4)]
     bq_bytes = sum(ball_query_algorithmic_bytes(BATCH, n, m, ns) for n, m, ns, _ in SA_LEVELS)
     gr_bytes = [group_algorithmic_bytes(BATCH, n, m, ns, c) for n, m, ns, c in SA_LEVELS]
-    total_ms, total_b = bq_ms + sum(gr_ms), bq_bytes + sum(gr_bytes)
+    one_ms = sum(t_one) / reps
+    per_level_gbs = sum(gr_bytes) / (sum(gr_ms) * 1e-3) / 1e9
+    total_ms, total_b = bq_ms + one_ms, bq_bytes + sum(gr_bytes)
     gbs = total_b / (total_ms * 1e-3) / 1e9
-    grp_gbs = sum(gr_bytes) / (sum(gr_ms) * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "ball_query (SA1-4, one launch pair) + query_group_fused[_pm] (SA1-4), dense lists, "
-                                      "BASELINE config 3 shapes, standalone launches through the C ABI",
+    grp_gbs = sum(gr_bytes) / (one_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "ball_query (SA1-4, one launch pair) + QueryAndGroup's grouping (SA1-4, one launch: "
+                                      "sig3d_query_group_levels), dense lists, BASELINE config 3 shapes, through the C ABI",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "algorithmic_bytes": total_b, "ms": round(total_ms, 4),
             "ball_query": {"ms": round(bq_ms, 4), "algorithmic_bytes": bq_bytes},
-            "group_points": {"ms": [round(t, 4) for t in gr_ms], "algorithmic_bytes": gr_bytes,
-                             "achieved": round(grp_gbs, 1), "frac": round(grp_gbs / HBM_PEAK_GBS, 4)}}
+            "group_points": {"ms": round(one_ms, 4), "algorithmic_bytes": gr_bytes,
+                             "achieved": round(grp_gbs, 1), "frac": round(grp_gbs / HBM_PEAK_GBS, 4),
+                             "per_level_launches": {"ms": [round(t, 4) for t in gr_ms], "achieved": round(per_level_gbs, 1),
+                                                    "frac": round(per_level_gbs / HBM_PEAK_GBS, 4)}}}
 
 
 def forward_only_variant(device, bsz=4, reps=20):

@@ -140,9 +140,6 @@ int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, vo
  * (b, levels sizes) since it was last written by anyone else: the per-centre counters are then zero (the rank kernel
  * zeroes each one it reads) and the memset in front of the launch pair is skipped.  flags = 0 is always safe. */
 #define SIG3D_BQ_CLEAN 1
-/* SIG3D_BQ_SHARED_TABLE: a pre-pass (one workgroup per scene of a big level) builds the table of the scene's centres
- * once and the scatter workgroups copy it, instead of every workgroup sorting the centres itself. */
-#define SIG3D_BQ_SHARED_TABLE 4
 int sig3d_ball_query_levels_ex(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
                                long workspace_bytes, int flags, void *stream);
 /* The same call, counting its work: *stats (a device word the caller zeroes) += the centre-point distance tests the
@@ -228,6 +225,21 @@ int sig3d_query_group_fused(int b, int n, int m, int c, int nsample, int use_xyz
                             int normalize_xyz, float radius, const float *xyz,
                             const float *new_xyz, const float *features, const int *idx,
                             float *out, void *stream);
+
+/* QueryAndGroup's grouping of SEVERAL set-abstraction levels as ONE launch (pointnet2_utils.py:348-359 per level;
+ * group_points_gpu.cu:8-28): the neighbour lists of all levels exist once sig3d_ball_query_levels has run, so a stack's
+ * four bandwidth-sized launches -- each with a ramp and a tail of its own -- become one grid (largest level first).
+ * Each level is exactly sig3d_query_group_fused (point_major == 0: features (b,c,n), nsample % 4 == 0) or
+ * sig3d_query_group_fused_pm (point_major != 0: features (b,n,ld)) with the same arguments; same bits out. */
+typedef struct sig3d_group_level {
+  int n, m, c, ld, nsample;
+  int point_major, use_xyz, normalize_xyz;
+  float radius;
+  const float *xyz, *new_xyz, *features;
+  const int *idx;
+  float *out;
+} sig3d_group_level;
+int sig3d_query_group_levels(int b, int nlevels, const sig3d_group_level *levels, void *stream);
 
 /* Same result, bit for bit, from POINT-MAJOR features: features_pm (b,n,ld) holds the c channels of
  * point k at features_pm[(b*n + k)*ld .. +c) (c % 4 == 0, ld % 4 == 0, 16-byte aligned), so a neighbour is

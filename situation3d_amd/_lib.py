@@ -260,7 +260,6 @@ SIGNATURES["sig3d_ball_query_levels"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ct
 SIGNATURES["sig3d_ball_query_levels_ex"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P]
 SIGNATURES["sig3d_ball_query_levels_stats"] = [_I, _I, ctypes.POINTER(BqLevel), _P, ctypes.c_long, _I, _P, _P]
 BQ_CLEAN = 1
-BQ_SHARED_TABLE = 4
 
 
 def bq_levels(problems):
@@ -269,6 +268,28 @@ def bq_levels(problems):
     for q, (xyz, new_xyz, radius, nsample, idx) in zip(arr, problems):
         q.n, q.m, q.nsample, q.radius = xyz.shape[1], new_xyz.shape[1], int(nsample), float(radius)
         q.xyz, q.new_xyz, q.idx = xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr()
+    return arr
+
+
+class GroupLevel(ctypes.Structure):
+    """sig3d_group_level of include/sig3d_hip.h: the grouping of one level inside sig3d_query_group_levels."""
+    _fields_ = [("n", _I), ("m", _I), ("c", _I), ("ld", _I), ("nsample", _I), ("point_major", _I), ("use_xyz", _I),
+                ("normalize_xyz", _I), ("radius", _F), ("xyz", _P), ("new_xyz", _P), ("features", _P), ("idx", _P),
+                ("out", _P)]
+
+
+SIGNATURES["sig3d_query_group_levels"] = [_I, _I, ctypes.POINTER(GroupLevel), _P]
+
+
+def group_levels(problems, use_xyz=True, normalize_xyz=True):
+    """problems: [(xyz (b,n,3), new_xyz (b,m,3), radius, idx (b,m,ns), features (b,c,n) or point-major (b,n,c), point_major,
+    out (b,3+c,m,ns))] -> ctypes array for sig3d_query_group_levels."""
+    arr = (GroupLevel * len(problems))()
+    for q, (xyz, new_xyz, radius, idx, feat, pm, out) in zip(arr, problems):
+        q.n, q.m, q.nsample, q.radius = xyz.shape[1], new_xyz.shape[1], idx.shape[2], float(radius)
+        q.c = feat.shape[2] if pm else feat.shape[1]
+        q.ld, q.point_major, q.use_xyz, q.normalize_xyz = q.c, int(bool(pm)), int(use_xyz), int(normalize_xyz)
+        q.xyz, q.new_xyz, q.features, q.idx, q.out = xyz.data_ptr(), new_xyz.data_ptr(), feat.data_ptr(), idx.data_ptr(), out.data_ptr()
     return arr
 
 

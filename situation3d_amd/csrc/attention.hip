@@ -1207,11 +1207,10 @@ extern "C" int sig3d_attention_fwd(int b, int h, int nq, int nk, int d, int q_se
   dim3 grid(h, ((nq + 31) / 32) * key_splits, b);
   (void)k_rows;
   const long rows = (long)b * h * nq;
-  // rotating K / V prefetch when a wave streams many key tiles (3D-LLM shapes); SIG3D_ATTN_FWD_PIPE=0/1 forces it
-  static const char *pipe_env = getenv("SIG3D_ATTN_FWD_PIPE");
+  // rotating K / V prefetch when a wave streams many key tiles (3D-LLM shapes)
   const int tiles_per_wave = ntiles_fwd / (key_splits * AT_WAVES);
   // (head size 64 only: at 96 the rotating form spills)
-  const bool pipe = d == 64 && (pipe_env ? pipe_env[0] == '1' : tiles_per_wave >= 4);
+  const bool pipe = d == 64 && tiles_per_wave >= 4;
 #define SIG3D_ATT_FWD(DD)                                                                                         \
   if (pipe)                                                                                                       \
     hipLaunchKernelGGL((attention_fwd_kernel<64, true>), grid, dim3(AT_WAVES * 64), 0, stream, h, nq, nk, q_seg,   \

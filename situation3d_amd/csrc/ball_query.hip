@@ -139,12 +139,10 @@ struct BqcLevel {
   int wg_begin;           // first scatter workgroup of the level
   int rank_wg_begin;      // first rank workgroup of the level
   int ctr_begin;          // first slot of the level in cnt / list (slot = bi * m + j)
-  long table_off;         // kind 0: byte offset of the level's prebuilt tables (scene bi: + bi * (4 H + 16 m))
 };
 struct BqcParams {
   int nlevels, b;
   unsigned long long *stats;   // or null: [0] += distance tests of the scatter kernel (bench.py's roofline_ball_query)
-  char *tables;                // or null: per-scene centre tables built ONCE by bqc_table_kernel (SIG3D_BQ_SHARED_TABLE)
   BqcLevel lv[BQC_MAXLV];
 };
 
@@ -212,31 +210,6 @@ __device__ __forceinline__ void bqc_build_table(int *s_end, float4 *s_ctr, int *
   __syncthreads();
 }
 
-// One workgroup per (kind-0 level, scene): the table above, written to global memory for the scene's ~40 scatter
-// workgroups to copy (SIG3D_BQ_SHARED_TABLE: VERDICT r04 item 6 asked for this form to be MEASURED).
-__global__ __launch_bounds__(BQC_THREADS) void bqc_table_kernel(BqcParams P, int b) {
-  extern __shared__ __attribute__((aligned(16))) int bqc_smem[];
-  __shared__ int s_wave[BQC_THREADS / 64];
-  int li = -1, rest = (int)blockIdx.x;
-  for (int i = 0; i < P.nlevels; ++i) {
-    if (P.lv[i].kind != 0) continue;
-    if (rest < b) { li = i; break; }
-    rest -= b;
-  }
-  if (li < 0) return;
-  const BqcLevel &L = P.lv[li];
-  const int bi = rest, m = L.m, H = L.hsize, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int *s_end = bqc_smem;
-  float4 *s_ctr = reinterpret_cast<float4 *>(bqc_smem + H);
-  const float *ctr = L.new_xyz + ((size_t)bi * L.m_total + L.c_off) * 3;
-  bqc_build_table(s_end, s_ctr, s_wave, ctr, m, H, L.inv_e, (unsigned)H - 1u, tid, lane, wave);
-  char *tb = P.tables + L.table_off + (size_t)bi * ((size_t)H * 4 + (size_t)m * 16);
-  int4 *ge = reinterpret_cast<int4 *>(tb);
-  float4 *gc = reinterpret_cast<float4 *>(tb + (size_t)H * 4);
-  for (int i = tid; i < H / 4; i += BQC_THREADS) ge[i] = reinterpret_cast<const int4 *>(s_end)[i];
-  for (int i = tid; i < m; i += BQC_THREADS) gc[i] = s_ctr[i];
-}
-
 __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, int *__restrict__ cnt,
                                                                   int *__restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) int bqc_smem[];
@@ -291,17 +264,7 @@ __global__ __launch_bounds__(BQC_THREADS) void bqc_scatter_kernel(BqcParams P, i
   float4 *s_ctr = reinterpret_cast<float4 *>(bqc_smem + H);     // [m] {x, y, z, centre}
   const float *ctr = L.new_xyz + ((size_t)bi * L.m_total + L.c_off) * 3;
 
-  if (P.tables != nullptr) {
-    // the scene's table was built once (bqc_table_kernel): 4 H + 16 m bytes from L2 instead of a counting sort per workgroup
-    const char *tb = P.tables + L.table_off + (size_t)bi * ((size_t)H * 4 + (size_t)m * 16);
-    const int4 *ge = reinterpret_cast<const int4 *>(tb);
-    const float4 *gc = reinterpret_cast<const float4 *>(tb + (size_t)H * 4);
-    for (int i = tid; i < H / 4; i += BQC_THREADS) reinterpret_cast<int4 *>(s_end)[i] = ge[i];
-    for (int i = tid; i < m; i += BQC_THREADS) s_ctr[i] = gc[i];
-    __syncthreads();
-  } else {
-    bqc_build_table(s_end, s_ctr, s_wave, ctr, m, H, inv_e, hmask, tid, lane, wave);
-  }
+  bqc_build_table(s_end, s_ctr, s_wave, ctr, m, H, inv_e, hmask, tid, lane, wave);
 
   // The chunk's points against the table, TWICE.  A returning global atomic per hit inside these divergent
   // loops made every loop trip a memory round trip (measured: 105 us at SA3, where 1024 points find 11 centres
@@ -487,9 +450,9 @@ __global__ __launch_bounds__(256) void bqc_rank_kernel(BqcParams P, int *__restr
 // Host side of a multi-level launch: fills P (splitting problems with more than BQC_MAXM centres into blocks)
 // and returns the workspace it needs, or -1 when the problems do not fit one launch.
 static long bqc_plan(int b, int nlevels, const sig3d_bq_level *levels, BqcParams *P, int *scatter_wgs,
-                     int *rank_wgs, size_t *lds_bytes, long *table_bytes = nullptr, int *table_wgs = nullptr) {
-  int nl = 0, wg = 0, rwg = 0, twg = 0;
-  long slots = 0, tbytes = 0;
+                     int *rank_wgs, size_t *lds_bytes) {
+  int nl = 0, wg = 0, rwg = 0;
+  long slots = 0;
   size_t lds = 0;
   for (int i = 0; i < nlevels; ++i) {
     const sig3d_bq_level &q = levels[i];
@@ -516,11 +479,6 @@ static long bqc_plan(int b, int nlevels, const sig3d_bq_level *levels, BqcParams
         L.chunks = sig3d_ceil_div(q.n, BQC_THREADS * BQC_PPT);
       }
       L.wg_begin = wg; L.rank_wg_begin = rwg; L.ctr_begin = (int)slots;
-      L.table_off = tbytes;
-      if (L.kind == 0) {
-        tbytes += (long)b * ((long)h * 4 + (long)L.m * 16);
-        twg += b;
-      }
       wg += b * L.chunks;
       // kind 1 writes its rows itself -- except for an empty scene (no workgroup at all): the rank kernel then
       // writes the zero rows from the zeroed counters
@@ -537,8 +495,6 @@ static long bqc_plan(int b, int nlevels, const sig3d_bq_level *levels, BqcParams
   if (scatter_wgs) *scatter_wgs = wg;
   if (rank_wgs) *rank_wgs = rwg;
   if (lds_bytes) *lds_bytes = lds;
-  if (table_bytes) *table_bytes = tbytes;
-  if (table_wgs) *table_wgs = twg;
   if (slots >= (1L << 22)) return -1;   // slot * BQC_CAP stays inside 31 bits
   return slots * (long)sizeof(int) * (1 + BQC_CAP);
 }
@@ -585,9 +541,7 @@ extern "C" long sig3d_ball_query_levels_workspace_bytes(int b, int nlevels, cons
   if (b <= 0 || nlevels <= 0 || levels == nullptr) return 0;
   BqcParams P;
   P.stats = nullptr;
-  long tbytes = 0;
-  const long need = bqc_plan(b, nlevels, levels, &P, nullptr, nullptr, nullptr, &tbytes);
-  return need < 0 ? need : (need + 15) / 16 * 16 + tbytes;     // counters + lists, then the shared tables
+  return bqc_plan(b, nlevels, levels, &P, nullptr, nullptr, nullptr);     // counters + lists
 }
 
 extern "C" int sig3d_ball_query_levels(int b, int nlevels, const sig3d_bq_level *levels, void *workspace,
@@ -615,17 +569,12 @@ extern "C" int sig3d_ball_query_levels_stats(int b, int nlevels, const sig3d_bq_
   BqcParams P;
   int wgs = 0, rwgs = 0;
   size_t lds = 0;
-  long tbytes = 0;
-  int twgs = 0;
-  const long need = bqc_plan(b, nlevels, levels, &P, &wgs, &rwgs, &lds, &tbytes, &twgs);
+  const long need = bqc_plan(b, nlevels, levels, &P, &wgs, &rwgs, &lds);
   SIG3D_REQUIRE(need >= 0, "too many problems / centres for one launch (16 blocks of 4096 centres)");
   P.stats = stats;
   if (P.nlevels == 0) return 0;
-  const bool shared = (flags & SIG3D_BQ_SHARED_TABLE) != 0 && twgs > 0;
-  const long need_all = (need + 15) / 16 * 16 + (shared ? tbytes : 0);
-  SIG3D_REQUIRE(need_all == 0 || (workspace != nullptr && workspace_bytes >= need_all),
+  SIG3D_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need),
                 "workspace too small: see sig3d_ball_query_levels_workspace_bytes");
-  P.tables = shared ? (char *)workspace + (need + 15) / 16 * 16 : nullptr;
   const long slots = need / (long)(sizeof(int) * (1 + BQC_CAP));
   int *cnt = (int *)workspace;
   int *list = cnt + slots;
@@ -633,13 +582,9 @@ extern "C" int sig3d_ball_query_levels_stats(int b, int nlevels, const sig3d_bq_
   // list) is clean: SIG3D_BQ_CLEAN lets the caller vouch for that and saves the memset node
   if (slots > 0 && !(flags & SIG3D_BQ_CLEAN)) SIG3D_HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)slots, stream));
   if (wgs > 0) {
-    if (lds > 48 * 1024) {
+    if (lds > 48 * 1024)
       SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)bqc_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-      SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)bqc_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-    }
-    if (shared) hipLaunchKernelGGL(bqc_table_kernel, dim3(twgs), dim3(BQC_THREADS), lds, stream, P, b);
     hipLaunchKernelGGL(bqc_scatter_kernel, dim3(wgs), dim3(BQC_THREADS), lds, stream, P, cnt, list);
   }
   if (rwgs > 0) hipLaunchKernelGGL(bqc_rank_kernel, dim3(rwgs), dim3(256), 0, stream, P, cnt, list);

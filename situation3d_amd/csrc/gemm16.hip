@@ -17,7 +17,6 @@
 
 namespace {
 
-const int SIG3D_GEMM16_TARGET_WGS = getenv("SIG3D_GEMM16_TARGET_WGS") ? atoi(getenv("SIG3D_GEMM16_TARGET_WGS")) : 0;
 
 int tiles_of(const sig3d_gemm16_problem &q, int tm, int tn) {
   return q.batch * sig3d_ceil_div(q.m, tm) * sig3d_ceil_div(q.n, tn);
@@ -37,8 +36,8 @@ int choose_splits(const sig3d_gemm16_problem &q, int config) {
   const int chunks = sig3d_ceil_div(q.k, gemm16::BK);
   // ~one workgroup per CU for short reductions, two for long ones (measured alone AND inside the training step:
   // 256 / 384 everywhere cost the step +0.15 / +0.07 ms against this rule although every slab is re-read by the
-  // LayerNorm tail that consumes the product); SIG3D_GEMM16_TARGET_WGS overrides both
-  const int target = SIG3D_GEMM16_TARGET_WGS > 0 ? SIG3D_GEMM16_TARGET_WGS : (q.k <= 1024 ? 256 : 512);
+  // LayerNorm tail that consumes the product)
+  const int target = q.k <= 1024 ? 256 : 512;
   int s = (target + t64 / 2) / (t64 > 0 ? t64 : 1);
   if (s > chunks / 4) s = chunks / 4;
   if (s > 8) s = 8;
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(int n4, int nslabs, size
   }
 }
 
-const int SIG3D_DW_STREAM_WGS = getenv("SIG3D_DW_STREAM_WGS") ? atoi(getenv("SIG3D_DW_STREAM_WGS")) : 512;
+constexpr int SIG3D_DW_STREAM_WGS = 512;   // workgroups a k-streaming weight gradient aims for (256 / 1024: slower in the step)
 
 // 131 / 259 input channels (3 coordinates in front of 128 / 256 features): 64-wide column tiles would give a third / a
 // fifth of the workgroups 3 live columns; 48-wide ones (4 waves of 16 x 48) waste 9-10 % instead

@@ -154,8 +154,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_grad_lds_kernel(
 // scene L % 8 (+ 8 per further round of scenes; b = 1, 2, 4: 8 / b XCDs share a scene): a scene's sources are then
 // fetched into ONE L2.  A pure speed choice (guide: placement may change speed only): any other dealing gives the same
 // result.  w is the workgroup's index inside its scene (0 .. per_scene - 1).
-__device__ __forceinline__ void xcd_local_scene(int b, int per_scene, int &scene, int &w) {
-  const int L = blockIdx.x;
+__device__ __forceinline__ void xcd_local_scene(int b, int per_scene, int &scene, int &w, int L = blockIdx.x) {
   if ((b & 7) == 0) {
     const int k = L >> 3;
     scene = (L & 7) + 8 * (k / per_scene);
@@ -181,16 +180,19 @@ __device__ __forceinline__ void gp_store4(float *o, float a, float b, float c, f
   else *reinterpret_cast<gp_f32x4 *>(o) = v;
 }
 
+// `wg`: the workgroup's number inside this problem's grid (blockIdx.x of a launch of its own; the multi-level launch
+// below hands every level a range of its grid that starts at a multiple of 8, so the XCD dealing is the same)
 template <bool VEC4, bool NT>
-__global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
-    int b, int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
+__device__ __forceinline__ void query_group_fused_body(
+    int wg, int b, int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
   const long total = (long)m * nsample;
   const int tiles_e = (int)(((VEC4 ? total / 4 : total) + GP_THREADS - 1) / GP_THREADS);
   const int slabs = (use_xyz ? 1 : 0) + (c + GP_CSLAB - 1) / GP_CSLAB;
   int bi, w;
-  xcd_local_scene(b, tiles_e * slabs, bi, w);
+  xcd_local_scene(b, tiles_e * slabs, bi, w, wg);
+  if (bi >= b || w >= tiles_e * slabs) return;          // (the padding of a level's range in the multi-level launch)
   const int by = w / tiles_e, bx = w - by * tiles_e;
   const long e = ((long)bx * GP_THREADS + threadIdx.x) * (VEC4 ? 4 : 1);
   if (e >= total) return;
@@ -250,6 +252,15 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
   }
 }
 
+template <bool VEC4, bool NT>
+__global__ __launch_bounds__(GP_THREADS) void query_group_fused_kernel(
+    int b, int n, int m, int c, int nsample, int use_xyz, int normalize_xyz, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out) {
+  query_group_fused_body<VEC4, NT>((int)blockIdx.x, b, n, m, c, nsample, use_xyz, normalize_xyz, radius, xyz, new_xyz,
+                                   features, idx, out);
+}
+
 // ---- point-major variant of the fused grouping -------------------------------------------------
 // The (b,c,n) layout makes every grouped element a 4-byte gather per channel.  With the features
 // ALSO available point-major (b,n,ld) a neighbour's channels are one contiguous row: a workgroup takes
@@ -262,16 +273,16 @@ constexpr int GPM_C = 128;   // channels per tile
 // Compact mode (centre_of / n_act given, compact.hip): idx holds the DISTINCT neighbours of a batch element
 // back to back, centre_of their centres, n_act[b] how many there are; positions >= n_act[b] are not written.
 template <bool COMPACT>
-__global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
-    int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
+__device__ __forceinline__ void query_group_fused_pm_body(
+    int wg, gp_f32x4 *s_tile, int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
     const int *__restrict__ idx, float *__restrict__ out, const int *__restrict__ centre_of,
     const int *__restrict__ n_act) {
-  __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
   const int stride = m * nsample;                       // positions per (batch, channel) row of out
   const int tiles_e = (stride + GPM_P - 1) / GPM_P, tiles_c = (c + GPM_C - 1) / GPM_C;
   int bi, w;
-  xcd_local_scene(b, tiles_e * tiles_c, bi, w);
+  xcd_local_scene(b, tiles_e * tiles_c, bi, w, wg);
+  if (bi >= b || w >= tiles_e * tiles_c) return;        // (workgroup-uniform: the padding of a level's range)
   const int by = w / tiles_e, bx = w - by * tiles_e;    // element tile fastest: neighbours share source rows
   const int c0 = by * GPM_C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,6 +343,42 @@ __global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
         if (cc + k < c) __builtin_nontemporal_store(w4[q][k], o + (size_t)k * stride);
     }
   }
+}
+
+template <bool COMPACT>
+__global__ __launch_bounds__(GP_THREADS) void query_group_fused_pm_kernel(
+    int b, int n, int m, int c, int ld, int nsample, int use_xyz, int normalize_xyz, float radius,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, const float *__restrict__ feat_pm,
+    const int *__restrict__ idx, float *__restrict__ out, const int *__restrict__ centre_of,
+    const int *__restrict__ n_act) {
+  __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
+  query_group_fused_pm_body<COMPACT>((int)blockIdx.x, s_tile, b, n, m, c, ld, nsample, use_xyz, normalize_xyz, radius, xyz,
+                                     new_xyz, feat_pm, idx, out, centre_of, n_act);
+}
+
+// ---- QueryAndGroup of several set-abstraction levels in ONE launch (sig3d_query_group_levels) -----------------------
+// The grouping of a level is a bandwidth-sized launch of 10-30 us; four of them in a row each pay their own ramp and
+// tail (4.0 TB/s over the four against 4.9 for the largest alone).  Their neighbour lists all exist before the first
+// of them runs (sig3d_ball_query_levels), so one grid takes all of them: level ranges back to back, the largest first,
+// every range starting at a multiple of 8 workgroups so that a scene still meets one XCD's L2 (xcd_local_scene).
+struct GroupLevels {
+  int levels;
+  int first[5];                       // first workgroup of level l (first[levels] = grid size)
+  sig3d_group_level lv[4];
+};
+
+__global__ __launch_bounds__(GP_THREADS) void query_group_levels_kernel(GroupLevels g, int b) {
+  __shared__ gp_f32x4 s_tile[GPM_P * (GPM_C / 4)];
+  int l = 0;
+  while (l + 1 < g.levels && (int)blockIdx.x >= g.first[l + 1]) ++l;
+  const sig3d_group_level &v = g.lv[l];
+  const int wg = (int)blockIdx.x - g.first[l];
+  if (v.point_major)
+    query_group_fused_pm_body<false>(wg, s_tile, b, v.n, v.m, v.c, v.ld, v.nsample, v.use_xyz, v.normalize_xyz, v.radius,
+                                     v.xyz, v.new_xyz, v.features, v.idx, v.out, nullptr, nullptr);
+  else
+    query_group_fused_body<true, true>(wg, b, v.n, v.m, v.c, v.nsample, v.use_xyz, v.normalize_xyz, v.radius, v.xyz,
+                                       v.new_xyz, v.features, v.idx, v.out);
 }
 
 // (b,c,n) -> (b,n,c): 32x32 tiles through LDS, both sides coalesced
@@ -656,6 +703,47 @@ static int launch_group_grad_pm(int b, int n, int m, int c, int ld, int nsample,
   hipLaunchKernelGGL(group_points_grad_pm_kernel, grid, dim3(GP_THREADS), 0, stream, b, n, c, ld, (int)total, c_total,
                      c_off, grad_out, idx, grad_features_pm, n_act);
   SIG3D_LAUNCH_CHECK("group_points_grad_pm_kernel");
+  return 0;
+}
+
+extern "C" int sig3d_query_group_levels(int b, int nlevels, const sig3d_group_level *levels, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SIG3D_REQUIRE(b >= 0 && nlevels >= 1 && nlevels <= 4 && levels != nullptr, "1 to 4 levels");
+  if (b == 0) return 0;
+  long blocks[4];
+  int order[4];
+  for (int l = 0; l < nlevels; ++l) {
+    const sig3d_group_level &v = levels[l];
+    SIG3D_REQUIRE(v.n >= 1 && v.m >= 0 && v.c >= 0 && v.nsample >= 0, "bad level size");
+    SIG3D_REQUIRE(v.use_xyz || v.c > 0, "Cannot have not features and not use xyz as a feature!");
+    SIG3D_REQUIRE(v.c == 0 || v.features != nullptr, "features pointer is NULL with c > 0");
+    const long total = (long)v.m * v.nsample;
+    SIG3D_REQUIRE(total < (1L << 31) - GPM_P, "m * nsample too large");
+    if (v.point_major) {
+      SIG3D_REQUIRE(v.c >= 4 && v.c % 4 == 0 && v.ld % 4 == 0 && v.ld >= v.c && ((uintptr_t)v.features & 15) == 0,
+                    "point-major rows: c and ld multiples of 4, ld >= c, 16-byte aligned");
+      blocks[l] = (long)sig3d_ceil_div(total, GPM_P) * sig3d_ceil_div(v.c, GPM_C) * b;
+    } else {
+      SIG3D_REQUIRE(v.nsample % 4 == 0, "channel-major levels of the multi-level launch need nsample % 4 == 0");
+      blocks[l] = (long)sig3d_ceil_div(total / 4, GP_THREADS) * ((v.use_xyz ? 1 : 0) + sig3d_ceil_div(v.c, GP_CSLAB)) * b;
+    }
+    order[l] = l;
+  }
+  for (int i = 1; i < nlevels; ++i)          // largest level first: the small ones fill its tail
+    for (int j = i; j > 0 && blocks[order[j]] > blocks[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  GroupLevels g{};
+  long at = 0;
+  for (int k = 0; k < nlevels; ++k) {
+    g.first[k] = (int)at;
+    g.lv[k] = levels[order[k]];
+    at += (blocks[order[k]] + 7) / 8 * 8;
+    SIG3D_REQUIRE(at < (1L << 31), "sig3d_query_group_levels: more than 2^31 - 1 workgroups");
+  }
+  g.levels = nlevels;
+  g.first[nlevels] = (int)at;
+  if (at == 0) return 0;
+  hipLaunchKernelGGL(query_group_levels_kernel, dim3((unsigned)at), dim3(GP_THREADS), 0, stream, g, b);
+  SIG3D_LAUNCH_CHECK("query_group_levels_kernel");
   return 0;
 }
 

@@ -651,9 +651,8 @@ __global__ __launch_bounds__(1024) void fps_morton_order_kernel(int n, const flo
 template <int NT, int PPT, int W, bool BLOCKED = false>
 int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *temp, int *idxs,
                     hipStream_t stream) {
-  // one packed granule per workgroup and round when the key fits 16 bits (SIG3D_FPS_PACK=0: the two-granule form)
-  const char *pk = getenv("SIG3D_FPS_PACK");
-  const bool pack = n <= 65536 && m <= 65536 && L >= 6 && L <= 16 && !(pk && atoi(pk) == 0);
+  // one packed granule per workgroup and round when the key fits 16 bits, else the two-granule form
+  const bool pack = n <= 65536 && m <= 65536 && L >= 6 && L <= 16;
   // the granule slots live at the front of the caller's temp scratch (b*n floats >= b*128), the Morton order of the
   // blocked form behind them (b * n 16-bit numbers: b * 1024 + 2 b n <= 4 b n bytes from n = 512)
   SIG3D_HIP_TRY(hipMemsetAsync(temp, 0, sizeof(u64) * (size_t)b * FPS_SLOT_U64, stream));
@@ -780,14 +779,14 @@ __global__ __launch_bounds__(1024) void fps_blocks_sort_kernel(int n, int n_pad,
   for (int k = n + tid; k < n_pad; k += 1024) rows[k] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, FPSB_NOKEY));
 }
 
-template <int NW, int MB, int PPL>
+template <int NW, int MB, int PPL, int U>
 __global__ __launch_bounds__(NW * 64) void fps_blocks_kernel(int n, int n_pad, int m, int L,
                                                              const float *__restrict__ dataset_all,
                                                              const float4 *__restrict__ rows_all,
                                                              float *__restrict__ dist_all,
                                                              int *__restrict__ idxs_all) {
   constexpr int BP = 64 * PPL;
-  static_assert(NW == 4 || NW == 8 || NW == 16, "the candidates of all waves are reduced inside a 16-lane row");
+  static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "the candidates of all waves are reduced inside a 16-lane row");
   __shared__ int s_part[2][NW][8];   // a wave's candidate: value bits, key, x, y, z
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -897,18 +896,21 @@ __global__ __launch_bounds__(NW * 64) void fps_blocks_kernel(int n, int n_pad, i
       unsigned long long todo = __builtin_amdgcn_ballot_w64(!sit_out && s * 64 + lane < mine);
       swept |= todo != 0;
 
+      // up to UU blocks per trip, all their loads in flight together (a trip is one round trip to L2; a short list is
+      // padded with its last block: sweeping twice is idempotent)
       auto sweep = [&](auto ucount) {
-        constexpr int U = decltype(ucount)::value;
-        int bi[U];
+        constexpr int UU = decltype(ucount)::value;
+        int bi[UU], cnt = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          bi[u] = (int)__builtin_ctzll(todo);
-          todo &= todo - 1;
+        for (int u = 0; u < UU; ++u) {
+          const bool have = todo != 0;
+          bi[u] = have ? (int)__builtin_ctzll(todo) : bi[u > 0 ? u - 1 : 0];
+          if (have) { todo &= todo - 1; ++cnt; }
         }
-        float4 p[U][PPL];
-        float t[U][PPL];
+        float4 p[UU][PPL];
+        float t[UU][PPL];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UU; ++u) {
           const size_t base = (size_t)((s * 64 + bi[u]) * NW + wave) * BP;
 #pragma unroll
           for (int q = 0; q < PPL; ++q) {
@@ -917,54 +919,62 @@ __global__ __launch_bounds__(NW * 64) void fps_blocks_kernel(int n, int n_pad, i
           }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const size_t base = (size_t)((s * 64 + bi[u]) * NW + wave) * BP;
+        for (int u = 0; u < UU; ++u) {
+          if (u < cnt) {
+            const size_t base = (size_t)((s * 64 + bi[u]) * NW + wave) * BP;
 #pragma unroll
-          for (int q = 0; q < PPL; ++q) {
-            const float d = sq_dist3(p[u][q].x, p[u][q].y, p[u][q].z, x1, y1, z1);
-            const float tn = fminf(d, t[u][q]);
-            if (tn != t[u][q]) dist[base + q * 64 + lane] = tn;
-            t[u][q] = tn;
+            for (int q = 0; q < PPL; ++q) {
+              const float d = sq_dist3(p[u][q].x, p[u][q].y, p[u][q].z, x1, y1, z1);
+              const float tn = fminf(d, t[u][q]);
+              if (tn != t[u][q]) dist[base + q * 64 + lane] = tn;
+              t[u][q] = tn;
+            }
+            const Cand c = reduce_block(p[u], t[u]);
+            if (lane == bi[u]) { bval[s] = c.v; bkey[s] = c.k; cx[s] = c.x; cy[s] = c.y; cz[s] = c.z; }
           }
-          const Cand c = reduce_block(p[u], t[u]);
-          if (lane == bi[u]) { bval[s] = c.v; bkey[s] = c.k; cx[s] = c.x; cy[s] = c.y; cz[s] = c.z; }
         }
       };
-      while (__builtin_popcountll(todo) >= 4) sweep(std::integral_constant<int, 4>{});
-      if (__builtin_popcountll(todo) >= 2) sweep(std::integral_constant<int, 2>{});
-      while (todo) sweep(std::integral_constant<int, 1>{});
+      while (__builtin_popcountll(todo) > 2) sweep(std::integral_constant<int, U>{});
+      if (todo) sweep(std::integral_constant<int, 2>{});
     }
     if (swept) refresh_candidate();
 
-    const int par = j & 1;
-    if (lane == 0) {
-      s_part[par][wave][0] = pub_v;
-      s_part[par][wave][1] = (int)pub_k;
-      s_part[par][wave][2] = __builtin_bit_cast(int, pub_x);
-      s_part[par][wave][3] = __builtin_bit_cast(int, pub_y);
-      s_part[par][wave][4] = __builtin_bit_cast(int, pub_z);
-    }
-    // the barrier orders the LDS candidates only: running distances are private to their wave, and their stores
-    // may still be in flight behind it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    int gvu;
+    unsigned gku;
+    if (NW == 1) {
+      gvu = pub_v; gku = pub_k;
+      x1 = pub_x; y1 = pub_y; z1 = pub_z;
+    } else {
+      const int par = j & 1;
+      if (lane == 0) {
+        s_part[par][wave][0] = pub_v;
+        s_part[par][wave][1] = (int)pub_k;
+        s_part[par][wave][2] = __builtin_bit_cast(int, pub_x);
+        s_part[par][wave][3] = __builtin_bit_cast(int, pub_y);
+        s_part[par][wave][4] = __builtin_bit_cast(int, pub_z);
+      }
+      // the barrier orders the LDS candidates only: running distances are private to their wave, and their stores
+      // may still be in flight behind it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 
-    const int *sp = s_part[par][lane & (NW - 1)];
-    const int ov = sp[0];
-    const unsigned ok = (unsigned)sp[1];
-    const float ox = __builtin_bit_cast(float, sp[2]), oy = __builtin_bit_cast(float, sp[3]), oz = __builtin_bit_cast(float, sp[4]);
-    const int gv = row_allreduce_max_i32(ov);
-    const unsigned gk = row_allreduce_min_u32(ov == gv ? ok : FPSB_NOKEY);
-    const int gvu = __builtin_amdgcn_readfirstlane(gv);
-    const unsigned gku = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
+      const int *sp = s_part[par][lane & (NW - 1)];
+      const int ov = sp[0];
+      const unsigned ok = (unsigned)sp[1];
+      const float ox = __builtin_bit_cast(float, sp[2]), oy = __builtin_bit_cast(float, sp[3]), oz = __builtin_bit_cast(float, sp[4]);
+      const int gv = row_allreduce_max_i32(ov);
+      const unsigned gk = row_allreduce_min_u32(ov == gv ? ok : FPSB_NOKEY);
+      gvu = __builtin_amdgcn_readfirstlane(gv);
+      gku = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);
+      const int gl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(ov == gvu && ok == gku) | (1ull << 63));
+      x1 = readlane_f32(ox, gl); y1 = readlane_f32(oy, gl); z1 = readlane_f32(oz, gl);
+    }
     if (gvu < 0) {
       // nothing takes part (every point within the skip rule): the reference returns index 0 for every round
       for (int jj = j + tid; jj < m; jj += NW * 64) idxs[jj] = 0;
       return;
     }
-    const int gl = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(ov == gvu && ok == gku) | (1ull << 63));
-    x1 = readlane_f32(ox, gl); y1 = readlane_f32(oy, gl); z1 = readlane_f32(oz, gl);
     if (tid == 0) idxs[j] = (int)fps_unkey(gku, L);
   }
 }
@@ -1060,32 +1070,12 @@ extern "C" int sig3d_furthest_point_sampling(int b, int n, int m, const float *d
       if (n <= 16384) rc = launch_fps_coop<512, 4, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 24576) rc = launch_fps_coop<512, 6, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 40960) {
-        // 8 x 256 threads x 20 points since round 3: alone 1.71 us/round against 1.76 for 8 x 512 x 10, and half the
-        // waves beside the training step (-0.06 ms per step, tools/ab_step.py); 16 x 256 x 10: 2.29 us/round alone and
-        // +1.4 ms per step, 32 x 128 x 10: 3.03 (more peers per hop); 4 x 256 x 40 and 8 x 128 x 40 (234 VGPRs): 2.18 / 2.15
-        // us/round and +0.23 / +0.44 ms per step (the chain becomes the critical path).  SIG3D_FPS_SHAPE = 0 / 1 / 2
-        // selects the first three.  Round 5, three chains in flight (the chain has two steps of slack, so only what the
-        // kernel costs the step beside it counts: 0.31 of the chain's 0.40 ms): 16 x 256 x 10 +0.14 ms, 32 x 128 x 10
-        // +2.3, 16 x 128 x 20 (shape 4) +0.34, 32 x 64 x 20 (5) +2.1, 4 x 512 x 20 (6) +0.16, 2 x 1024 x 20 (7) +0.51:
-        // neither thinner over more CUs nor fatter on fewer beats 8 x 256 x 20 (tools/ab_step.py env:SIG3D_FPS_SHAPE).
-        // Late round 5, the blocked form (fps_coop_kernel BLOCKED: waves own a compact block of the scene and sit out the
-        // rounds that cannot change it): alone 1.72 us/round as before (the exchange bounds a round), beside the step
-        // -0.062 +- 0.008 ms (tools/ab_step.py env:SIG3D_FPS_SHAPE 8 3 --builds 4).  Blocked 8 x 512 x 10 (shape 9, blocks
-        // of half the size) level with it (+0.018 +- 0.025), 16 x 256 x 10 (10) +0.57, 4 x 512 x 20 (11) +0.12.
-        const char *shape = getenv("SIG3D_FPS_SHAPE");
-        const int sh = shape ? atoi(shape) : 3;
-        if (sh == 1) rc = launch_fps_coop<256, 10, 16>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 2) rc = launch_fps_coop<128, 10, 32>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 0) rc = launch_fps_coop<512, 10, 8>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 4) rc = launch_fps_coop<128, 20, 16>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 5) rc = launch_fps_coop<64, 20, 32>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 6) rc = launch_fps_coop<512, 20, 4>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 7) rc = launch_fps_coop<1024, 20, 2>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 8) rc = launch_fps_coop<256, 20, 8>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 9) rc = launch_fps_coop<512, 10, 8, true>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 10) rc = launch_fps_coop<256, 10, 16, true>(bc, n, m, L, ds, tp, ix, stream);
-        else if (sh == 11) rc = launch_fps_coop<512, 20, 4, true>(bc, n, m, L, ds, tp, ix, stream);
-        else rc = launch_fps_coop<256, 20, 8, true>(bc, n, m, L, ds, tp, ix, stream);   // blocks that sit rounds out
+        // 8 x 256 threads x 20 points, waves that own a compact block of the scene's Morton order and sit out the rounds
+        // that cannot change it (fps_coop_kernel BLOCKED).  What was measured on the way (DESIGN.md sections 4e / 4i):
+        // 8 x 512 x 10 unblocked 1.76 us / round alone (this: 1.71), 16 x 256 x 10 2.29, 32 x 128 x 10 3.03 (more peers
+        // per hop), 4 x 256 x 40 / 8 x 128 x 40 2.18 / 2.15; beside the training step every thinner or fatter shape cost
+        // +0.12 ... +2.3 ms, the blocked form -0.062 +- 0.008.  Those instances left the library in round 6.
+        rc = launch_fps_coop<256, 20, 8, true>(bc, n, m, L, ds, tp, ix, stream);
       }
       else if (n <= 65536) rc = launch_fps_coop<512, 16, 8>(bc, n, m, L, ds, tp, ix, stream);
       else if (n <= 98304) rc = launch_fps_coop<512, 24, 8>(bc, n, m, L, ds, tp, ix, stream);
@@ -1124,31 +1114,32 @@ extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const f
   float *dist = (float *)(rows + (size_t)b * n_pad);
   hipLaunchKernelGGL(fps_blocks_sort_kernel, dim3(b), dim3(1024), 0, stream, n, (int)n_pad, L, dataset, rows);
   SIG3D_LAUNCH_CHECK("fps_blocks_sort_kernel");
-  // waves per scene x managed blocks per lane (SIG3D_FPS_BLOCKS_SHAPE: 0 = 16 x 1, 1 = 8 x 2, 2 = 4 x 4): what the
-  // workgroup holds of its CU is what the training step's kernels cannot use there
+  // waves per scene x managed blocks per lane x points per lane and block x blocks per trip (SIG3D_FPS_BLOCKS_SHAPE):
+  // what the workgroup holds of its CU is what the training step's kernels cannot use there
   const char *shape = getenv("SIG3D_FPS_BLOCKS_SHAPE");
   const int sh = shape ? atoi(shape) : 0;
-#define SIG3D_FPSB(NWV, MBV, PPLV)                                                                                  \
+#define SIG3D_FPSB(NWV, MBV, PPLV, UV)                                                                              \
   do {                                                                                                              \
     SIG3D_REQUIRE(nblocks <= 64L * NWV * MBV, "block-list FPS: more blocks than managing lanes");                    \
-    hipLaunchKernelGGL((fps_blocks_kernel<NWV, MBV, PPLV>), dim3(b), dim3(NWV * 64), 0, stream, n, (int)n_pad, m, L,  \
-                       dataset, rows, dist, idxs);                                                                  \
+    hipLaunchKernelGGL((fps_blocks_kernel<NWV, MBV, PPLV, UV>), dim3(b), dim3(NWV * 64), 0, stream, n, (int)n_pad,   \
+                       m, L, dataset, rows, dist, idxs);                                                            \
   } while (0)
-  if (ppl == 1 && sh == 1) SIG3D_FPSB(8, 2, 1);
-  else if (ppl == 1 && sh == 2) SIG3D_FPSB(4, 4, 1);
-  else if (ppl == 1) SIG3D_FPSB(16, 1, 1);
-  else if (ppl == 2) SIG3D_FPSB(16, 1, 2);
-  else SIG3D_FPSB(16, 1, 3);
+  if (ppl == 1 && sh == 1) SIG3D_FPSB(8, 2, 1, 4);
+  else if (ppl == 1 && sh == 2) SIG3D_FPSB(16, 1, 1, 4);
+  else if (ppl == 1 && sh == 3 && nblocks <= 640) SIG3D_FPSB(2, 5, 1, 8);
+  else if (ppl == 1 && sh == 5 && nblocks <= 768) SIG3D_FPSB(4, 3, 1, 4);
+  else if (ppl == 1) SIG3D_FPSB(4, 4, 1, 4);
+  else if (ppl == 2) SIG3D_FPSB(16, 1, 2, 4);
+  else SIG3D_FPSB(16, 1, 3, 4);
 #undef SIG3D_FPSB
   SIG3D_LAUNCH_CHECK("fps_blocks_kernel");
   return 0;
 }
 
-// the segmented check from 256 rounds (8 threads per point); below, the plain one (SIG3D_FPS_CHECK_SEG=0: always)
+// the segmented check from 256 rounds (8 threads per point); below, the plain one
 static void launch_prefix_check(const FpsChain &ch, int b, const float *dataset, const float *r, int *flags,
                                 hipStream_t stream) {
-  const char *e = getenv("SIG3D_FPS_CHECK_SEG");
-  const bool seg = ch.m[0] >= 256 && ch.m[0] <= 4000 && !(e && atoi(e) == 0);   // <= 64 KB of LDS
+  const bool seg = ch.m[0] >= 256 && ch.m[0] <= 4000;   // <= 64 KB of LDS
   if (seg) {
     constexpr int S = 8;
     hipLaunchKernelGGL(fps_prefix_check_seg_kernel<S>, dim3(sig3d_ceil_div(ch.n[0], 256 / S), b, ch.levels), dim3(256),

@@ -1454,13 +1454,6 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
   };
   // widest channel tile whose weights leave room for a second workgroup on the CU (x is then
   // re-read from L2 as rarely as possible)
-  static const int forced_nt = [] { const char *v = getenv("SIG3D_MLP_NT"); return v ? atoi(v) : 0; }();
-  if (forced_nt == 4 && fits(128, 160 * 1024))
-    return dispatch_mlp_fwd<4>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
-  if (forced_nt == 2 && fits(64, 160 * 1024))
-    return dispatch_mlp_fwd<2>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
-  if (forced_nt == 1)
-    return dispatch_mlp_fwd<1>(pscale != nullptr, vec, b, cin, cout, e, x, w, pscale, pshift, y, stat_sum, stat_sq, stream);
   // compact lists: a sample has a few hundred live tiles, i.e. one or two per wave -- the launch then takes as long as
   // ONE wave needs for a tile, and a 64-channel tile halves that (measured at the step's shapes, 11 % and 36 % / 4 % and
   // 16 % live: 39 / 19 / 24 us against 46 / 31 / 32 with 128-channel tiles; 100 / 29 / 48 against 98 / 36 / 56)
@@ -1737,8 +1730,7 @@ extern "C" int sig3d_mlp_layer_dw_dx(int b, int cin, int cout, long e, const flo
   const int kpad = ml_kpad(cin_k), ldw = kpad | 1;
   const size_t lds_mlp = sizeof(float) * ((size_t)64 * ldw + 2 * kpad + ML_WAVES * 2 * 64 + ML_WAVES * 16 * ML_TRLD);
   const bool ragged = (cin_k % (2 * ML_KC) != 0 && kpad - cin_k >= 2) || (cout_k % 64 != 0 && cout_k % 64 <= 32);
-  static const bool off = [] { const char *v = getenv("SIG3D_DW_DX_ONE_LAUNCH"); return v && atoi(v) == 0; }();
-  if (off || !usable || ragged || cout_k <= 32 || lds_mlp > 80 * 1024 || e % 4 != 0 || getenv("SIG3D_MLP_NT") ||
+  if (!usable || ragged || cout_k <= 32 || lds_mlp > 80 * 1024 || e % 4 != 0 ||
       (long)cin_k * e >= (1L << 31) || (long)cout_k * e >= (1L << 31)) {
     if (int rc = sig3d_mlp_layer_dw_stream_nofold(b, cin, cout, e, dY, x, pscale, pshift, n_act, dW, work, stream_)) return rc;
     return sig3d_mlp_layer_dx(b, cin, cout, e, dY, w, dA, n_act, stream_);

@@ -23,8 +23,7 @@ from .pointnet2 import _ext, fused_mlp
 
 # SIG3D_NESTED_FPS=0 runs the dependent rounds on every level (A/B timing; results are identical)
 NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
-# SIG3D_FPS_CHAIN=0: the nested levels prove their prefix one after the other (round 2) instead of in one launch pair
-NESTED_CHAIN = os.environ.get("SIG3D_FPS_CHAIN", "1") != "0"
+NESTED_CHAIN = True   # the nested levels prove their prefix in one launch pair (False: one after the other, round 2)
 
 
 class Announced:
@@ -46,11 +45,6 @@ class Announced:
         if token is not None or self.token is not None:
             return token is not None and token == self.token
         return tensor is self.tensor and tensor._version == self.version
-
-
-# SIG3D_BQ_TABLE=1: the table of a scene's centres is built once by a pre-pass and copied by the scene's scatter workgroups
-# (csrc/ball_query.hip: SIG3D_BQ_SHARED_TABLE) instead of being sorted by each of them; measured, not the default
-BQ_TABLE_FLAG = _lib.BQ_SHARED_TABLE if os.environ.get("SIG3D_BQ_TABLE", "0") == "1" else 0
 
 
 class GeometryPlan:
@@ -136,7 +130,7 @@ class GeometryPlan:
                 self._bq_clean = False   # a new workspace / problem list: the next call zeroes the counters itself
             # after one completed call the workspace's counters are zero again (the rank kernel cleans up): no memset
             _lib.call("sig3d_ball_query_levels_ex", b, len(self._bq_levels), self._bq_levels, _lib.ptr(self._bq_work),
-                      self._bq_work.numel(), (_lib.BQ_CLEAN if self._bq_clean else 0) | BQ_TABLE_FLAG, s)
+                      self._bq_work.numel(), _lib.BQ_CLEAN if self._bq_clean else 0, s)
             # the flag describes the workspace as the DEVICE will find it at the next call: only a call that was
             # really issued (not one recorded into a graph that may never be replayed) leaves the counters zero
             self._bq_clean = not torch.cuda.is_current_stream_capturing()

@@ -8,15 +8,14 @@ head layout) takes the torch path of the very same modules.
 """
 import ctypes
 import itertools
-import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib, scratch
 
-# SIG3D_FUSED_HEADS=0: the torch modules (A/B timing; same results up to f32 summation order and the dropout stream)
-ENABLED = os.environ.get("SIG3D_FUSED_HEADS", "1") != "0"
+# False: the torch modules (tests compare the two forms; same results up to f32 summation order and the dropout stream)
+ENABLED = True
 _call_ids = itertools.count(0x5EAD0000)
 
 

@@ -39,8 +39,8 @@ _REC = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8")
 
 
 # workgroups that walk the chunk table of one update launch when the optimizer is not given max_workgroups
-# (0: one workgroup per 64 Ki-element chunk); SIG3D_ADAMW_WORKGROUPS
-DEFAULT_MAX_WORKGROUPS = int(os.environ.get("SIG3D_ADAMW_WORKGROUPS", "0"))
+# (0: one workgroup per 64 Ki-element chunk)
+DEFAULT_MAX_WORKGROUPS = 0
 
 
 def flat_offsets(params):

@@ -94,23 +94,21 @@ def compact_lists(idx):
     return CompactLists(idx.shape[0], idx.shape[1], idx.shape[2], idx.device).compute(idx.contiguous())
 
 
-# SIG3D_DW_STREAM=0: the layers' weight gradients through mlp_dw_kernel (one 64-byte run per lane and row, f32 atomics)
-# instead of the k-streaming split product of sig3d_mlp_layer_dw_stream
-DW_STREAM = int(os.environ.get("SIG3D_DW_STREAM", "1"))      # 3: every level, whatever its size
-# SIG3D_DW_FOLD_ONCE=0: every streaming weight gradient folds its own slabs (a launch per layer: 11 per step) instead of one
-# fold per SharedMLP stack (sig3d_sum_slabs_multi: 4 per step)
-DW_FOLD_ONCE = os.environ.get("SIG3D_DW_FOLD_ONCE", "1") != "0"
-# SIG3D_DW_DX_ONE=0: a compact level's layer launches its weight gradient and its input gradient separately
-DW_DX_ONE = os.environ.get("SIG3D_DW_DX_ONE", "1") != "0"
-# SIG3D_DW_REGROUP=0: the gathered first layer of a compact level keeps its gathering weight-gradient kernel
-DW_REGROUP = os.environ.get("SIG3D_DW_REGROUP", "1") != "0"
+# Module constants below are not environment switches: each alternative lost its A/B (DESIGN.md sections 4f-4i) and stays
+# only where a test compares the two forms (monkeypatched there).
+# the layers' weight gradients: 1 = the k-streaming split product (sig3d_mlp_layer_dw_stream) on compact levels and
+# dense rows up to DW_STREAM_MAX_E positions, 0 = mlp_dw_kernel everywhere, 3 = streaming on every level
+DW_STREAM = 1
+DW_FOLD_ONCE = True      # one slab fold per SharedMLP stack (sig3d_sum_slabs_multi) instead of one per layer
+DW_DX_ONE = True         # a compact level's layer: weight gradient + input gradient as two workgroup ranges of ONE launch
+DW_REGROUP = True        # the gathered first layer of a compact level re-materialises its operand for the streaming dW
 # dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
 # variant of the bench is 0.15 ms slower with the streaming product there)
-DW_STREAM_MAX_E = int(os.environ.get("SIG3D_DW_STREAM_MAX_E", "16384"))
+DW_STREAM_MAX_E = 16384
 # SIG3D_COMPACT=0 keeps every set-abstraction level dense
 COMPACT = os.environ.get("SIG3D_COMPACT", "1") != "0"
 # levels with at least this many (dense) positions run compact; the others keep the library-GEMM hybrid
-COMPACT_MIN_POSITIONS = int(os.environ.get("SIG3D_COMPACT_MIN_POSITIONS", str(MIN_POSITIONS)))
+COMPACT_MIN_POSITIONS = MIN_POSITIONS
 
 
 class _QueryGroupCompact(torch.autograd.Function):
@@ -610,8 +608,7 @@ def fused_mlp_max(mlp, x, library_gemm=None, want_pm=False):
     return _with_pm(*_FusedMLPMax.apply(x, layers, bool(library_gemm), None, None, bool(want_pm), False, None, *flat))
 
 
-# SIG3D_GATHER_L0=0: always store the grouped tensor (A/B timing; same results up to f32 summation order)
-GATHER_L0 = os.environ.get("SIG3D_GATHER_L0", "1") != "0"
+GATHER_L0 = True     # False: always store the grouped tensor (tests compare the two forms)
 
 
 def gather_applies(features, use_xyz):
@@ -621,7 +618,7 @@ def gather_applies(features, use_xyz):
             and features.shape[1] % 32 == 0 and features.is_cuda and features.dtype == torch.float32)
 
 
-FIRST_L0 = os.environ.get("SIG3D_FIRST_L0", "1") != "0"   # 0: SA1 keeps the stored grouped tensor (A/B timing)
+FIRST_L0 = True      # False: SA1 keeps the stored grouped tensor (tests compare the two forms)
 
 
 def attach_scan(features, point_clouds):
@@ -634,7 +631,7 @@ def attach_scan(features, point_clouds):
 
 # dense (full) lists: the stored grouped tensor + MFMA layer is faster (13 + 76 us against 114 us at SA1, B = 8:
 # the scan kernel writes its 64 output rows as 64 separate 256-byte stores per wave); 1 forces the scan path anyway
-FIRST_L0_DENSE = os.environ.get("SIG3D_FIRST_L0_DENSE", "0") != "0"
+FIRST_L0_DENSE = False
 
 
 def first_layer_scan(mlp, xyz, features, use_xyz, dense=False):

@@ -8,7 +8,6 @@ new_xyz needs a gradient; the result is bit-identical to the unfused composition
 for the differentiable-xyz case.
 """
 import ctypes
-import os
 
 import torch
 import torch.nn as nn
@@ -141,7 +140,7 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
-POINT_MAJOR_MIN_CHANNELS = int(os.environ.get("SIG3D_GROUP_PM_MIN_C", "32"))
+POINT_MAJOR_MIN_CHANNELS = 32
 
 
 class _QueryGroupFused(Function):

@@ -119,23 +119,19 @@ def advance_dropout_seed(device):
 
 
 # SIG3D_QF_GEMM=1: the Q-Former's dense products on sig3d_gemm16 (csrc/gemm16_core.h: exact-f32 MFMA, bias / GELU / gelu' /
-# residual-gradient epilogues, split reductions whose slabs the LayerNorm tails add while loading), product by product
-# (SIG3D_QF_GEMM_MASK, all by default):
-#   1 query/key/value, 2 attention output, 4 feed-forward up (+ GELU), 8 feed-forward down, 16 d(feed-forward up) (* gelu'),
-#   32 d(feed-forward down) + residual, 64 d(projections) + residual.
+# residual-gradient epilogues, split reductions whose slabs the LayerNorm tails add while loading): query/key/value,
+# attention output, feed-forward up (+ GELU) and down, and the three input-gradient products.
 # Correct at every golden and full-size parity test and level with rocBLAS's default picks kernel by kernel
-# (tools/micro/gemm16_bench.hip) -- but INSIDE the training step the tuned library is not beaten: all products +0.13 ms
-# (round 4: 7.85-7.98 against 8.18-8.28 ms), and no single product pays either (round 5, tools/ab_step.py with four step
-# objects per arm: product 64 alone +0.010 +- 0.009 ms; a first pass with ONE object per arm had shown -0.090 for it and
-# -0.03 ... +0.01 for the others -- the spread of two identical arms, as a null switch showed).  Default: the vendor
-# library (rocBLAS / hipBLASLt through torch); this switch is the A/B.
+# (tools/micro/gemm16_bench.hip) -- but INSIDE the training step the tuned library is not beaten: all products +0.30 ms
+# (round 5, four step objects per arm), and no single product pays either (product by product: -0.007 ... +0.119 ms,
+# DESIGN.md section 4i).  Default: the vendor library (rocBLAS / hipBLASLt through torch); this switch is the A/B.
 OWN_GEMM = os.environ.get("SIG3D_QF_GEMM", "0") != "0"
-OWN_MASK = int(os.environ.get("SIG3D_QF_GEMM_MASK", "127"))
+OWN_MASK = 127      # every product (tests pick single ones; the per-product environment switch went with its measurements)
 OWN_CONFIG = 0      # sig3d_gemm16's own choice among its f32 tilings
 
 
-# the flush's column sums (bias gradients, LayerNorm-tail folds) as one launch (sig3d_column_sum_multi) or one per kind
-COLSUM_MULTI = os.environ.get("SIG3D_QF_COLSUM_MULTI", "1") != "0"
+# the flush's column sums (bias gradients, LayerNorm-tail folds) as one launch (sig3d_column_sum_multi); False: one per kind
+COLSUM_MULTI = True
 
 
 # Cross-attention over MANY encoder tokens (the 3D-LLM shape: B x 5000 ... 80 000 point tokens of width 1408,
@@ -733,7 +729,6 @@ class _WeightGradArena:
         self._marks = set()
         self._expected = 2 * NL + nc
         self._flushed_hi = NL           # layers >= this are flushed
-        self.side_stream, self._forked = None, False
         # Input-gradient products whose reduction is split hand their slabs from one block's backward to the next
         # block's LayerNorm-tail backward, which adds them while loading (sig3d_dropout_add_ln_bwd_slabs).  The
         # tensor autograd carries is slab 0; the others wait here under its address.  Only between blocks of THIS
@@ -861,11 +856,8 @@ class _WeightGradArena:
     def flush(self):
         """Weight / bias gradients of every layer whose blocks have all run their backward and that is not
         flushed yet (a contiguous range below the last flush), batched over that range.
-        The products are MFMA-bound and nothing before the optimizer needs them, while what the backward pass
-        still has to do after the Q-Former -- the point encoder's BatchNorm / gather / scatter kernels -- is
-        HBM-bound: with `side_stream` set they are issued on that stream (forked from the current one), and
-        join() makes the current stream wait for them (trainer.train_step / graph_step call it before the
-        gradients are consumed).  Inside a hipGraph capture this is a forked branch of the graph."""
+        (Issuing them on a side stream beside the point encoder's backward pass was measured slower -- 9.27 against
+        8.99 ms per step: the batched GEMMs fill every CU -- and was removed in round 6.)"""
         hi = self._flushed_hi
         lo = hi
         while lo > 0 and self._layer_done(lo - 1):
@@ -877,14 +869,7 @@ class _WeightGradArena:
             self._products_shared(lo, hi)
             return
         self._check_adopted(lo, hi)
-        side = self.side_stream
-        if side is None:
-            self._products_cut(lo, hi)
-            return
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._products_cut(lo, hi)
-        self._forked = True
+        self._products_cut(lo, hi)
 
     def _products_cut(self, lo, hi):
         """The products of layers [lo, hi), one batch per storage arena (upper arena first, like the backward pass)."""
@@ -892,11 +877,6 @@ class _WeightGradArena:
             a, b = max(a, lo), min(b, hi)
             if a < b:
                 self._products(a, b)
-
-    def join(self):
-        if self._forked:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-            self._forked = False
 
     @torch.no_grad()
     def _products(self, lo, hi):
@@ -1269,7 +1249,7 @@ def _key_mask(mask, batch, nk):
     return mask.expand(batch, nk).to(torch.float32)
 
 
-FUSED_EMBED = os.environ.get("SIG3D_FUSED_EMBED", "1") != "0"   # 0: BertEmbeddings / masks through torch ops
+FUSED_EMBED = True   # False: BertEmbeddings / masks through torch ops (tests compare the two forms)
 
 
 class _EmbeddingsFn(torch.autograd.Function):
@@ -1683,10 +1663,7 @@ class BertEncoder(nn.Module):
         # at forward time (autograd must adopt, not accumulate into, the views it is handed), no per-parameter
         # gradient hooks that would fire before flush().  trainer.train_step / graph_step switch it per mode.
         self.defer_weight_grads = os.environ.get("SIG3D_QF_DEFER", "1") != "0"
-        # opt-in: measured SLOWER on MI355X (9.27 vs 8.99 ms per step): the batched GEMMs fill every CU, the point
-        # encoder's backward kernels beside them (and the FPS branch) only get in each other's way
-        self.flush_on_side_stream = os.environ.get("SIG3D_QF_FLUSH_STREAM", "0") != "0"
-        self._arena_ref, self._side = None, None
+        self._arena_ref = None
 
     # The arena of the last grad-enabled forward, held WEAKLY: the autograd graph (every block's ctx) owns it, so an
     # abandoned forward's arena dies with its outputs and never counts as pending.
@@ -1724,11 +1701,6 @@ class BertEncoder(nn.Module):
                                  storage_cut=getattr(self, "storage_cut", None))
         if cut is not None:
             arena.slabs_ok = False   # the gradient crosses the cut through a leaf's .grad, not from block to block
-        if self.flush_on_side_stream:
-            dev = hidden_states.device
-            if self._side is None or self._side.device != dev:
-                self._side = torch.cuda.Stream(dev)
-            arena.side_stream = self._side
         return arena
 
     def flush_weight_grads(self):
@@ -1738,7 +1710,6 @@ class BertEncoder(nn.Module):
         arena = self._arena
         if arena is not None:
             arena.flush()
-            arena.join()
             if arena._flushed_hi == 0:
                 self._arena = None   # every gradient is in place (the views keep their storage alive)
 

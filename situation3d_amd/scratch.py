@@ -19,13 +19,12 @@ streams (geometry.GeometryPipeline) and keep their own buffers.  The region reme
 request made with another stream current gets a plain `torch.zeros` (not the thread: autograd runs the backward pass
 of the same step on its own thread, with the forward's stream current).
 """
-import os
 
 import torch
 
 _ALIGN = 256
-# SIG3D_STEP_ZEROS=0: every request is its own torch.zeros again (A/B measurements)
-ENABLED = os.environ.get("SIG3D_STEP_ZEROS", "1") != "0"
+# False: every request is its own torch.zeros again (tests compare the two forms)
+ENABLED = True
 
 
 class StepZeros:

@@ -5,15 +5,14 @@
 forward launch and two backward launches instead of torch's 4 + ~12.  The module's own parameters are used (same
 state_dict); anything the kernels do not cover (CPU tensors, other shapes, a tanh GELU) takes the torch path.
 """
-import os
 
 import torch
 import torch.nn as nn
 
 from . import _lib, scratch
 
-# SIG3D_SMALL_MLP=0: the torch modules (A/B timing; same results up to f32 summation order)
-ENABLED = os.environ.get("SIG3D_SMALL_MLP", "1") != "0"
+# False: the torch modules (tests compare the two forms; same results up to f32 summation order)
+ENABLED = True
 
 
 class _PosMLPFn(torch.autograd.Function):

@@ -274,8 +274,7 @@ def test_gemmp_work_space_and_argument_checks_are_host_arithmetic():
 
 def test_ball_query_levels_workspace_is_host_arithmetic():
     """sig3d_ball_query_levels_workspace_bytes plans a multi-level launch on the host (no GPU call): scenes of at most
-    4096 points take the in-LDS ordered scan and need no scratch; larger ones a counter + 256 list slots per centre
-    (+ room for the optional shared tables of SIG3D_BQ_SHARED_TABLE: per scene 4 bytes per hash bucket + 16 per centre);
+    4096 points take the in-LDS ordered scan and need no scratch; larger ones a counter + 256 list slots per centre;
     more than 16 blocks of 4096 centres do not fit one launch (-1)."""
     from situation3d_amd import _lib
     lib = _lib.load()
@@ -287,10 +286,10 @@ def test_ball_query_levels_workspace_is_host_arithmetic():
         return arr
 
     stack = levels([(40000, 2048, 64, 0.2), (2048, 1024, 32, 0.4), (1024, 512, 16, 0.8), (512, 256, 16, 1.2)])
-    assert lib.sig3d_ball_query_levels_workspace_bytes(8, 4, stack) == 8 * 2048 * 4 * 257 + 8 * (4096 * 4 + 2048 * 16)   # SA1 only
+    assert lib.sig3d_ball_query_levels_workspace_bytes(8, 4, stack) == 8 * 2048 * 4 * 257   # SA1 only
     assert lib.sig3d_ball_query_levels_workspace_bytes(8, 3, levels([(2048, 1024, 32, 0.4)] * 3)) == 0
     assert lib.sig3d_ball_query_levels_workspace_bytes(2, 1, levels([(50000, 5000, 8, 0.3)])) == \
-        2 * 5000 * 4 * 257 + 2 * ((8192 * 4 + 4096 * 16) + (2048 * 4 + 904 * 16))        # two blocks of centres
+        2 * 5000 * 4 * 257        # two blocks of centres
     assert lib.sig3d_ball_query_levels_workspace_bytes(1, 1, levels([(50000, 17 * 4096, 8, 0.3)])) == -1
     assert lib.sig3d_ball_query_levels_workspace_bytes(0, 1, stack) == 0
 

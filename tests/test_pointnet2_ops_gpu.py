@@ -28,12 +28,23 @@ def test_fps_sizes(hip_ext, oracle, n, m):
     _fps_case(hip_ext, oracle, 2, n, m, seed=n)
 
 
+@pytest.fixture(params=["blocks", "coop"])
+def fps_path(request, monkeypatch):
+    """Scenes above 8192 points: the block-list kernel behind sig3d_furthest_point_sampling_blocks (one workgroup per
+    scene over a Morton-ordered copy in L2; the default of pointnet2._ext) or the cooperative register-resident kernel
+    behind the reference's own argument list (sig3d_furthest_point_sampling)."""
+    from situation3d_amd.pointnet2 import _ext as amd_ext
+    monkeypatch.setattr(amd_ext, "FPS_BLOCKS", request.param == "blocks")
+    return request.param
+
+
 @pytest.mark.parametrize("b,n,m", [(3, 8193, 200), (9, 10000, 150), (2, 16384, 200), (2, 16385, 100), (2, 24576, 150),
                                    (1, 24577, 100), (2, 40960, 100), (1, 40961, 80), (2, 65536, 80), (1, 65537, 60),
-                                   (1, 98304, 60), (1, 98305, 50), (1, 150000, 40)])
-def test_fps_cooperative_instances(hip_ext, oracle, b, n, m):
-    """Every (points per thread) instance of the cooperative kernel at and just past its size limit,
-    batches that are not a multiple of the 8 scenes of one launch, ties and a zero tail included."""
+                                   (1, 98304, 60), (1, 98305, 50), (1, 131072, 40), (1, 131073, 40), (1, 150000, 40)])
+def test_fps_cooperative_instances(hip_ext, oracle, b, n, m, fps_path):
+    """Every instance of the cooperative kernel (points per thread) and of the block-list kernel (points per lane and
+    block) at and just past its size limit, batches that are not a multiple of the 8 scenes of one launch, ties and a
+    zero tail included."""
     _fps_case(hip_ext, oracle, b, n, m, seed=n + b, dup=n // 20, zero_tail=n // 50)
 
 
@@ -59,25 +70,29 @@ def test_fps_all_skipped_and_m_gt_n(hip_ext, oracle):
                        oracle.furthest_point_sampling(xyz, 60))
 
 
-@pytest.mark.parametrize("shape", ["0", "1", "2", "3", "3-two-granules", "8", "9", "10", "11"])
-def test_fps_workgroup_shapes_keep_the_reference_tie_order(hip_ext, oracle, shape, monkeypatch):
-    """SIG3D_FPS_SHAPE: 8 x 512 x 10, 16 x 256 x 10, 32 x 128 x 10 and 8 x 256 x 20 threads x points per scene at
-    24 577-40 960 points, where a thread's points share one slot of the reference's 512-thread block
-    (k = r + 512 (s G + grp)); 3 (the default) and 9-11: waves that own a compact block of the scene's Morton order and
-    sit rounds out, where a thread keeps its points sorted by tie key.  Exact ties (duplicated points, a grid) and the
-    zero tail resolve as in the reference whatever the shape; read at launch time."""
-    if shape.endswith("two-granules"):       # SIG3D_FPS_PACK=0: {round, value} + {round, key} instead of one packed granule
-        monkeypatch.setenv("SIG3D_FPS_PACK", "0")
-    monkeypatch.setenv("SIG3D_FPS_SHAPE", shape.split("-")[0])
+def test_fps_large_scenes_keep_the_reference_tie_order(hip_ext, oracle, fps_path):
+    """24 577-40 960 points: waves that own a compact block of the scene's Morton order and sit rounds out (the
+    cooperative kernel: a thread keeps its points sorted by tie key; the block-list kernel: the key travels with every
+    row).  Exact ties (duplicated points, a grid) and the zero tail resolve as in the reference."""
     _fps_case(hip_ext, oracle, 2, 40000, 600, seed=21, dup=4000, zero_tail=900)
     _fps_case(hip_ext, oracle, 1, 24577, 300, seed=22, dup=2000, zero_tail=100)
     g = torch.stack(torch.meshgrid(torch.arange(40.), torch.arange(40.), torch.arange(20.), indexing="ij"), -1)
     xyz = (g.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()          # 32 000 grid points: massive exact ties
     ref = oracle.furthest_point_sampling(xyz, 400)
     assert torch.equal(hip_ext.furthest_point_sampling(xyz.to(DEV), 400).cpu(), ref)
+    # every point inside the skip rule (index 0 for every round), and five points that take part among 9000 that do not
+    none = torch.zeros(2, 9000, 3)
+    assert torch.equal(hip_ext.furthest_point_sampling(none.to(DEV), 8).cpu(), oracle.furthest_point_sampling(none, 8))
+    few = torch.zeros(1, 9000, 3)
+    few[0, [7, 4000, 4001, 8999, 123]] = torch.tensor([[1.0, 2, 3], [4, 1, 0.5], [4, 1, 0.5], [0.1, 0.1, 0.1], [7, 7, 2]])
+    assert torch.equal(hip_ext.furthest_point_sampling(few.to(DEV), 20).cpu(), oracle.furthest_point_sampling(few, 20))
+    # NaN / infinite coordinates: never nearer than anything (min and the strict compare ignore them as the reference's do)
+    odd = scene(1, 12000, seed=31)
+    odd[0, 100] = float("nan"); odd[0, 5000, 1] = float("inf"); odd[0, 11999, 2] = float("-inf")
+    assert torch.equal(hip_ext.furthest_point_sampling(odd.to(DEV), 200).cpu(), oracle.furthest_point_sampling(odd, 200))
 
 
-def test_fps_blocked_degenerate_boxes(hip_ext, oracle):
+def test_fps_blocked_degenerate_boxes(hip_ext, oracle, fps_path):
     """The blocked kernel's Morton order and its sit-out test on boxes that break a grid: a flat scene (one extent 0),
     all points in one spot plus a far outlier, two tight clusters (most waves sit out from round 3), and a scene whose
     first rounds tie everywhere."""
@@ -97,7 +112,7 @@ def test_fps_blocked_degenerate_boxes(hip_ext, oracle):
         assert torch.equal(hip_ext.furthest_point_sampling(cloud.to(DEV), m).cpu(), ref)
 
 
-def test_fps_scene_40k(hip_ext, oracle):
+def test_fps_scene_40k(hip_ext, oracle, fps_path):
     # BASELINE shape (one scene, 40k points, SA1 npoint=2048) incl. the overflow-tail path
     _fps_case(hip_ext, oracle, 1, 40000, 2048, seed=11, dup=500, zero_tail=100)
 
@@ -369,6 +384,40 @@ def test_query_group_fused_point_major_is_bit_identical(b, n, m, ns, c, use_xyz,
     L.call("sig3d_query_group_fused_pm", b, n, m, c, c, ns, use_xyz, norm, ctypes.c_float(0.37), L.ptr(xyz),
            L.ptr(new_xyz), L.ptr(pm), L.ptr(idx), L.ptr(out), L.stream_ptr())
     assert not torch.isnan(ref).any() and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("b", [8, 2, 3, 1])
+def test_query_group_levels_in_one_launch_equals_the_level_by_level_launches(b):
+    """sig3d_query_group_levels: the grouping of a whole set-abstraction stack as one grid (largest level first, every
+    level's range starting at a multiple of 8 workgroups) against sig3d_query_group_fused / _pm level by level: every
+    bit, at batch sizes that take each branch of the XCD-local scene dealing; ragged tiles and a no-feature level."""
+    import ctypes
+    from situation3d_amd import _lib as L
+    g = torch.Generator().manual_seed(77 + b)
+    #        n     m    ns   c   point-major
+    shape = [(3000, 500, 16, 3, False), (500, 260, 32, 128, True), (260, 100, 12, 36, True), (100, 37, 8, 260, True)]
+    probs, refs, outs = [], [], []
+    for n, m, ns, c, pm in shape:
+        xyz = torch.rand(b, n, 3, generator=g).to(DEV)
+        new_xyz = xyz[:, :m].contiguous()
+        feat = torch.randn(b, c, n, generator=g).to(DEV)
+        idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(DEV)
+        ref = torch.full((b, 3 + c, m, ns), float("nan"), device=DEV)
+        L.call("sig3d_query_group_fused", b, n, m, c, ns, 1, 1, ctypes.c_float(0.4), L.ptr(xyz), L.ptr(new_xyz),
+               L.ptr(feat), L.ptr(idx), L.ptr(ref), L.stream_ptr())
+        out = torch.full((b, 3 + c, m, ns), float("nan"), device=DEV)
+        src = feat.transpose(1, 2).contiguous() if pm else feat
+        probs.append((xyz, new_xyz, 0.4, idx, src, pm, out))
+        refs.append(ref); outs.append(out)
+    arr = L.group_levels(probs)
+    L.call("sig3d_query_group_levels", b, len(arr), arr, L.stream_ptr())
+    for ref, out in zip(refs, outs):
+        assert not torch.isnan(ref).any() and torch.equal(out, ref)
+    sub = L.group_levels(probs[1:3])           # fewer levels, another order of sizes
+    for o in outs:
+        o.fill_(float("nan"))
+    L.call("sig3d_query_group_levels", b, len(sub), sub, L.stream_ptr())
+    assert torch.equal(outs[1], refs[1]) and torch.equal(outs[2], refs[2]) and torch.isnan(outs[0]).all()
 
 
 @pytest.mark.parametrize("b,n,m,ns,c,c_off", [(2, 2048, 1024, 32, 128, 3), (2, 1024, 512, 16, 256, 3),

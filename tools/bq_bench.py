@@ -64,8 +64,5 @@ for surface in (False, True):
     work = torch.empty(L.bq_levels_workspace_bytes(b, arr), dtype=torch.uint8, device=dev)
     tl = t(lambda: L.call("sig3d_ball_query_levels", b, len(arr), arr, L.ptr(work), work.numel(), L.stream_ptr()))
     got = [r[4].clone() for r in recs]
-    ts = t(lambda: L.call("sig3d_ball_query_levels_ex", b, len(arr), arr, L.ptr(work), work.numel(), L.BQ_SHARED_TABLE, L.stream_ptr()))
-    same = all(torch.equal(g, r[4]) for g, r in zip(got, recs))
-    print("  ... with the centres' table built once per scene (SIG3D_BQ_SHARED_TABLE: pre-pass + copy): %.1f us, equal=%s" % (ts, same))
     nb = sum(bench.ball_query_algorithmic_bytes(b, c.shape[1], a.shape[1], ns) for a, c, r, ns in probs)
     print("  SA1-4 in one launch pair: %.1f us for %.1f MB algorithmic = %.2f TB/s" % (tl, nb / 1e6, nb / tl / 1e6))
