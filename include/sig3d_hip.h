@@ -60,10 +60,13 @@ int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, flo
  * 16-byte aligned, contents irrelevant.  Scenes of 8193 .. 196 608 points then run as ONE workgroup per scene over
  * a Morton-ordered copy held in L2 -- only the blocks a new sample can reach are swept -- instead of eight
  * register-resident workgroups exchanging candidates through memory.  Same indices for any input
- * (sampling_gpu.cu:69-173: same distance arithmetic, skip rule and tie order). */
+ * (sampling_gpu.cu:69-173: same distance arithmetic, skip rule and tie order).
+ * waves (scenes of up to 65 536 points): waves of that workgroup -- 16: lowest latency (3.6 ms for 2047 rounds over
+ * 40 000 points, as the cooperative kernel), for a call nothing runs beside; 4 (= 0, the default): 6.1 ms, but a
+ * chain that runs BESIDE other kernels then takes nothing from them (16 waves: +0.27 ms on the training step). */
 long sig3d_fps_blocks_workspace_bytes(int b, int n);
 int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const float *dataset, void *work, long work_bytes,
-                                         int *idxs, void *stream);
+                                         int waves, int *idxs, void *stream);
 
 /* Same wrapper, same results for ANY input, for the call sites whose `dataset` is itself the
  * output of an earlier FPS stored in pick order (SA level l+1 sampling the centres of level l,

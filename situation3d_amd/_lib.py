@@ -19,7 +19,7 @@ _F = ctypes.c_float
 # name -> argtypes (restype is int status everywhere); order == include/sig3d_hip.h
 SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
-    "sig3d_furthest_point_sampling_blocks": [_I, _I, _I, _P, _P, ctypes.c_long, _P, _P],
+    "sig3d_furthest_point_sampling_blocks": [_I, _I, _I, _P, _P, ctypes.c_long, _I, _P, _P],
     "sig3d_furthest_point_sampling_nested": [_I, _I, _I, _P, _P, _P, _P, _P],
     "sig3d_fps_nested_chain": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_fps_timeout_count": [_P, _I],

@@ -1096,7 +1096,7 @@ extern "C" long sig3d_fps_blocks_workspace_bytes(int b, int n) {
 }
 
 extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const float *dataset, void *work,
-                                                    long work_bytes, int *idxs, void *stream_) {
+                                                    long work_bytes, int waves, int *idxs, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
   if (b == 0 || m <= 0) return 0;  // sampling_gpu.cu:73
@@ -1114,20 +1114,19 @@ extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const f
   float *dist = (float *)(rows + (size_t)b * n_pad);
   hipLaunchKernelGGL(fps_blocks_sort_kernel, dim3(b), dim3(1024), 0, stream, n, (int)n_pad, L, dataset, rows);
   SIG3D_LAUNCH_CHECK("fps_blocks_sort_kernel");
-  // waves per scene x managed blocks per lane x points per lane and block x blocks per trip (SIG3D_FPS_BLOCKS_SHAPE):
-  // what the workgroup holds of its CU is what the training step's kernels cannot use there
-  const char *shape = getenv("SIG3D_FPS_BLOCKS_SHAPE");
-  const int sh = shape ? atoi(shape) : 0;
+  // waves per scene x managed blocks per lane x points per lane and block x blocks per trip.  `waves` is the caller's
+  // choice between latency and footprint: 16 waves finish 2047 rounds over 40 000 points in 3.6 ms
+  // but hold four wave slots per SIMD of their CU (+0.27 ms on a training step that runs beside them); 4 waves take
+  // 6.1 ms and cost the step nothing.  0 = 4.
+  SIG3D_REQUIRE(waves == 0 || waves == 4 || waves == 8 || waves == 16, "waves must be 0 (default), 4, 8 or 16");
 #define SIG3D_FPSB(NWV, MBV, PPLV, UV)                                                                              \
   do {                                                                                                              \
     SIG3D_REQUIRE(nblocks <= 64L * NWV * MBV, "block-list FPS: more blocks than managing lanes");                    \
     hipLaunchKernelGGL((fps_blocks_kernel<NWV, MBV, PPLV, UV>), dim3(b), dim3(NWV * 64), 0, stream, n, (int)n_pad,   \
                        m, L, dataset, rows, dist, idxs);                                                            \
   } while (0)
-  if (ppl == 1 && sh == 1) SIG3D_FPSB(8, 2, 1, 4);
-  else if (ppl == 1 && sh == 2) SIG3D_FPSB(16, 1, 1, 4);
-  else if (ppl == 1 && sh == 3 && nblocks <= 640) SIG3D_FPSB(2, 5, 1, 8);
-  else if (ppl == 1 && sh == 5 && nblocks <= 768) SIG3D_FPSB(4, 3, 1, 4);
+  if (ppl == 1 && waves == 16) SIG3D_FPSB(16, 1, 1, 4);
+  else if (ppl == 1 && waves == 8) SIG3D_FPSB(8, 2, 1, 4);
   else if (ppl == 1) SIG3D_FPSB(4, 4, 1, 4);
   else if (ppl == 2) SIG3D_FPSB(16, 1, 2, 4);
   else SIG3D_FPSB(16, 1, 3, 4);

@@ -56,6 +56,9 @@ class GeometryPlan:
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
         self._fps_work = None   # scratch of the block-list FPS (level 0, scenes above 8192 points)
+        # waves per scene of that kernel: 4 for a chain that runs beside a training step (it then costs the step
+        # nothing; 16 waves: +0.27 ms), 16 where the chain's own latency bounds the throughput (serve.py)
+        self.fps_waves = 4
         self._bq_work = None    # scratch of the multi-level ball query (allocated once: static under hipGraph)
         self._bq_clean = False  # True once the workspace has been through a call (counters zero again)
         self._bq_levels = None  # its level table (ctypes array of sig3d_bq_level: raw pointers of the plan's buffers)
@@ -97,7 +100,8 @@ class GeometryPlan:
                     if self._fps_work is None:
                         self._fps_work = _lib.fps_workspace(b, n, dev)
                     _lib.call("sig3d_furthest_point_sampling_blocks", b, n, npoint, _lib.ptr(cur),
-                              _lib.ptr(self._fps_work), self._fps_work.numel(), _lib.ptr(self.inds[lvl]), s)
+                              _lib.ptr(self._fps_work), self._fps_work.numel(), int(self.fps_waves),
+                              _lib.ptr(self.inds[lvl]), s)
                 elif lvl == 0 or not NESTED_FPS:
                     _lib.call("sig3d_furthest_point_sampling", b, n, npoint, _lib.ptr(cur),
                               _lib.ptr(self._temp[lvl]), _lib.ptr(self.inds[lvl]), s)
@@ -209,10 +213,14 @@ class GeometryPipeline:
     (tools/probes/fork_penalty.py).  `handshake=False` restores the stream wait."""
 
     def __init__(self, batch, n_points, levels, device, stream, depth=1, handshake=True, stream_priority=0,
-                 example_xyz=None):
+                 example_xyz=None, fps_waves=4):
+        """fps_waves: waves per scene of the block-list FPS in the chains (GeometryPlan.fps_waves): 4 beside a training
+        step (the chain has steps of slack and must not take CU slots from the step), 16 where the chains' own latency
+        bounds the throughput (forward-only serving)."""
         assert depth >= 1
         self.depth, self.stream, self.device, self.handshake = int(depth), stream, device, bool(handshake)
         self.plan_cur = GeometryPlan(batch, n_points, levels, device)
+        self.plan_cur.fps_waves = fps_waves
         self.slots = []
         self._words = torch.zeros(4 * self.depth, dtype=torch.int32, device=device)   # per slot: ticket, consumed, error
         # the slots' buffers start from real coordinates when the caller has some (a plan of all-zero points is valid
@@ -235,6 +243,7 @@ class GeometryPipeline:
             self.slots.append(dict(plan=GeometryPlan(batch, n_points, levels, device), xyz=example.clone(),
                                    stream=st, graph=torch.cuda.CUDAGraph(),
                                    announced=Announced(), words=self._words[4 * k:4 * k + 4]))
+            self.slots[-1]["plan"].fps_waves = fps_waves
         for slot in self.slots:                       # scratch allocations and copy tables, outside any capture
             slot["plan"].compute(slot["xyz"])
             self.plan_cur.copy_from(slot["plan"])

@@ -20,6 +20,7 @@ NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
 # scenes above 8192 points: one workgroup per scene over a Morton-ordered copy in L2 (sig3d_furthest_point_sampling_blocks);
 # SIG3D_FPS_BLOCKS=0: the cooperative register-resident kernel behind the reference's own argument list (same indices)
 FPS_BLOCKS = os.environ.get("SIG3D_FPS_BLOCKS", "1") != "0"
+FPS_WAVES = 16      # waves per scene of that kernel for a stand-alone call (nothing runs beside it: latency counts)
 
 
 def _check_contiguous(t, name):
@@ -87,7 +88,7 @@ def furthest_point_sampling(points, nsamples):
         # reference's (B, N) `temp` is too small for it, so it takes a workspace of its own
         work = _lib.fps_workspace(b, n, dev)
         _run("sig3d_furthest_point_sampling_blocks", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(work),
-             work.numel(), _lib.ptr(out))
+             work.numel(), FPS_WAVES, _lib.ptr(out))
         return out
     _run("sig3d_furthest_point_sampling", dev, b, n, nsamples, _lib.ptr(points), _lib.ptr(tmp),
          _lib.ptr(out))

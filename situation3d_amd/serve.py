@@ -47,7 +47,8 @@ class PipelinedForward:
         b, n = pc.shape[0], pc.shape[1]
         self._pipe = GeometryPipeline(b, n, geometry_levels or model.encoder.LEVELS, pc.device, stream, depth=self.depth,
                                       handshake=os.environ.get("SIG3D_GEO_HANDSHAKE", "1") != "0",
-                                      stream_priority=-1 if high_priority else 0)
+                                      stream_priority=-1 if high_priority else 0,
+                                      fps_waves=16)    # forward-only: the sampling's latency bounds a chain, not its footprint
         self.plan_cur = self._pipe.plan_cur
         self.plan_cur.compute(pc[..., :3].contiguous())
 

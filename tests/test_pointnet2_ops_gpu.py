@@ -28,13 +28,15 @@ def test_fps_sizes(hip_ext, oracle, n, m):
     _fps_case(hip_ext, oracle, 2, n, m, seed=n)
 
 
-@pytest.fixture(params=["blocks", "coop"])
+@pytest.fixture(params=["blocks-16", "blocks-8", "blocks-4", "coop"])
 def fps_path(request, monkeypatch):
-    """Scenes above 8192 points: the block-list kernel behind sig3d_furthest_point_sampling_blocks (one workgroup per
-    scene over a Morton-ordered copy in L2; the default of pointnet2._ext) or the cooperative register-resident kernel
-    behind the reference's own argument list (sig3d_furthest_point_sampling)."""
+    """Scenes above 8192 points: the block-list kernel behind sig3d_furthest_point_sampling_blocks (one workgroup of 16 /
+    8 / 4 waves per scene over a Morton-ordered copy in L2: a stand-alone call takes 16, a chain beside the training step
+    4) or the cooperative register-resident kernel behind the reference's own argument list."""
     from situation3d_amd.pointnet2 import _ext as amd_ext
-    monkeypatch.setattr(amd_ext, "FPS_BLOCKS", request.param == "blocks")
+    monkeypatch.setattr(amd_ext, "FPS_BLOCKS", request.param != "coop")
+    if request.param != "coop":
+        monkeypatch.setattr(amd_ext, "FPS_WAVES", int(request.param.split("-")[1]))
     return request.param
 
 
