@@ -585,6 +585,10 @@ extern "C" int sig3d_ball_query_levels_stats(int b, int nlevels, const sig3d_bq_
     if (lds > 48 * 1024)
       SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)bqc_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
+    // (Round 6 tried the cell-role level and the ordered-scan levels as two launches with their own LDS sizes -- every
+    // workgroup of one launch is given the largest level's 74 KB, so a scan workgroup shares its CU with one other
+    // instead of three: 50.6 us for the stack against 39.3 in one launch.  The scan workgroups fill the cell-role
+    // workgroups' tail; a launch boundary between them costs more than the occupancy returns.)
     hipLaunchKernelGGL(bqc_scatter_kernel, dim3(wgs), dim3(BQC_THREADS), lds, stream, P, cnt, list);
   }
   if (rwgs > 0) hipLaunchKernelGGL(bqc_rank_kernel, dim3(rwgs), dim3(256), 0, stream, P, cnt, list);

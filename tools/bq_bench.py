@@ -22,6 +22,10 @@ def t(fn, it=20):
         fn()
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
+    # the side stream starts behind everything queued so far: the operands were produced on the default stream, and
+    # scratch that an earlier asynchronous call has already returned to the allocator (the FPS workspace: freed by
+    # Python while its kernel still runs, handed out again as `idx`) must not be written here before that call is done
+    s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         fn()
         torch.cuda.synchronize()
