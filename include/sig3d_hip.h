@@ -282,6 +282,12 @@ int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_
  * (input-gradient use).  `accumulate` (here and in sig3d_channel_stats / sig3d_bn_relu_bwd /
  * sig3d_mlp_layer_dw): 0 = the accumulators (stat_sum/stat_sq, s1/s2, dW) are zeroed by the call;
  * != 0 = the caller zeroed them (e.g. every layer of a stack with one fill) and the call only adds. */
+/* Which kernel serves sig3d_mlp_layer_fwd / _compact / sig3d_mlp_layer0_gather_fwd / sig3d_mlp_layer_dx from now on
+ * (process-wide, host-side; read when a call is issued or captured): 0 = the round-1 layer kernel
+ * (v_mfma_f32_32x32x2_f32, one LDS read per MFMA), 1 = the round-6 one (v_mfma_f32_16x16x4_f32, ds_read_b128 operand
+ * fragments, csrc/mlp16.hip) wherever its shapes apply (64 | cout; 32 | cin <= 288 or a gathering first layer with
+ * 32 | C <= 256), the round-1 kernel elsewhere.  Same results up to the order of the f32 sums. */
+int sig3d_mlp_layer_core(int core);
 int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                         const float *pscale, const float *pshift, float *y, double *stat_sum,
                         double *stat_sq, int accumulate, void *stream);

@@ -787,6 +787,9 @@ __global__ __launch_bounds__(NW * 64) void fps_blocks_kernel(int n, int n_pad, i
                                                              int *__restrict__ idxs_all) {
   constexpr int BP = 64 * PPL;
   static_assert(NW == 1 || NW == 2 || NW == 4 || NW == 8 || NW == 16, "the candidates of all waves are reduced inside a 16-lane row");
+  // (Raised wave priority -- s_setprio 3 -- was tried for the case beside a training step, where the kernel takes 1.5 x
+  // as long as alone: no effect, 14.1 against 14.2 ms per chain.  The extra time is memory latency under the step's
+  // traffic, not issue arbitration.)
   __shared__ int s_part[2][NW][8];   // a wave's candidate: value bits, key, x, y, z
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -35,6 +35,7 @@ with torch.cuda.stream(work):
         if prev_done is not None:
             recs.append((ready, prev_done, start))
         state["done"].append(done)
+        state.setdefault("span", []).append((start, done))      # this chain: ticket signalled -> chain finished
     pipe.advance = advance
     for i in range(120):
         up = [batches[(i + 1 + k) % 4] for k in range(depth)]
@@ -46,3 +47,6 @@ print("steps %d: chain done minus step ready: mean %+.3f ms, min %+.3f, max %+.3
          100.0 * sum(w > 0 for w in wait) / len(wait), statistics.mean([max(w, 0.0) for w in wait])))
 q = sorted(wait)
 print("quantiles (ms): 10%% %+.3f  50%% %+.3f  90%% %+.3f  99%% %+.3f" % (q[len(q) // 10], q[len(q) // 2], q[9 * len(q) // 10], q[-1]))
+span = [a.elapsed_time(b) for a, b in state["span"][20:]]
+print("chain duration (ticket signalled on the step's stream -> last kernel of the chain): mean %.3f ms, min %.3f, max %.3f"
+      % (statistics.mean(span), min(span), max(span)))
