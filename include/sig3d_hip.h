@@ -61,9 +61,12 @@ int sig3d_furthest_point_sampling(int b, int n, int m, const float *dataset, flo
  * a Morton-ordered copy held in L2 -- only the blocks a new sample can reach are swept -- instead of eight
  * register-resident workgroups exchanging candidates through memory.  Same indices for any input
  * (sampling_gpu.cu:69-173: same distance arithmetic, skip rule and tie order).
- * waves (scenes of up to 65 536 points): waves of that workgroup -- 16: lowest latency (3.6 ms for 2047 rounds over
- * 40 000 points, as the cooperative kernel), for a call nothing runs beside; 4 (= 0, the default): 6.1 ms, but a
- * chain that runs BESIDE other kernels then takes nothing from them (16 waves: +0.27 ms on the training step). */
+ * waves (scenes of up to 65 536 points): waves of that workgroup -- 16: lowest latency (3.7 ms for 2047 rounds over
+ * 40 000 points; the cooperative kernel: 3.5), for a call nothing runs beside; 4 (= 0, the default): 6.1 ms alone, and a
+ * chain that runs BESIDE other kernels then takes nothing from them (16 waves: +0.27 ms on the training step) -- but
+ * every round fetches its operands from L2 / memory, so beside a bandwidth-heavy step the call takes 1.5-2 x as long
+ * as alone (9.5-13 ms), where the register-resident cooperative kernel takes 7: DESIGN.md section 4j, why
+ * pointnet2._ext and geometry.GeometryPlan keep sig3d_furthest_point_sampling unless SIG3D_FPS_BLOCKS=1. */
 long sig3d_fps_blocks_workspace_bytes(int b, int n);
 int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const float *dataset, void *work, long work_bytes,
                                          int waves, int *idxs, void *stream);
@@ -282,12 +285,6 @@ int sig3d_query_group_fused_grad(int b, int n, int m, int c, int nsample, int c_
  * (input-gradient use).  `accumulate` (here and in sig3d_channel_stats / sig3d_bn_relu_bwd /
  * sig3d_mlp_layer_dw): 0 = the accumulators (stat_sum/stat_sq, s1/s2, dW) are zeroed by the call;
  * != 0 = the caller zeroed them (e.g. every layer of a stack with one fill) and the call only adds. */
-/* Which kernel serves sig3d_mlp_layer_fwd / _compact / sig3d_mlp_layer0_gather_fwd / sig3d_mlp_layer_dx from now on
- * (process-wide, host-side; read when a call is issued or captured): 0 = the round-1 layer kernel
- * (v_mfma_f32_32x32x2_f32, one LDS read per MFMA), 1 = the round-6 one (v_mfma_f32_16x16x4_f32, ds_read_b128 operand
- * fragments, csrc/mlp16.hip) wherever its shapes apply (64 | cout; 32 | cin <= 288 or a gathering first layer with
- * 32 | C <= 256), the round-1 kernel elsewhere.  Same results up to the order of the f32 sums. */
-int sig3d_mlp_layer_core(int core);
 int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float *x, const float *w,
                         const float *pscale, const float *pshift, float *y, double *stat_sum,
                         double *stat_sq, int accumulate, void *stream);

@@ -21,7 +21,6 @@ SIGNATURES = {
     "sig3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "sig3d_furthest_point_sampling_blocks": [_I, _I, _I, _P, _P, ctypes.c_long, _I, _P, _P],
     "sig3d_furthest_point_sampling_nested": [_I, _I, _I, _P, _P, _P, _P, _P],
-    "sig3d_mlp_layer_core": [_I],
     "sig3d_fps_nested_chain": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "sig3d_fps_timeout_count": [_P, _I],
     "sig3d_timestamp": [_P, _P],

@@ -14,8 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsig3d_hip.so")
 SOURCES = ["capi.hip", "sampling.hip", "ball_query.hip", "group_points.hip", "interpolate.hip",
-           "situational.hip", "attention.hip", "shared_mlp.hip", "pos_embed.hip", "rowops.hip", "optim.hip", "voxelize.hip", "compact.hip", "gemm16.hip", "gemmp.hip", "sqa_loss.hip", "sa_first.hip", "small_mlp.hip", "qformer_embed.hip", "heads.hip", "mlp16.hip"]
-HEADERS = [os.path.join(CSRC, "sig3d_common.h"), os.path.join(CSRC, "gemm16_core.h"), os.path.join(CSRC, "gemmp_core.h"), os.path.join(CSRC, "mlp16.h"), os.path.join(CSRC, "situational_pose.h"),
+           "situational.hip", "attention.hip", "shared_mlp.hip", "pos_embed.hip", "rowops.hip", "optim.hip", "voxelize.hip", "compact.hip", "gemm16.hip", "gemmp.hip", "sqa_loss.hip", "sa_first.hip", "small_mlp.hip", "qformer_embed.hip", "heads.hip"]
+HEADERS = [os.path.join(CSRC, "sig3d_common.h"), os.path.join(CSRC, "gemm16_core.h"), os.path.join(CSRC, "gemmp_core.h"), os.path.join(CSRC, "situational_pose.h"),
            os.path.join(HERE, "..", "include", "sig3d_hip.h"), os.path.join(HERE, "..", "include", "sig3d_debug.h")]
 # -ffp-contract=off: distances are spelled with _rn intrinsics already; this keeps every other
 # f32 expression in the point ops unfused too (parity contract, see oracle/pointnet2_oracle.c).

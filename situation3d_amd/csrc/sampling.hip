@@ -681,12 +681,12 @@ int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *tem
 // sample changes a small part of the scene after the first few dozen rounds.  Here that is the whole design:
 //   * a pre-pass (fps_blocks_sort_kernel) stores the scene along a Morton curve as {x, y, z, tie key} rows; a block is
 //     64 * PPL consecutive rows (625 blocks of 64 at n = 40 000); the running distances live beside them in global
-//     memory -- 800 KB per scene, resident in the XCD's L2 (workgroup i lands on XCD i mod 8);
-//   * lane l of wave w MANAGES block l * NW + w: its box, its largest running distance, the tie key and the coordinates
-//     of the point that holds it -- all in that lane's registers (11 VGPRs), nothing of it in LDS;
-//   * a round: every lane tests the new sample against its block's box (the blocked kernel's test, same margin); a
+//     memory -- 800 KB per scene, in the XCD's L2 / the memory-side cache (workgroup i lands on XCD i mod 8);
+//   * lane l of wave w MANAGES blocks (64 s + l) * NW + w, s < MB: box, largest running distance, the tie key and the
+//     coordinates of the point that holds it -- all in that lane's registers (11 VGPRs per block), nothing of it in LDS;
+//   * a round: every lane tests the new sample against its blocks' boxes (the blocked kernel's test, same margin); a
 //     wave sweeps the blocks of its own lanes that can change (ballot -> scalar loop; one point per lane and row, the
-//     loads of up to four blocks in flight), reduces each (max distance, then min key: the reference's total order)
+//     loads of up to U blocks in flight), reduces each (max distance, then min key: the reference's total order)
 //     and hands the result to the managing lane; the wave's candidate {value, key, x, y, z} goes to LDS, ONE barrier,
 //     every wave reduces the NW candidates itself.  The next sample's coordinates come with the candidate: no
 //     dependent global load, no exchange between CUs.
@@ -694,6 +694,10 @@ int launch_fps_coop(int b, int n, int m, int L, const float *dataset, float *tem
 // barrier waits for the LDS write only (the distance stores drain behind it).  Same indices as every other kernel of
 // this file: the same individually rounded distance, min, skip rule and (value, key) order; a block that sits a round
 // out holds exactly what a sweep would have left.
+// What it is for: a chain beside a training step costs the step the wave slots it holds -- 16
+// waves per scene +0.27 ms, 4 waves -0.07 ms against the cooperative kernel -- but every round here waits for L2 /
+// memory, 1.5-2 x longer beside the step's traffic, and the chain is then 10-14 ms long where the cooperative kernel's
+// is 7.7.  Opt-in (SIG3D_FPS_BLOCKS=1); sig3d_furthest_point_sampling keeps the cooperative kernel.
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v)));

@@ -25,7 +25,6 @@
 #include <cstdlib>
 
 #include "gemm16_core.h"
-#include "mlp16.h"
 #include "sig3d_common.h"
 
 extern "C" int sig3d_internal_dw_stream_problem(int b, int cin, int cout, long e, const float *dY, const float *x,
@@ -1350,15 +1349,6 @@ static thread_local const float *tl_mult = nullptr;
 
 static thread_local const MlpGather *tl_gather = nullptr;
 static thread_local int tl_w_t = 0;   // the weight operand of the call in flight is given transposed (sig3d_mlp_layer_dx)
-// which kernel serves the forward / input-gradient products: 0 = mlp_layer_fwd_kernel (32x32x2 MFMA, round 1),
-// 1 = mlp16_kernel (16x16x4 MFMA, ds_read_b128 fragments, round 6) wherever it applies (sig3d_mlp_layer_core)
-static int g_mlp_core = 0;
-extern "C" int sig3d_mlp_layer_core(int core) {
-  SIG3D_REQUIRE(core >= 0 && core <= 2, "core must be 0 (32x32x2 layer kernel), 1 (16x16x4 kernel on dense rows) or 2 (everywhere)");
-  g_mlp_core = core;
-  return 0;
-}
-
 template <int NT, bool PROLOGUE, bool VEC, bool RAGGED, bool GATHER, bool SCATTER = false>
 static int launch_mlp_fwd_g(int b, int cin, int cout, long e, const float *x, const float *w,
                             const float *pscale, const float *pshift, float *y, double *stat_sum,
@@ -1454,20 +1444,6 @@ extern "C" int sig3d_mlp_layer_fwd(int b, int cin, int cout, long e, const float
   if (b == 0 || e == 0) return 0;
   SIG3D_REQUIRE((long)cin * e < (1L << 31) && (long)cout * e < (1L << 31),
                 "cin*e and cout*e must stay below 2^31 (32-bit addressing inside the kernel)");
-  // core 1 serves DENSE rows; core 2 also compact lists (a sample's few thousand distinct neighbours are a handful of its
-  // 256-position tiles: on the headline's compact levels it loses to the 32-position wave tiles of the round-1 kernel)
-  if ((g_mlp_core == 2 || (g_mlp_core == 1 && tl_n_act == nullptr)) && !(tl_gather != nullptr && tl_gather->scatter != nullptr)) {
-    Mlp16Args a = {};
-    a.b = b; a.cin = cin; a.cout = cout; a.E = e; a.x = x; a.w = w; a.pscale = pscale; a.pshift = pshift; a.y = y;
-    a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.n_act = tl_n_act; a.mult = tl_mult; a.w_t = tl_gather ? 0 : tl_w_t;
-    if (tl_gather != nullptr) {
-      a.gather = 1;
-      a.g_xyz = tl_gather->xyz; a.g_centre = tl_gather->centre; a.g_feat = tl_gather->feat_pm; a.g_idx = tl_gather->idx;
-      a.g_centre_of = tl_gather->centre_of; a.gN = tl_gather->N; a.gP = tl_gather->P; a.gS = tl_gather->S; a.gC = tl_gather->C;
-      a.g_normalize = tl_gather->normalize; a.g_radius = tl_gather->radius;
-    }
-    if (sig3d_mlp16_applies(a)) return sig3d_mlp16_launch(a, stream);
-  }
   const int kpad = ml_kpad(cin), ldw = kpad | 1;
   SIG3D_REQUIRE(sizeof(float) * ((size_t)32 * ldw + 2 * kpad + ML_WAVES * 2 * 32 + ML_WAVES * 16 * ML_TRLD) <= 160 * 1024,
                 "input channel count too large for the LDS weight tile");

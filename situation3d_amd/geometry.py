@@ -56,8 +56,9 @@ class GeometryPlan:
         self.inds, self.new_xyz, self.ball_idx, self._temp, self.compact = [], [], [], [], []
         self.fps_proven = []  # per level: (B,) int32, 1 where the nested-FPS proof held (levels >= 1)
         self._fps_work = None   # scratch of the block-list FPS (level 0, scenes above 8192 points)
-        # waves per scene of that kernel: 4 for a chain that runs beside a training step (it then costs the step
-        # nothing; 16 waves: +0.27 ms), 16 where the chain's own latency bounds the throughput (serve.py)
+        # waves per scene of that kernel (only with SIG3D_FPS_BLOCKS=1): 4 for a chain that runs beside a training step
+        # (-0.07 ms per step in the steady state; 16 waves: +0.27), 16 where the chain's own latency bounds the
+        # throughput (serve.py)
         self.fps_waves = 4
         self._bq_work = None    # scratch of the multi-level ball query (allocated once: static under hipGraph)
         self._bq_clean = False  # True once the workspace has been through a call (counters zero again)

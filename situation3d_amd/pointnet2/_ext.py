@@ -17,9 +17,13 @@ from .. import _lib
 
 # SIG3D_NESTED_FPS=0: always run the dependent rounds (A/B timing; results are identical)
 NESTED_FPS = os.environ.get("SIG3D_NESTED_FPS", "1") != "0"
-# scenes above 8192 points: one workgroup per scene over a Morton-ordered copy in L2 (sig3d_furthest_point_sampling_blocks);
-# SIG3D_FPS_BLOCKS=0: the cooperative register-resident kernel behind the reference's own argument list (same indices)
-FPS_BLOCKS = os.environ.get("SIG3D_FPS_BLOCKS", "1") != "0"
+# SIG3D_FPS_BLOCKS=1: scenes above 8192 points on sig3d_furthest_point_sampling_blocks (one workgroup per scene over a
+# Morton-ordered copy in L2) instead of the cooperative register-resident kernel behind the reference's own argument list.
+# Same indices.  Measured: in the steady state of a long run the 4-wave form beside the training
+# step is worth -0.07 ms per step, but its chain takes 10-14 ms beside the step (7.7 for the cooperative kernel) and the
+# 20 timed steps of bench.py end 0.1 ms per step later; alone and in forward-only serving the cooperative kernel is level
+# or ahead.  Not the default.
+FPS_BLOCKS = os.environ.get("SIG3D_FPS_BLOCKS", "0") != "0"
 FPS_WAVES = 16      # waves per scene of that kernel for a stand-alone call (nothing runs beside it: latency counts)
 
 

@@ -101,9 +101,6 @@ def compact_lists(idx):
 DW_STREAM = 1
 DW_FOLD_ONCE = True      # one slab fold per SharedMLP stack (sig3d_sum_slabs_multi) instead of one per layer
 DW_DX_ONE = True         # a compact level's layer: weight gradient + input gradient as two workgroup ranges of ONE launch
-# which kernel serves the layers' forward / input-gradient products (sig3d_mlp_layer_core): 0 = the round-1 layer kernel
-# (32x32x2 MFMA), 1 = the round-6 one (16x16x4 MFMA, 16-byte operand fragments: csrc/mlp16.hip) wherever it applies
-MLP_CORE = int(os.environ.get("SIG3D_MLP_CORE", "0"))
 DW_REGROUP = True        # the gathered first layer of a compact level re-materialises its operand for the streaming dW
 # dense rows longer than this keep mlp_dw_kernel (it was tuned on the 131 072-position rows of a dense SA1: the dense
 # variant of the bench is 0.15 ms slower with the streaming product there)
@@ -191,7 +188,6 @@ class _FusedMLPMax(torch.autograd.Function):
         # (B, 3 + C, npoint, nsample) tensor in either direction); idx = ball-query lists, or the compact lists
         dev = x.device
         ctx.set_materialize_grads(False)   # an unused output (channel-major OR point-major) arrives as None, not zeros
-        _lib.call("sig3d_mlp_layer_core", int(MLP_CORE))
         if compact is not None:
             assert not library_gemm
             c_cidx, c_cent, c_mult, c_seg, c_nact = compact
@@ -315,7 +311,6 @@ class _FusedMLPMax(torch.autograd.Function):
         e = p * s
         dev = x.device
         stream = _lib.stream_ptr(dev)
-        _lib.call("sig3d_mlp_layer_core", int(MLP_CORE))
         top_from_pm = None
         if grad_out_pm is not None and grad_out is None:
             # the point-major output's gradient (rows scattered by the level above / the Q-Former's token gradient):
@@ -437,7 +432,7 @@ class _FusedMLPMax(torch.autograd.Function):
                     # operands read along their rows, slabs folded in a fixed order (1.5-2.5 x sig3d_mlp_layer_dw)
                     n_work = int(_lib.load().sig3d_mlp_layer_dw_stream_work_floats(b, cin, cout, e))
                     work = torch.empty(max(n_work, 4), dtype=torch.float32, device=dev)
-                    if DW_DX_ONE and DW_FOLD_ONCE and compact is not None and k > 0 and not ctx.library_gemm and MLP_CORE != 2:
+                    if DW_DX_ONE and DW_FOLD_ONCE and compact is not None and k > 0 and not ctx.library_gemm:
                         # the layer's two products over dY as workgroup ranges of one launch (they share only what they read)
                         dA_next = torch.empty((b, cin, p, s), dtype=torch.float32, device=dev)
                         _lib.call("sig3d_mlp_layer_dw_dx", b, cin, cout, e, _lib.ptr(dY), _lib.ptr(prev), _lib.ptr(pps),

@@ -9,6 +9,11 @@ its buffers and queues landed), the same in every replay.  One build per arm the
 `--builds N` (default 3) builds N objects per arm, alternately, and reports the arm means with the standard error ACROSS
 builds; a difference counts when it exceeds that.  SIG3D_GEO_DEPTH (chains in flight) defaults to 3 as in bench.py.
 
+WHAT IT CANNOT SEE AT ALL (round 6): how long the geometry chains themselves take.  Every timed block runs behind a re-primed
+pipeline (three chains = 22 ms of slack), so a chain that needs 14 ms beside the step instead of 7.7 looks free here, while
+the 20 timed steps of bench.py end when their last chains end (+0.33 ms per step).  A change that touches the chain is
+measured with tools/probes/chain_slack.py and with alternating bench.py runs (tools/probes/bench_fps_forms.sh) as well.
+
 python tools/ab_step.py situation3d_amd.qformer.FUSED_EMBED False True [--rounds 24] [--replays 10]
 python tools/ab_step.py env:SIG3D_GEO_HANDSHAKE 0 1
 python tools/ab_step.py env:SIG3D_GEO_DEPTH 1 2
