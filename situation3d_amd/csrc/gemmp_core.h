@@ -3,7 +3,7 @@
 // The products of the Q-Former's dense layers (3DLLM_BLIP2-base/lavis/models/blip2_models/Qformer.py:116-118 query /
 // key / value, :238 BertSelfOutput.dense, :305 BertIntermediate.dense + erf-GELU, :320 BertOutput.dense), of their
 // input gradients (dX = dY W) and of their weight gradients (dW = dY^T X).
-// Arithmetic as gemmx6_core.h: an f32 number is the exact sum of three bf16 numbers (x = x1 + x2 + x3); the six cross
+// Arithmetic as round 4's gemmx6_core.h (removed in round 6; git history): an f32 number is the exact sum of three bf16 numbers (x = x1 + x2 + x3); the six cross
 // products with i + j <= 4, each exact in f32, are accumulated in f32 by v_mfma_f32_32x32x16_bf16, smallest first --
 // f32-equivalent results (closer to the float64 product than an f32 GEMM's: DESIGN.md 4g).
 // What round 4 measured (profiles/r04_gemmx6.md): with the split made INSIDE the product's loop the loop is bound by the

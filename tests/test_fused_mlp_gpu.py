@@ -297,7 +297,7 @@ def test_first_layer_with_the_grouped_operand_gathered_on_load(b, n, m, ns, c, c
 def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monkeypatch):
     """PointnetSAModuleVotes on the MFMA path with the first SharedMLP layer gathering its operand on load
     (fused_mlp.fused_sa_dense / fused_sa_compact) against the same module with the
-    grouped tensor stored (SIG3D_GATHER_L0=0): features out, feature gradient in, every parameter gradient and
+    grouped tensor stored (fused_mlp.GATHER_L0 = False): features out, feature gradient in, every parameter gradient and
     the BatchNorm running statistics."""
     from situation3d_amd.pointnet2 import fused_mlp, pointnet2_modules
     from util import scene
@@ -586,7 +586,7 @@ def test_first_layer_from_the_raw_scan_matches_group_then_conv(compact, c, cout,
 def test_sa1_reading_the_raw_scan_matches_the_stored_grouped_tensor(mode, monkeypatch):
     """PointnetSAModuleVotes on a (B, N, 6) scan: the first SharedMLP layer formed from point-major rows
     (fused_mlp.attach_scan / first_layer_scan; no colour transpose, no grouped tensor) against the stored form
-    (SIG3D_FIRST_L0=0): pooled features, every parameter gradient, BatchNorm running statistics."""
+    (fused_mlp.FIRST_L0 = False): pooled features, every parameter gradient, BatchNorm running statistics."""
     import copy
     from situation3d_amd.pointnet2 import fused_mlp
     from situation3d_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes

@@ -1,6 +1,6 @@
 """Per-layer timing of the fused SharedMLP kernels at the SA1 / SA2 shapes of the bench
 (sig3d_mlp_layer_fwd, sig3d_mlp_layer_dw, bn_relu_bwd, bn_relu_maxpool) with achieved HBM rates.
-SIG3D_MLP_NT=1|2|4 forces the channel-tile width of the forward kernel (tuning knob).
+(Round 6 removed SIG3D_MLP_NT: the launcher picks the channel-tile width.)
 
 python tools/mlp_bench.py
 """

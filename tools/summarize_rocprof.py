@@ -5,7 +5,7 @@ python tools/summarize_rocprof.py gpurun_out/prof_x profiles/r01_name.md "comman
 Groups at the end: library GEMMs (Cijk_*), torch glue (at::native / rocclr copy+fill), own kernels.
 Per-step figures divide by the call count of a kernel that runs exactly ONCE per step in EVERY mode -- the loss kernel
 (sqa_loss_kernel), else the step counter (step_increment_kernel); the flat AdamW launch runs once per bucket in the
-data-parallel modes and twice with SIG3D_UPDATE_BESIDE=1 and is only the last resort -- not by a step count guessed from the
+data-parallel modes and is only the last resort -- not by a step count guessed from the
 command line; the optional [steps] argument is only used when the trace holds none of them.  The divisor is printed.
 """
 import csv
