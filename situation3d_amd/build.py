@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
-    for src in SOURCES:
+    for src in sorted(SOURCES, key=lambda f: -os.path.getsize(os.path.join(CSRC, f))):   # longest compile first
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
@@ -53,7 +53,8 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        # the longest translation unit (shared_mlp.hip, ~70 s) bounds the wall time once every file has a core
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

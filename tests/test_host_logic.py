@@ -345,3 +345,53 @@ def test_storage_layout_keeps_two_arenas_when_the_backward_pass_is_cut_inside_th
         i = dec.index("Qformer.bert.encoder.layer.3.attention.self.value.weight")
         after = dec[i + 1]
         assert (after == "Qformer.bert.encoder.layer.4.attention.self.query.weight") == (cut is None)
+
+
+def test_runs_index_like_the_tensor_they_replace_and_refuse_a_range_across_the_cut():
+    """qformer._Runs: a layer-batched buffer stored as one run per parameter arena.  Indexing by a layer, by a
+    (layer, ...) tuple and by a range inside one run must return what the single tensor would; a range that straddles the
+    storage cut is an error (flush() cuts its ranges at the boundary and never issues one)."""
+    import pytest
+    from situation3d_amd.qformer import _Runs
+    whole = torch.arange(6 * 2 * 3, dtype=torch.float32).view(6, 2, 3)
+    runs = _Runs([(0, 4, whole[:4].clone()), (4, 6, whole[4:].clone())])
+    for l in range(6):
+        assert torch.equal(runs[l], whole[l]) and torch.equal(runs[l, 1], whole[l, 1])
+    assert torch.equal(runs[0:4], whole[0:4]) and torch.equal(runs[4:6], whole[4:6]) and torch.equal(runs[1:3, 0], whole[1:3, 0])
+    assert torch.equal(runs[:4], whole[:4]) and torch.equal(runs[4:], whole[4:])
+    with pytest.raises(IndexError):
+        runs[3:5]
+    # row-indexed form (the stacked key / value weight gradients: 2H rows per cross layer)
+    rows = torch.arange(12 * 5, dtype=torch.float32).view(12, 5)
+    kv = _Runs([(0, 8, rows[:8].clone()), (8, 12, rows[8:].clone())])
+    assert torch.equal(kv[4:8], rows[4:8]) and torch.equal(kv[8:10], rows[8:10])
+    like = kv.empty_like()
+    assert [t.shape for t in like.tensors()] == [t.shape for t in kv.tensors()] and like.tensors()[0] is not kv.tensors()[0]
+    kv[8:12].fill_(7.0)                                  # views: a write through an index lands in the run's storage
+    assert float(kv.tensors()[1].min()) == 7.0
+
+
+def test_capture_tables_hand_out_every_set_once():
+    from situation3d_amd.optim import CaptureTables
+    import pytest
+    t = CaptureTables(["a", "b"])
+    assert t.take() == "a" and t.take() == "b"
+    with pytest.raises(RuntimeError, match="more gradient tables than were reserved"):
+        t.take()
+
+
+def test_comm_model_states_both_forms_and_the_cut_never_costs_more():
+    """bench.comm_model: the prediction a multi-GPU line carries -- both data-parallel forms at N = 2 / 4 / 8, the second
+    cut putting half of the bytes on the wire earlier, so its predicted step is never the longer one; the line's own
+    form follows --qf-cut."""
+    import bench
+    nbytes = 615_044_192
+    m = bench.comm_model(8, nbytes, 7.4, qf_cut=6)
+    assert set(m["forms"]) == {"N=2", "N=4", "N=8", "N=8 at rccl 180 GB/s"} and m["form"] == "cut 6"
+    for n, f in m["forms"].items():
+        assert f["cut"]["predicted_ms_per_step"] <= f["uncut"]["predicted_ms_per_step"], n
+        assert f["cut"]["exposed_ms"] <= f["uncut"]["exposed_ms"] and f["cut"]["wire_ms"] == f["uncut"]["wire_ms"]
+    assert abs(m["forms"]["N=2"]["uncut"]["wire_ms"] - nbytes / 76.8e9 * 1e3) < 1e-2      # one link between two GPUs
+    assert m["predicted_ms_per_step"] == m["forms"]["N=8"]["cut"]["predicted_ms_per_step"]
+    assert bench.comm_model(8, nbytes, 7.4, qf_cut=0)["form"] == "uncut"
+    assert bench.comm_model(1, nbytes)["predicted_ms_per_step"] is None and "forms" in bench.comm_model(1, nbytes)
