@@ -395,3 +395,40 @@ def test_comm_model_states_both_forms_and_the_cut_never_costs_more():
     assert m["predicted_ms_per_step"] == m["forms"]["N=8"]["cut"]["predicted_ms_per_step"]
     assert bench.comm_model(8, nbytes, 7.4, qf_cut=0)["form"] == "uncut"
     assert bench.comm_model(1, nbytes)["predicted_ms_per_step"] is None and "forms" in bench.comm_model(1, nbytes)
+
+
+def test_ctypes_signatures_have_the_arity_and_argument_classes_of_the_header_prototypes():
+    """Every entry point bound in situation3d_amd._lib.SIGNATURES takes as many arguments as its prototype in
+    include/sig3d_hip.h / sig3d_debug.h declares, each of the prototype's class (int / long / float / double / pointer): a
+    drifted ctypes table only shows on a GPU box, as a wrong result."""
+    from situation3d_amd import _lib
+    protos = {}
+    for h in ("sig3d_hip.h", "sig3d_debug.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"\b(?:int|long|const char \*)\s*(sig3d_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+            args = m.group(2).strip()
+            protos[m.group(1)] = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+    assert len(protos) >= 100
+
+    def kind(decl):            # C parameter -> the class of ctypes type that may carry it
+        if "*" in decl or "[" in decl:
+            return "pointer"
+        base = decl.rsplit(" ", 1)[0].replace("const", "").replace("unsigned", "").strip() if " " in decl else decl
+        return {"int": "int", "long": "long", "float": "float", "double": "double", "": "int",
+                "long long": "long", "size_t": "long"}.get(base, base)
+
+    def ctype_kind(t):
+        if t in (ctypes.c_void_p,) or hasattr(t, "contents") or getattr(t, "_type_", None) not in ("i", "l", "f", "d", "I", "L", "q", "Q"):
+            return "pointer"
+        return {"i": "int", "I": "int", "l": "long", "L": "long", "q": "long", "Q": "long", "f": "float", "d": "double"}[t._type_]
+
+    checked = 0
+    for name, argtypes in _lib.SIGNATURES.items():
+        assert name in protos, "%s is bound but not declared" % name
+        assert len(argtypes) == len(protos[name]), "%s: %d ctypes arguments, %d in the header" % (name, len(argtypes), len(protos[name]))
+        for i, (t, decl) in enumerate(zip(argtypes, protos[name])):
+            assert ctype_kind(t) == kind(decl), "%s argument %d: ctypes %s for `%s`" % (name, i, t, decl)
+        checked += 1
+    assert checked == len(_lib.SIGNATURES) >= 90
