@@ -115,3 +115,44 @@ def test_three_nn_fewer_than_three_known_points(oracle):
     d2, i3 = oracle.three_nn(unknown, known)
     assert torch.isinf(d2[..., 2]).all() and (i3[..., 2] == 0).all()
     assert torch.isfinite(d2[..., :2]).all()
+
+
+@pytest.mark.parametrize("n,m,dup,zero_tail", [(9000, 160, 0, 0), (10000, 140, 900, 300), (8500, 120, 4000, 0)])
+def test_block_list_fps_algorithm_equals_the_reference_sampling(oracle, n, m, dup, zero_tail):
+    """tests/fps_blocks_sim.py -- the ALGORITHM of the block-list kernel (csrc/sampling.hip: fps_blocks_kernel) in
+    NumPy float32: Morton blocks of 64 rows, a block sits a round out when the sample is farther from its box (x 0.99998)
+    than its largest running distance.  Same indices as the oracle (= the reference's sampling) on random scenes,
+    scenes with thousands of duplicated points (exact ties decided by the key) and a zero tail (skipped points), and
+    whichever order the points of a Morton cell arrive in; most block-rounds are sat out."""
+    import numpy as np
+    import fps_blocks_sim
+    from util import scene
+    xyz = scene(1, n, seed=n + m, dup=dup, zero_tail=zero_tail)
+    ref = oracle.furthest_point_sampling(xyz, m)[0].numpy()
+    stats = {}
+    got = fps_blocks_sim.furthest_point_sampling(xyz[0].numpy(), m, stats=stats)
+    assert np.array_equal(got, ref), np.nonzero(got != ref)[0][:5]
+    again = fps_blocks_sim.furthest_point_sampling(xyz[0].numpy(), m, rng=np.random.default_rng(3))
+    assert np.array_equal(again, ref)
+    swept = np.array(stats["swept"])
+    assert swept[0] >= stats["blocks"] - 8 and swept[len(swept) // 2:].mean() < 0.35 * stats["blocks"]
+
+
+def test_block_list_fps_algorithm_on_degenerate_scenes(oracle):
+    """A flat scene (one box extent 0), a lattice (every round ties), everything inside the skip rule, NaN / infinite
+    coordinates: the sit-out rule and the candidate order of the block-list algorithm against the oracle."""
+    import numpy as np
+    import torch
+    import fps_blocks_sim
+    g = torch.Generator().manual_seed(5)
+    flat = torch.rand(1, 9000, 3, generator=g) * 6 + 0.5
+    flat[..., 2] = 1.25
+    lat = torch.stack(torch.meshgrid(torch.arange(24.), torch.arange(24.), torch.arange(16.), indexing="ij"), -1)
+    lat = (lat.reshape(1, -1, 3) * 0.25 + 0.5).contiguous()
+    none = torch.zeros(1, 8300, 3)
+    odd = torch.rand(1, 9000, 3, generator=g) * torch.tensor([8.0, 8.0, 3.0])
+    odd[0, 100] = float("nan"); odd[0, 5000, 1] = float("inf"); odd[0, 8999, 2] = float("-inf")
+    for cloud, m in ((flat, 120), (lat, 150), (none, 8), (odd, 100)):
+        ref = oracle.furthest_point_sampling(cloud.contiguous(), m)[0].numpy()
+        got = fps_blocks_sim.furthest_point_sampling(cloud[0].numpy(), m)
+        assert np.array_equal(got, ref), (tuple(cloud.shape), np.nonzero(got != ref)[0][:5])
