@@ -432,3 +432,45 @@ def test_ctypes_signatures_have_the_arity_and_argument_classes_of_the_header_pro
             assert ctype_kind(t) == kind(decl), "%s argument %d: ctypes %s for `%s`" % (name, i, t, decl)
         checked += 1
     assert checked == len(_lib.SIGNATURES) >= 90
+
+
+def test_weight_gradient_arena_follows_a_storage_cut():
+    """qformer._WeightGradArena over two parameter arenas (storage_cut = k: the layout trainer.build_optimizer(qf_cut=k)
+    gives the Q-Former), on the host: every layer parameter still gets exactly one gradient view of its own shape, the
+    layer-batched buffers and the stacked key / value weights have a run per arena, a flush over all layers is issued as one
+    batch per arena (upper arena first), and the scene-token gradient of the two runs equals the single-run product."""
+    from situation3d_amd.qformer import _Runs, _WeightGradArena, init_Qformer
+    torch.manual_seed(0)
+    qf, _ = init_Qformer(32, 64, hidden_size=64, num_hidden_layers=4, num_attention_heads=2, intermediate_size=128,
+                         max_position_embeddings=64, vocab_size=50)
+    layers = list(qf.bert.encoder.layer)
+    enc2 = torch.randn(2 * 40, 64)
+
+    def arena(cut):
+        return _WeightGradArena(layers, 2, 32, 20, 64, enc2, 2, [0], grad_store=None, storage_cut=cut)
+
+    one, two = arena(None), arena(2)
+    assert one.runs == [(0, 4)] and two.runs == [(0, 2), (2, 4)] and two.cross_runs == [(0, 1), (1, 2)]
+    assert isinstance(two.gwqkv, _Runs) and isinstance(two.gwkv, _Runs) and not isinstance(one.gwqkv, _Runs)
+    layer_params = {id(p) for l in layers for p in l.parameters()}
+    for a in (one, two):
+        views = a.param_views(0, 4)
+        assert {id(p) for p, _ in views} == layer_params and len(views) == len(layer_params)
+        assert all(tuple(v.shape) == tuple(p.shape) for p, v in views)
+        spans = sorted((v.data_ptr(), v.data_ptr() + 4 * v.numel()) for _, v in views)
+        assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:]))          # no two views overlap
+    # the stacked key / value weights: one zero-copy-or-cat view per arena, same rows as the single stack
+    assert len(two.wkv_runs) == 2 and len(one.wkv_runs) == 1
+    assert torch.equal(torch.cat([w for _, _, w in two.wkv_runs]), one.wkv_runs[0][2])
+    assert torch.allclose(two.kv, one.kv, atol=1e-5)                                  # the projection of the scene tokens
+    # a flush over every layer: one batch of products per arena, the upper one first
+    calls = []
+    two._products = lambda lo, hi: calls.append((lo, hi))
+    two._products_cut(0, 4)
+    two._products_cut(1, 2)
+    two._products_cut(1, 3)
+    assert calls == [(2, 4), (0, 2), (1, 2), (2, 3), (1, 2)]
+    # the gradient of the scene tokens over both cross layers
+    dkv = torch.randn_like(one.dkv)
+    one.dkv.copy_(dkv); two.dkv.copy_(dkv)
+    torch.testing.assert_close(two.g_enc(0), one.g_enc(0), rtol=1e-5, atol=1e-5)
