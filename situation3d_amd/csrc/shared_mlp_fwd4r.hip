@@ -1,0 +1,4 @@
+// shared_mlp_fwd4r.hip -- mlp_layer_fwd_kernel's instances with 128 output channels per workgroup, ragged shapes (shared_mlp_fwd.h)
+#include "shared_mlp_fwd.h"
+
+SIG3D_MLP_FWD_INSTANCES(4, 1)
