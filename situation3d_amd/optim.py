@@ -606,5 +606,8 @@ class FlatAdamW(torch.optim.Optimizer):
         # weight decay sits in the static chunk table; learning rate in the device scalar
         for k, pi in enumerate(self._owners):
             self._static["wd"][k] = self.param_groups[self._params[pi][1]]["weight_decay"]
+        # tables a captured graph replays (memcpy nodes re-read their pinned staging buffers) stay allocated; a graph
+        # captured before this call keeps the weight decay it was captured with -- rebuild the step after loading
+        self._retired = self.__dict__.get("_retired", []) + [v for v in self._flat_tables.values() if v[3]]
         self._flat_tables.clear()
         self.sync_lr()
