@@ -1111,6 +1111,7 @@ extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const f
   SIG3D_REQUIRE(work != nullptr && work_bytes >= sig3d_fps_blocks_workspace_bytes(b, n),
                 "workspace smaller than sig3d_fps_blocks_workspace_bytes(b, n)");
   SIG3D_REQUIRE(((uintptr_t)work & 15u) == 0, "workspace must be 16-byte aligned");
+  SIG3D_REQUIRE(waves == 0 || waves == 4 || waves == 8 || waves == 16, "waves must be 0 (default), 4, 8 or 16");
   if (n <= 8192 || n > 196608)
     return sig3d_furthest_point_sampling(b, n, m, dataset, (float *)work, idxs, stream_);
   const int L = ref_opt_n_threads_log2(n);
@@ -1125,7 +1126,6 @@ extern "C" int sig3d_furthest_point_sampling_blocks(int b, int n, int m, const f
   // choice between latency and footprint: 16 waves finish 2047 rounds over 40 000 points in 3.6 ms
   // but hold four wave slots per SIMD of their CU (+0.27 ms on a training step that runs beside them); 4 waves take
   // 6.1 ms and cost the step nothing.  0 = 4.
-  SIG3D_REQUIRE(waves == 0 || waves == 4 || waves == 8 || waves == 16, "waves must be 0 (default), 4, 8 or 16");
 #define SIG3D_FPSB(NWV, MBV, PPLV, UV)                                                                              \
   do {                                                                                                              \
     SIG3D_REQUIRE(nblocks <= 64L * NWV * MBV, "block-list FPS: more blocks than managing lanes");                    \

@@ -294,6 +294,45 @@ def test_ball_query_levels_workspace_is_host_arithmetic():
     assert lib.sig3d_ball_query_levels_workspace_bytes(0, 1, stack) == 0
 
 
+def test_block_list_fps_and_level_grouping_check_their_arguments_before_any_launch():
+    """The two entry points of round 6 refuse an inconsistent call on the host, before a device pointer is touched
+    (the reference raises through AT_ASSERT / TORCH_CHECK before its launch, sampling.cpp:9-12, group_points.cpp:9-12);
+    the FPS work space is host arithmetic: rows {x, y, z, key} + one distance per padded point."""
+    import ctypes
+    from situation3d_amd import _lib
+    lib = _lib.load()
+    ws = lib.sig3d_fps_blocks_workspace_bytes
+    assert ws(8, 40000) == 8 * 40000 * 20 and ws(1, 40001) == 40064 * 20        # padded to whole 64-point blocks
+    assert ws(0, 40000) == 0 and ws(-1, 5) == -1
+    fps = lib.sig3d_furthest_point_sampling_blocks
+    P = ctypes.c_void_p
+    assert fps(0, 40000, 2048, P(64), P(0), 0, 0, P(64), None) == 0              # empty batch: nothing to do
+    assert fps(1, 40000, 0, P(64), P(0), 0, 0, P(64), None) == 0                 # m = 0 (sampling_gpu.cu:73)
+    assert fps(1, 40000, 2048, P(64), P(0), 0, 0, P(64), None) != 0 and b"workspace" in lib.sig3d_last_error()
+    assert fps(1, 40000, 2048, P(64), P(4096), ws(1, 40000) - 1, 0, P(64), None) != 0
+    assert fps(1, 40000, 2048, P(64), P(4100), ws(1, 40000), 0, P(64), None) != 0 and b"aligned" in lib.sig3d_last_error()
+    assert fps(1, 40000, 2048, P(64), P(4096), ws(1, 40000), 5, P(64), None) != 0 and b"waves" in lib.sig3d_last_error()
+    assert fps(1, -1, 2048, P(64), P(4096), 1 << 20, 0, P(64), None) != 0
+
+    grp = lib.sig3d_query_group_levels
+    lv = (_lib.GroupLevel * 5)()
+    for q in lv:
+        q.n, q.m, q.c, q.ld, q.nsample, q.point_major, q.use_xyz, q.normalize_xyz = 2048, 1024, 128, 128, 32, 1, 1, 1
+        q.radius = 0.4
+        q.xyz = q.new_xyz = q.features = q.idx = q.out = 4096
+    assert grp(0, 4, lv, None) == 0                                              # empty batch
+    assert grp(8, 5, lv, None) != 0 and b"1 to 4 levels" in lib.sig3d_last_error()
+    assert grp(8, 0, lv, None) != 0
+    lv[1].c, lv[1].use_xyz = 0, 0
+    assert grp(8, 2, lv, None) != 0 and b"Cannot have not features" in lib.sig3d_last_error()   # pointnet2_utils.py:368
+    lv[1].c, lv[1].use_xyz, lv[1].ld = 128, 1, 126
+    assert grp(8, 2, lv, None) != 0 and b"point-major" in lib.sig3d_last_error()
+    lv[1].ld, lv[1].point_major, lv[1].nsample = 128, 0, 30
+    assert grp(8, 2, lv, None) != 0 and b"nsample % 4" in lib.sig3d_last_error()
+    lv[1].nsample, lv[1].m = 64, 1 << 26
+    assert grp(8, 2, lv, None) != 0 and b"too large" in lib.sig3d_last_error()
+
+
 def test_storage_layout_keeps_two_arenas_when_the_backward_pass_is_cut_inside_the_qformer():
     """trainer.storage_layout: the order FlatAdamW lays the parameters out in.  One arena: every kind runs over all
     layers (the layer-batched weight-gradient buffers are slices of the flat gradients).  qf_cut = k: the layers below
