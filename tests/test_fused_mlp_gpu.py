@@ -329,7 +329,7 @@ def test_sa_level_without_the_grouped_tensor_matches_the_stored_form(mode, monke
     assert "sig3d_mlp_layer0_gather_fwd" in calls
     if mode == "compact":   # no grouped tensor in the forward pass; the backward pass re-materialises the few MB of
         # DISTINCT neighbours for the streaming weight gradient (recompute in backward) or,
-        # with SIG3D_DW_REGROUP=0, gathers them inside the weight-gradient kernel; the input gradient is scattered
+        # with fused_mlp.DW_REGROUP = False, gathers them inside the weight-gradient kernel; the input gradient is scattered
         fwd_end = calls.index("sig3d_bn_relu_maxpool_compact") if "sig3d_bn_relu_maxpool_compact" in calls else \
             max(i for i, nm in enumerate(calls) if nm.startswith("sig3d_bn_relu_maxpool"))
         assert not any(nm.startswith("sig3d_query_group") for nm in calls[:fwd_end + 1])
