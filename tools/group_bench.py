@@ -1,5 +1,4 @@
-"""query_group_fused at the four SA shapes of the bench (per-level time and achieved HBM rate).
-SIG3D_GROUP_LDS=0 forces the direct-gather kernel for the small levels."""
+"""query_group_fused at the four SA shapes of the bench (per-level time and achieved HBM rate)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
