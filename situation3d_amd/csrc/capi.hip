@@ -163,7 +163,7 @@ extern "C" int sig3d_whereami(unsigned int *slots, int blocks, int threads, int 
 // (tools/ab_step.py with SIG3D_PROBE_SPIN_US / SIG3D_PROBE_SPIN_SHAPE)
 namespace {
 template <int NV>
-__global__ void hold_kernel(float *sink, unsigned long long hold_ticks) {
+__global__ __launch_bounds__(NV > 128 ? 256 : 1024) void hold_kernel(float *sink, unsigned long long hold_ticks) {
   extern __shared__ float hold_lds[];
   float v[NV > 0 ? NV : 1];
 #pragma unroll
@@ -185,6 +185,8 @@ __global__ void hold_kernel(float *sink, unsigned long long hold_ticks) {
 extern "C" int sig3d_hold(float *sink, int blocks, int threads, int hold_us, int vgprs, int lds_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SIG3D_REQUIRE(sink != nullptr && blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 4, "bad arguments");
+  // (without the bound a 1024-thread launch caps a lane at 128 registers and the 220-register variant spills to scratch)
+  SIG3D_REQUIRE(vgprs < 200 || threads <= 256, "more than 128 live registers per lane need workgroups of at most 256 threads");
   const unsigned long long ticks = (unsigned long long)hold_us * 100ull;
   if (lds_bytes > 48 * 1024) {
     SIG3D_HIP_TRY(hipFuncSetAttribute((const void *)hold_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
