@@ -322,6 +322,27 @@ def cpu_baseline(model, seed):
             "answer_scores_max_abs_diff": float("%.3g" % scores_diff)}
 
 
+# The sources that decide which launches the ball-query / grouping pair consists of and what they move: its two kernel
+# files, the distinct-neighbour lists the compact grouping reads, the helpers both include, the set-abstraction modules'
+# Python (which levels group at all) and the geometry plan.  (Until late round 6 every file under csrc/ counted: a comment in
+# a GEMM header marked the pair's counters stale.)
+PAIR_SOURCES = ("situation3d_amd/csrc/ball_query.hip", "situation3d_amd/csrc/group_points.hip",
+                "situation3d_amd/csrc/compact.hip", "situation3d_amd/csrc/sig3d_common.h",
+                "situation3d_amd/pointnet2/", "situation3d_amd/geometry.py")
+
+
+def pair_traffic_is_stale(source_hashes, root=None):
+    """source_hashes: {path: sha256[:16]} stored with the PMC counters (tools/pmc_traffic.py).  True when one of the pair's
+    sources is missing or differs from the tree the counters were read in (by content: there is no git on the GPU box)."""
+    import hashlib
+    root = ROOT if root is None else root
+    mine = {f: h for f, h in source_hashes.items() if f.startswith(PAIR_SOURCES)}
+    if not mine:
+        return True
+    return any(not os.path.exists(os.path.join(root, f)) or
+               hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest()[:16] != h for f, h in mine.items())
+
+
 TIMED_ENTRY_POINTS = ["sig3d_query_group_fused", "sig3d_query_group_fused_pm", "sig3d_query_group_compact",
                       "sig3d_transpose_cn", "sig3d_adamw_table", "sig3d_adamw_flat", "sig3d_ball_query",
                       "sig3d_ball_query_grid", "sig3d_ball_query_levels", "sig3d_ball_query_levels_ex",
@@ -784,11 +805,7 @@ def main():
             # geometry plan) differs from the tree the counters were read in; by content hash (no git on the GPU box),
             # null for files of rounds that stored no hashes
             if j.get("source_hashes"):
-                import hashlib
-                traffic_stale = any(
-                    not os.path.exists(os.path.join(ROOT, f)) or
-                    hashlib.sha256(open(os.path.join(ROOT, f), "rb").read()).hexdigest()[:16] != h
-                    for f, h in j["source_hashes"].items())
+                traffic_stale = pair_traffic_is_stale(j["source_hashes"])
         out = {
             "metric": "QA samples/sec fwd+bwd (SQA3D, 40k pts, B=8)",
             "value": round(world * BATCH * args.steps / dt, 3),

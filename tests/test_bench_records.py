@@ -78,3 +78,23 @@ def test_the_cut_is_cheaper_than_one_cut_in_the_committed_pair():
     assert {"N=2", "N=4", "N=8"} <= set(forms)
     for at in forms.values():
         assert at["cut"]["exposed_ms"] <= at["uncut"]["exposed_ms"] and at["cut"]["wire_ms"] == at["uncut"]["wire_ms"]
+
+
+def test_the_pair_counters_were_read_in_a_tree_whose_pair_sources_are_the_head_s():
+    """roofline.traffic comes from profiles/*_pmc_group_pair.json; bench.py marks it stale when a source that decides the
+    pair's launches changed after the counters were read.  The committed counters must not be stale against this tree, and
+    the rule must notice a change in one of the pair's files and ignore one elsewhere."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_group_pair.json"))
+    hashes = json.load(open(os.path.join(ROOT, "profiles", pmcs[-1])))["source_hashes"]
+    assert any(f.endswith("ball_query.hip") for f in hashes) and any(f.endswith("group_points.hip") for f in hashes)
+    assert bench.pair_traffic_is_stale(hashes) is False
+    touched = dict(hashes)
+    touched["situation3d_amd/csrc/group_points.hip"] = "0" * 16
+    assert bench.pair_traffic_is_stale(touched) is True
+    elsewhere = dict(hashes)
+    elsewhere["situation3d_amd/csrc/gemmp_core.h"] = "0" * 16
+    assert bench.pair_traffic_is_stale(elsewhere) is False
+    assert bench.pair_traffic_is_stale({"situation3d_amd/csrc/gemmp_core.h": "0" * 16}) is True    # nothing to compare

@@ -39,6 +39,7 @@ for k in sorted(fe):
 fetch = sum(r["fetch_bytes_per_step"] for r in rows.values())
 write = sum(r["write_bytes_per_step"] for r in rows.values())
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+# every source is hashed; bench.pair_traffic_is_stale compares the ones that decide the pair (bench.PAIR_SOURCES)
 WATCHED = ("situation3d_amd/csrc/*.hip", "situation3d_amd/csrc/*.h", "situation3d_amd/pointnet2/*.py", "situation3d_amd/geometry.py")
 
 
