@@ -22,7 +22,8 @@ int sig3d_stream_destroy(void *stream);
 int sig3d_whereami(unsigned int *slots, int blocks, int threads, int hold_us, void *stream);
 
 /* blocks x threads workgroups that keep ~vgprs (0 / 100 / 220) registers per lane and lds_bytes of LDS while they
- * sleep for hold_us: the cost of a resident footprint to another stream's kernels. */
+ * sleep for hold_us: the cost of a resident footprint to another stream's kernels.  The
+ * 220-register variant needs threads <= 256 (a lane of a larger workgroup has 128). */
 int sig3d_hold(float *sink, int blocks, int threads, int hold_us, int vgprs, int lds_bytes, void *stream);
 
 #ifdef __cplusplus
