@@ -98,3 +98,28 @@ def test_the_pair_counters_were_read_in_a_tree_whose_pair_sources_are_the_head_s
     elsewhere["situation3d_amd/csrc/gemmp_core.h"] = "0" * 16
     assert bench.pair_traffic_is_stale(elsewhere) is False
     assert bench.pair_traffic_is_stale({"situation3d_amd/csrc/gemmp_core.h": "0" * 16}) is True    # nothing to compare
+
+
+def test_algorithmic_bytes_are_survey_8d_s():
+    """SURVEY.md 8(d) fixes the numerator of every `achieved`: ball_query B(12N + 12M + 4 M ns), group_points(C)
+    B(4CN + 4 M ns + 4C M ns); at B = 8 over the suggested stack that is 8.23 / 1.34 / 0.41 / 0.20 MB of ball query and
+    314.8 MB for the pair.  bench.py's functions must give those figures (the fused launch reads the index list once for
+    both groups, so it counts 4 M ns less than the two groups apart), and the committed line's op-level pair must be them."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    b = 8
+    levels = [(40000, 2048, 64, 3), (2048, 1024, 32, 128), (1024, 512, 16, 256), (512, 256, 16, 256)]
+
+    def group(c, n, m, ns):
+        return b * (4 * c * n + 4 * m * ns + 4 * c * m * ns)
+
+    bq = [bench.ball_query_algorithmic_bytes(b, n, m, ns) for n, m, ns, _ in levels]
+    assert [round(x / 1e6, 2) for x in bq] == [8.23, 1.34, 0.41, 0.20]
+    apart = [(group(3, n, m, ns), group(c, n, m, ns)) for n, m, ns, c in levels]
+    assert [(round(x / 1e6, 1), round(f / 1e6, 1)) for x, f in apart] == [(20.6, 20.6), (4.4, 143.7), (1.1, 75.8), (0.6, 37.9)]
+    assert round((sum(bq) + sum(x + f for x, f in apart)) / 1e6, 1) == 314.8
+    fused = [bench.group_algorithmic_bytes(b, n, m, ns, c) for n, m, ns, c in levels]
+    assert all(x + f - g == b * 4 * m * ns for (x, f), g, (n, m, ns, c) in zip(apart, fused, levels))
+    ops = _line(RECORDS[0])["roofline_ops"]
+    assert ops["algorithmic_bytes"] == sum(bq) + sum(fused)
