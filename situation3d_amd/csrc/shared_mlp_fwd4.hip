@@ -1,4 +1,6 @@
 // shared_mlp_fwd4.hip -- mlp_layer_fwd_kernel's instances with 128 output channels per workgroup, full tiles (shared_mlp_fwd.h)
 #include "shared_mlp_fwd.h"
 
+#ifndef SIG3D_MLP_TIMING   // (with the phase timing compiled in, shared_mlp.hip holds every instance itself)
 SIG3D_MLP_FWD_INSTANCES(4, 0)
+#endif
